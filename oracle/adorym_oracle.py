@@ -1,0 +1,686 @@
+"""
+CPU oracle for the Adorym multislice forward + hand-adjoint hot path.
+
+*** TEST INFRASTRUCTURE ONLY ***  Only tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py may import this module -- and there only as the
+checker / the timed CPU baseline, never as the product path.  The product
+(adorym_amd/) must fail loudly if the HIP extension is missing; it never falls
+back to this file.
+
+What this is: a plain-NumPy restatement of the reference algorithm
+(mdw771/adorym, PyTorch-CPU backend) for the path named in BASELINE.json:
+rotation lookup + bilinear gather, zero-pad + tile extraction, multislice
+Fresnel propagation, far-field / near-field magnitude loss, the hand-derived
+adjoint that replaces ``torch.autograd.grad``, L1/TV regularisers, Adam / GD
+updates and the DP-mode batching order.  Each function cites the reference
+``file:line`` it follows (paths relative to the reference repo root).
+
+Parity pinning: the reference's own test-suite holds no golden vectors for
+this path (one smoke test without assertions whose data file is absent), so
+this oracle is pinned against outputs of the *imported reference itself*
+(PyTorch CPU, fp64 and fp32) captured in this container by
+``tests/golden/gen_goldens.py`` and committed as ``tests/golden/*.npz``;
+``tests/test_oracle_vs_golden.py`` checks every function below against them.
+
+The arithmetic type is selectable (``dtype='float64'`` = the fp64 oracle,
+``'float32'`` = the timed CPU baseline that mirrors the reference's default).
+"""
+from __future__ import annotations
+
+import math
+import numpy as np
+
+# adorym/constants.py:90 -- the reference uses this truncated value everywhere on the
+# path (propagate.py:20 star-imports it); ptychography.py:52 redefines PI = 3.1415927 but
+# only uses it as the default theta_end.
+PI = 3.14159265359
+
+
+def _cdtype(dtype):
+    return np.complex128 if np.dtype(dtype) == np.float64 else np.complex64
+
+
+# --------------------------------------------------------------------------------------
+# R4  Fresnel transfer function
+# --------------------------------------------------------------------------------------
+def gen_freq_mesh(voxel_nm, shape):
+    """adorym/propagate.py:54-60."""
+    u = np.fft.fftfreq(shape[0])
+    v = np.fft.fftfreq(shape[1])
+    vv, uu = np.meshgrid(v, u)
+    vv = vv / voxel_nm[1]
+    uu = uu / voxel_nm[0]
+    return uu, vv
+
+
+def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, fresnel_approx=True, sign_convention=1):
+    """adorym/propagate.py:62-81.  Returns complex128 [Py, Px] (unshifted)."""
+    u, v = gen_freq_mesh(voxel_nm, grid_shape[0:2])
+    if fresnel_approx:
+        H = np.exp(-sign_convention * 1j * PI * lmbda_nm * dist_nm * (u ** 2 + v ** 2))
+    else:
+        quad = 1 - lmbda_nm ** 2 * (u ** 2 + v ** 2)
+        quad_inner = np.clip(quad, 0, None)
+        quad_mask = (quad > 0)
+        H = np.exp(sign_convention * 1j * 2 * PI * dist_nm / lmbda_nm * np.sqrt(quad_inner))
+        H = H * quad_mask
+    return H
+
+
+# --------------------------------------------------------------------------------------
+# R1  rotation lookup table (fp16)
+# --------------------------------------------------------------------------------------
+def rotation_coords(array_size, theta, dtype='float32'):
+    """
+    adorym/util.py:446-477 + 492-516 (save_rotation_lookup), axis=0.
+
+    Returns the fp16 table ``[X*Z, 2]`` of source coordinates ``(x_old, z_old)`` for every
+    rotated-frame voxel, flat index ``x*Z + z``.  The reference evaluates this in torch at the
+    dtype chosen by w.create_variable / w.create_constant (wrappers.py:121-176): float32 by
+    default, float64 under run_float64 -- and stores float16 either way.
+    NOTE the reference subtracts the *other* axis' centre (util.py:459-460) -- reproduced.
+    """
+    dt = np.dtype(dtype).type
+    Y, X, Z = array_size
+    cx = dt((X - 1) / 2)
+    cz = dt((Z - 1) / 2)
+    # coords_ls[0]: this_axis=1 (X): repeat over Z, minus image_center[other_axis=2]
+    xc = np.repeat(np.arange(X), Z).astype(np.float64) - (Z - 1) / 2
+    # coords_ls[1]: this_axis=2 (Z): tile over X, minus image_center[other_axis=1]
+    zc = np.tile(np.arange(Z), X).astype(np.float64) - (X - 1) / 2
+    coord_new = np.stack([xc, zc]).astype(dt)
+    th = dt(theta)
+    c = np.cos(th, dtype=dt)
+    s = np.sin(th, dtype=dt)
+    # torch.matmul [2,2]x[2,N]: two-term dot products, one rounding per product and per add
+    # (no FMA contraction on the CPU path).
+    old0 = (c * coord_new[0]).astype(dt) + ((-s) * coord_new[1]).astype(dt)
+    old1 = (s * coord_new[0]).astype(dt) + (c * coord_new[1]).astype(dt)
+    coord1_old = (old0 + cx).astype(dt)   # + image_center[1]
+    coord2_old = (old1 + cz).astype(dt)   # + image_center[2]
+    return np.stack([coord1_old, coord2_old], axis=1).astype(np.float16)
+
+
+def _sample_setup(coords_fp16, X, Z, dtype):
+    """
+    Coordinate pipeline of apply_rotation -> w.grid_sample (util.py:536-552,
+    wrappers.py:1105-1147) followed by torch's grid_sampler (align_corners=False,
+    padding_mode='border', bilinear).
+
+    coords fp16 -> float64 (util.py:539-540) -> normalised in float64
+    ``-1 + 2 g / s + 1 / s`` (wrappers.py:1137; s = arr.shape[2:] = (X, Z) applied to the
+    flipped (z, x) pair -- harmless for cubic arrays, reproduced as written) -> cast to the
+    array dtype (wrappers.py:1141) -> un-normalised ``((g + 1) * size - 1) / 2`` in that dtype.
+    """
+    dt = np.dtype(dtype)
+    c = coords_fp16.astype(np.float64)
+    x_old = c[:, 0]
+    z_old = c[:, 1]
+    # after tc.flip: grid[..., 0] = z_old (torch "x" = W axis = Z), grid[..., 1] = x_old (H axis = X)
+    gz = (-1 + 2. * z_old / X + 1. / X).astype(dt)   # divided by arr_shape[0] == X (sic)
+    gx = (-1 + 2. * x_old / Z + 1. / Z).astype(dt)   # divided by arr_shape[1] == Z (sic)
+    iz = ((gz + dt.type(1)) * dt.type(Z) - dt.type(1)) / dt.type(2)
+    ix = ((gx + dt.type(1)) * dt.type(X) - dt.type(1)) / dt.type(2)
+    iz = np.minimum(dt.type(Z - 1), np.maximum(iz, dt.type(0)))
+    ix = np.minimum(dt.type(X - 1), np.maximum(ix, dt.type(0)))
+    iz0 = np.floor(iz)
+    ix0 = np.floor(ix)
+    tz = (iz - iz0).astype(dt)
+    tx = (ix - ix0).astype(dt)
+    iz0 = iz0.astype(np.int64)
+    ix0 = ix0.astype(np.int64)
+    iz1 = iz0 + 1
+    ix1 = ix0 + 1
+    one = dt.type(1)
+    # torch weights: nw = (ix_se - ix) * (iy_se - iy) ... with x = W (z here), y = H (x here)
+    w00 = (one - tx) * (one - tz)   # (ix0, iz0)
+    w01 = (one - tx) * tz           # (ix0, iz1)
+    w10 = tx * (one - tz)           # (ix1, iz0)
+    w11 = tx * tz                   # (ix1, iz1)
+    v_x1 = ix1 <= X - 1
+    v_z1 = iz1 <= Z - 1
+    return ix0, ix1, iz0, iz1, w00, w01, w10, w11, v_x1, v_z1
+
+
+def rotate_fwd(obj, coords_fp16, dtype=None):
+    """R2: apply_rotation (util.py:536-552).  obj [Y,X,Z,C] -> rotated [Y,X,Z,C]."""
+    dtype = obj.dtype if dtype is None else dtype
+    Y, X, Z, C = obj.shape
+    ix0, ix1, iz0, iz1, w00, w01, w10, w11, vx1, vz1 = _sample_setup(coords_fp16, X, Z, dtype)
+    ix1c = np.minimum(ix1, X - 1)
+    iz1c = np.minimum(iz1, Z - 1)
+    o = obj.astype(dtype, copy=False)
+    w01 = np.where(vz1, w01, 0)
+    w10 = np.where(vx1, w10, 0)
+    w11 = np.where(vx1 & vz1, w11, 0)
+    out = (o[:, ix0, iz0, :] * w00[None, :, None] + o[:, ix0, iz1c, :] * w01[None, :, None]
+           + o[:, ix1c, iz0, :] * w10[None, :, None] + o[:, ix1c, iz1c, :] * w11[None, :, None])
+    return out.reshape(Y, X, Z, C).astype(dtype, copy=False)
+
+
+def rotate_adj(grad_rot, coords_fp16, dtype=None):
+    """R2 adjoint (autograd of grid_sampler_2d): scatter-add of the four weighted corners."""
+    dtype = grad_rot.dtype if dtype is None else dtype
+    Y, X, Z, C = grad_rot.shape
+    ix0, ix1, iz0, iz1, w00, w01, w10, w11, vx1, vz1 = _sample_setup(coords_fp16, X, Z, dtype)
+    g = grad_rot.reshape(Y, X * Z, C).astype(dtype, copy=False)
+    out = np.zeros((Y, X * Z, C), dtype=dtype)
+    flat = lambda a, b: a * Z + b
+    for (ia, ib, ww, valid) in ((ix0, iz0, w00, None), (ix0, iz1, w01, vz1),
+                                (ix1, iz0, w10, vx1), (ix1, iz1, w11, vx1 & vz1)):
+        if valid is None:
+            idx = flat(ia, ib)
+            contrib = g * ww[None, :, None]
+        else:
+            idx = flat(ia[valid], ib[valid])
+            contrib = g[:, valid, :] * ww[valid][None, :, None]
+        for y in range(Y):
+            np.add.at(out[y], idx, contrib[y])
+    return out.reshape(Y, X, Z, C)
+
+
+# --------------------------------------------------------------------------------------
+# R3  padding + tile extraction
+# --------------------------------------------------------------------------------------
+def calculate_pad_len(this_obj_size, probe_pos, probe_size):
+    """adorym/util.py:1374-1406 (both unknown_type branches are identical)."""
+    probe_pos = np.asarray(probe_pos)
+    pad_arr = np.array([[0, 0], [0, 0]])
+    if min(probe_pos[:, 0]) < 0:
+        pad_arr[0, 0] = -int(min(probe_pos[:, 0]))
+    if max(probe_pos[:, 0]) + probe_size[0] > this_obj_size[0]:
+        pad_arr[0, 1] = int(max(probe_pos[:, 0])) + probe_size[0] - this_obj_size[0]
+    if min(probe_pos[:, 1]) < 0:
+        pad_arr[1, 0] = -int(min(probe_pos[:, 1]))
+    if max(probe_pos[:, 1]) + probe_size[1] > this_obj_size[1]:
+        pad_arr[1, 1] = int(max(probe_pos[:, 1])) + probe_size[1] - this_obj_size[1]
+    return pad_arr
+
+
+def extract_tiles(obj_rot, pos_batch, probe_size):
+    """pad_object (util.py:1327-1351, delta_beta: zero pad) + the tile stack of
+    forward_model.py:313-331.  Returns tiles [B, Py, Px, S, 2] and pad_arr."""
+    pos = np.round(np.asarray(pos_batch)).astype(int)            # forward_model.py:248
+    pad = calculate_pad_len(obj_rot.shape[:3], pos, probe_size)
+    o = np.pad(obj_rot, [tuple(pad[0]), tuple(pad[1]), (0, 0), (0, 0)], mode='constant')
+    tiles = np.stack([o[p[0] + pad[0, 0]: p[0] + pad[0, 0] + probe_size[0],
+                        p[1] + pad[1, 0]: p[1] + pad[1, 0] + probe_size[1]] for p in pos])
+    return tiles, pad
+
+
+def scatter_tiles_adj(grad_tiles, pos_batch, obj_shape):
+    """Adjoint of extract_tiles: overlap-add the tile gradients, dropping the pad region."""
+    pos = np.round(np.asarray(pos_batch)).astype(int)
+    B, Py, Px = grad_tiles.shape[:3]
+    Y, X = obj_shape[:2]
+    pad = calculate_pad_len(obj_shape[:3], pos, (Py, Px))
+    buf = np.zeros((Y + pad[0].sum(), X + pad[1].sum()) + tuple(grad_tiles.shape[3:]), dtype=grad_tiles.dtype)
+    for b, p in enumerate(pos):
+        buf[p[0] + pad[0, 0]: p[0] + pad[0, 0] + Py, p[1] + pad[1, 0]: p[1] + pad[1, 0] + Px] += grad_tiles[b]
+    return buf[pad[0, 0]: pad[0, 0] + Y, pad[1, 0]: pad[1, 0] + X]
+
+
+# --------------------------------------------------------------------------------------
+# R5-R8  multislice forward, detector-plane transform, loss
+# --------------------------------------------------------------------------------------
+class Physics(object):
+    """Static parameters of multislice_propagate_batch (propagate.py:131-153, 196-207)."""
+
+    def __init__(self, probe_size, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
+                 fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None,
+                 scale_ri_by_k=True):
+        self.probe_size = tuple(int(p) for p in probe_size)
+        self.energy_ev = float(energy_ev)
+        self.psize_cm = float(psize_cm)
+        self.voxel_nm = np.array([psize_cm] * 3) * 1.e7            # propagate.py:146
+        self.lmbda_nm = 1240. / energy_ev                            # propagate.py:148
+        self.delta_nm = self.voxel_nm[-1]
+        self.binning = int(binning)
+        self.sigma = int(sign_convention)
+        self.normalize_fft = bool(normalize_fft)
+        self.free_prop_cm = free_prop_cm
+        self.k1 = 2. * PI * self.delta_nm / self.lmbda_nm if scale_ri_by_k else 1.   # propagate.py:215
+        if kernel is None:
+            kernel = get_kernel(self.delta_nm * binning, self.lmbda_nm, self.voxel_nm, self.probe_size,
+                                fresnel_approx=fresnel_approx, sign_convention=sign_convention)
+        self.h = np.asarray(kernel)
+        if free_prop_cm in (0, None):
+            self.det_mode = 'none'
+            self.h_free = None
+        elif isinstance(free_prop_cm, str) and free_prop_cm == 'inf':
+            self.det_mode = 'far'
+            self.h_free = None
+        else:
+            # fresnel_propagate (propagate.py:537-553) always uses the Fresnel-approx kernel
+            self.det_mode = 'fresnel'
+            self.h_free = get_kernel(free_prop_cm * 1e7, self.lmbda_nm, self.voxel_nm, self.probe_size,
+                                     sign_convention=sign_convention)
+
+    def h_cast(self, dtype):
+        """h_real/h_imag are cast separately to the working dtype (propagate.py:202-204)."""
+        dt = np.dtype(dtype)
+        return (self.h.real.astype(dt) + 1j * self.h.imag.astype(dt)).astype(_cdtype(dt))
+
+    def h_free_cast(self, dtype):
+        dt = np.dtype(dtype)
+        return (self.h_free.real.astype(dt) + 1j * self.h_free.imag.astype(dt)).astype(_cdtype(dt))
+
+
+def _fftshift2(a):
+    """w.fftshift (wrappers.py:796-813) == np.fft.fftshift on the last two axes."""
+    return np.fft.fftshift(a, axes=(-2, -1))
+
+
+def _detector_fwd(psi, phys, dtype):
+    """propagate.py:263-280 (+ wrappers.py:725-770)."""
+    norm = 'ortho' if phys.normalize_fft else None
+    if phys.det_mode == 'none':
+        return psi
+    if phys.det_mode == 'far':
+        if phys.sigma == 1:
+            return _fftshift2(np.fft.fft2(psi, norm=norm))
+        return _fftshift2(np.fft.ifft2(psi, norm=norm))
+    return np.fft.ifft2(np.fft.fft2(psi) * phys.h_free_cast(dtype))
+
+
+def _detector_adj(G, phys, dtype):
+    """Adjoint of _detector_fwd for the convention G := dL/dRe + i dL/dIm."""
+    N = G.shape[-2] * G.shape[-1]
+    if phys.det_mode == 'none':
+        return G
+    if phys.det_mode == 'far':
+        G = np.fft.ifftshift(G, axes=(-2, -1))
+        if phys.normalize_fft:
+            return np.fft.ifft2(G, norm='ortho') if phys.sigma == 1 else np.fft.fft2(G, norm='ortho')
+        if phys.sigma == 1:
+            return np.fft.ifft2(G) * N        # (unnormalised fft2)^H
+        return np.fft.fft2(G) / N             # (ifft2 with 1/N)^H
+    return np.fft.ifft2(np.fft.fft2(G) * np.conj(phys.h_free_cast(dtype)))
+
+
+def _slice_sums(tiles, i_step, binning):
+    S = tiles.shape[3]
+    lo = i_step * binning
+    hi = min(lo + binning, S)
+    if hi - lo == 1:
+        return tiles[:, :, :, lo, 0], tiles[:, :, :, lo, 1], lo, hi
+    return tiles[:, :, :, lo:hi, 0].sum(axis=3), tiles[:, :, :, lo:hi, 1].sum(axis=3), lo, hi
+
+
+def _modulator(delta_s, beta_s, phys, dtype):
+    """w.exp_complex(-k1*beta, -sigma*k1*delta) (propagate.py:241, wrappers.py:600-608)."""
+    dt = np.dtype(dtype)
+    k1 = dt.type(phys.k1)
+    e = np.exp(-k1 * beta_s)
+    ph = -dt.type(phys.sigma) * k1 * delta_s
+    return (e * np.cos(ph) + 1j * (e * np.sin(ph))).astype(_cdtype(dt))
+
+
+def multislice_forward(tiles, probe, phys, dtype='float64', keep=False):
+    """
+    multislice_propagate_batch, non-projection delta_beta branch (propagate.py:195-270).
+
+    tiles [B,Py,Px,S,2]; probe complex [Py,Px] (one mode).  Returns the detector-plane
+    complex field [B,Py,Px] (and, with keep=True, the list of post-modulation fields psi'_s).
+    """
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    tiles = tiles.astype(dt, copy=False)
+    B = tiles.shape[0]
+    S = tiles.shape[3]
+    n_steps = int(np.ceil(S / phys.binning))
+    h = phys.h_cast(dt)
+    psi = np.broadcast_to(probe.astype(cdt), (B,) + probe.shape).copy()
+    kept = []
+    for i in range(n_steps):
+        d, b, lo, hi = _slice_sums(tiles, i, phys.binning)
+        c = _modulator(d, b, phys, dt)
+        psi = (psi * c).astype(cdt)
+        if keep:
+            kept.append(psi)
+        if i < n_steps - 1:
+            psi = np.fft.ifft2(np.fft.fft2(psi) * h).astype(cdt)
+    out = _detector_fwd(psi, phys, dt).astype(cdt)
+    return (out, kept) if keep else out
+
+
+def predict(tiles, probes, phys, dtype='float64'):
+    """forward_model.py:337-375: |Psi| for one mode, sqrt(sum_m |Psi_m|^2) for several."""
+    probes = np.asarray(probes)
+    if probes.ndim == 2:
+        probes = probes[None]
+    fields = [multislice_forward(tiles, p, phys, dtype) for p in probes]
+    if len(fields) == 1:
+        return np.abs(fields[0]), fields
+    inten = sum((f.real ** 2 + f.imag ** 2) for f in fields)
+    return np.sqrt(inten), fields
+
+
+def target_magnitude(meas, raw_data_type='magnitude'):
+    """forward_model.py:113-119 + 88-93: abs(prj) (and sqrt for intensity data)."""
+    t = np.abs(meas)
+    return np.sqrt(t) if raw_data_type == 'intensity' else t
+
+
+def mismatch_loss(pred, meas, loss_function_type='lsq', raw_data_type='magnitude', poisson_multiplier=1.):
+    """ForwardModel.get_mismatch_loss (forward_model.py:88-103)."""
+    if loss_function_type == 'lsq':
+        return np.mean((pred - target_magnitude(meas, raw_data_type)) ** 2)
+    a = np.abs(meas) ** 2 if raw_data_type == 'magnitude' else np.abs(meas)
+    return np.mean(pred ** 2 * poisson_multiplier - a * poisson_multiplier * np.log(pred ** 2 * poisson_multiplier))
+
+
+def _dloss_dpred(pred, meas, loss_function_type, raw_data_type, poisson_multiplier):
+    n = pred.size
+    if loss_function_type == 'lsq':
+        return 2. * (pred - target_magnitude(meas, raw_data_type)) / n
+    a = np.abs(meas) ** 2 if raw_data_type == 'magnitude' else np.abs(meas)
+    return (2. * pred * poisson_multiplier - a * poisson_multiplier * 2. / pred) / n
+
+
+def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_function_type='lsq',
+                          raw_data_type='magnitude', poisson_multiplier=1.):
+    """
+    Loss + hand-derived gradient w.r.t. the tiles and the probe(s).  Replaces
+    ``torch.autograd.grad`` (wrappers.py:322) over forward_model.py:337-375 +
+    propagate.py:195-270 + forward_model.py:88-103.  SURVEY section 3.4.
+
+    Returns loss, pred [B,Py,Px], grad_tiles [B,Py,Px,S,2], grad_probes complex [M,Py,Px]
+    (real part = dL/dprobe_real, imag part = dL/dprobe_imag).
+    """
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    probes = np.asarray(probes)
+    if probes.ndim == 2:
+        probes = probes[None]
+    tiles = tiles.astype(dt, copy=False)
+    B, Py, Px, S, _ = tiles.shape
+    n_steps = int(np.ceil(S / phys.binning))
+    h = phys.h_cast(dt)
+    fields, kepts = [], []
+    for p in probes:
+        f, k = multislice_forward(tiles, p, phys, dt, keep=True)
+        fields.append(f)
+        kepts.append(k)
+    if len(fields) == 1:
+        pred = np.abs(fields[0])
+    else:
+        pred = np.sqrt(sum((f.real ** 2 + f.imag ** 2) for f in fields))
+    meas = np.asarray(meas).astype(dt, copy=False)
+    loss = mismatch_loss(pred, meas, loss_function_type, raw_data_type, poisson_multiplier)
+    dldp = _dloss_dpred(pred, meas, loss_function_type, raw_data_type, poisson_multiplier).astype(dt)
+    grad_tiles = np.zeros_like(tiles)
+    grad_probes = np.zeros(probes.shape, dtype=cdt)
+    k1 = dt.type(phys.k1)
+    sg = dt.type(phys.sigma)
+    for m, (f, kept) in enumerate(zip(fields, kepts)):
+        with np.errstate(divide='ignore', invalid='ignore'):
+            unit = np.where(pred > 0, f / pred, 0) if len(fields) == 1 else f / pred
+        G = _detector_adj((dldp * unit).astype(cdt), phys, dt).astype(cdt)
+        for i in range(n_steps - 1, -1, -1):
+            d, b, lo, hi = _slice_sums(tiles, i, phys.binning)
+            c = _modulator(d, b, phys, dt)
+            z = np.conj(G) * kept[i]
+            gb = (-k1 * z.real).astype(dt)
+            gd = (sg * k1 * z.imag).astype(dt)
+            grad_tiles[:, :, :, lo:hi, 0] += gd[..., None]
+            grad_tiles[:, :, :, lo:hi, 1] += gb[..., None]
+            G = (G * np.conj(c)).astype(cdt)
+            if i > 0:
+                G = np.fft.ifft2(np.fft.fft2(G) * np.conj(h)).astype(cdt)
+        grad_probes[m] = G.sum(axis=0)
+    return loss, pred, grad_tiles, grad_probes
+
+
+def forward_adjoint_object(obj, coords_fp16, probes, pos_batch, meas, phys, dtype='float64', **loss_kw):
+    """
+    The whole differentiable block of PtychographyModel.get_loss_function
+    (forward_model.py:264-353, 389-401) and its gradient w.r.t. ``obj`` [Y,X,Z,2] and the
+    probes.  ``coords_fp16=None`` means no rotation (two_d_mode / rotate_out_of_loop).
+    """
+    dt = np.dtype(dtype)
+    obj = obj.astype(dt, copy=False)
+    obj_rot = rotate_fwd(obj, coords_fp16, dt) if coords_fp16 is not None else obj
+    probes = np.asarray(probes)
+    psize = probes.shape[-2:]
+    tiles, _ = extract_tiles(obj_rot, pos_batch, psize)
+    loss, pred, gt, gp = forward_adjoint_tiles(tiles, probes, meas, phys, dt, **loss_kw)
+    g_rot = scatter_tiles_adj(gt, pos_batch, obj.shape)
+    g_obj = rotate_adj(g_rot, coords_fp16, dt) if coords_fp16 is not None else g_rot
+    return loss, pred, g_obj, gp
+
+
+# --------------------------------------------------------------------------------------
+# R9  regularisers (value and gradient)
+# --------------------------------------------------------------------------------------
+def l1_value_grad(obj, alpha_d, alpha_b):
+    """L1Regularizer.get_value (regularizers.py:30-46), delta_beta branch."""
+    V = obj[..., 0].size
+    val = 0.
+    g = np.zeros_like(obj)
+    if alpha_d not in (None, 0):
+        val += alpha_d * np.mean(np.abs(obj[..., 0]))
+        g[..., 0] = alpha_d * np.sign(obj[..., 0]) / V
+    if alpha_b not in (None, 0):
+        val += alpha_b * np.mean(np.abs(obj[..., 1]))
+        g[..., 1] = alpha_b * np.sign(obj[..., 1]) / V
+    return val, g
+
+
+def tv_value_grad(obj, gamma):
+    """TVRegularizer.get_value (regularizers.py:95-110) -> total_variation_3d (util.py:1427-1440):
+    sum over the three axes of sum|roll(a,1,ax) - a| / a.size, periodic, per channel."""
+    val = 0.
+    g = np.zeros_like(obj)
+    V = obj[..., 0].size
+    for ch in range(2):
+        a = obj[..., ch]
+        for ax in range(3):
+            d = np.roll(a, 1, axis=ax) - a            # d[i] = a[i-1] - a[i]
+            val += gamma * np.sum(np.abs(d)) / V
+            s = np.sign(d)
+            # d/da[i] of |a[i-1]-a[i]| = -s[i];  of |a[i]-a[i+1]| = +s[i+1]
+            g[..., ch] += gamma * (np.roll(s, -1, axis=ax) - s) / V
+    return val, g
+
+
+# --------------------------------------------------------------------------------------
+# R13-R15  optimisers and constraints
+# --------------------------------------------------------------------------------------
+def adam_step(x, g, m, v, i_batch, step_size=0.001, b1=0.9, b2=0.999, eps=1e-7):
+    """AdamOptimizer.apply_gradient math (optimizers.py:309-318), in x's dtype."""
+    dt = x.dtype.type
+    m = dt(b1) * m
+    m = m + dt(1 - b1) * g
+    v = dt(b2) * v
+    v = v + dt(1 - b2) * (g ** 2)
+    mhat = m / dt(1 - b1 ** (i_batch + 1))
+    vhat = v / dt(1 - b2 ** (i_batch + 1))
+    d = dt(step_size) * mhat / (np.sqrt(vhat) + dt(eps))
+    return (x - d).astype(x.dtype), m.astype(x.dtype), v.astype(x.dtype)
+
+
+def gd_step_size(i_batch, step_size, dynamic_rate=True, first_downrate_iteration=92):
+    """GDOptimizer.apply_gradient schedule (optimizers.py:452-460)."""
+    if dynamic_rate:
+        threshold_iteration = first_downrate_iteration
+        i = 1
+        while threshold_iteration < i_batch:
+            threshold_iteration += first_downrate_iteration * 2 ** i
+            i += 1
+            step_size /= 2.
+    return step_size
+
+
+def gd_step(x, g, i_batch, step_size=0.001, dynamic_rate=True, first_downrate_iteration=92):
+    return (x - x.dtype.type(gd_step_size(i_batch, step_size, dynamic_rate, first_downrate_iteration)) * g).astype(x.dtype)
+
+
+def apply_constraints(x, non_negativity=False, object_type='normal', mask=None):
+    """ptychography.py:1135-1158 (delta_beta) + array_ops.py:239-251."""
+    if non_negativity:
+        x = np.clip(x, 0, None)
+    if object_type == 'absorption_only':
+        x = x.copy(); x[..., 0] *= 0
+    if object_type == 'phase_only':
+        x = x.copy(); x[..., 1] *= 0
+    if mask is not None:
+        x = x * mask[..., None].astype(x.dtype)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# R16  probe initialisation
+# --------------------------------------------------------------------------------------
+def generate_gaussian_map(size, mag_max, mag_sigma, phase_max, phase_sigma):
+    """adorym/util.py:189-195."""
+    py = np.arange(size[0]) - (size[0] - 1.) / 2
+    px = np.arange(size[1]) - (size[1] - 1.) / 2
+    pxx, pyy = np.meshgrid(px, py)
+    map_mag = mag_max * np.exp(-(pxx ** 2 + pyy ** 2) / (2 * mag_sigma ** 2))
+    map_phase = phase_max * np.exp(-(pxx ** 2 + pyy ** 2) / (2 * phase_sigma ** 2))
+    return map_mag, map_phase
+
+
+def gaussian_probe(size, mag_sigma, phase_sigma, phase_max):
+    """initialize_probe, 'gaussian' branch (util.py:201-206)."""
+    mag, ph = generate_gaussian_map(size, 1, mag_sigma, phase_max, phase_sigma)
+    return mag * np.cos(ph) + 1j * mag * np.sin(ph)
+
+
+# --------------------------------------------------------------------------------------
+# R17  DP-mode task list
+# --------------------------------------------------------------------------------------
+def split_tasks(arr, split_size):
+    """adorym/util.py:1629-1635."""
+    res = []
+    ind = 0
+    while ind < len(arr):
+        res.append(arr[ind:min(ind + split_size, len(arr))])
+        ind += split_size
+    return res
+
+
+def epoch_task_list(i_epoch, n_theta, n_pos, minibatch_size, n_ranks=1, update_scheme='immediate',
+                    randomize_probe_pos=False, two_d_mode=False):
+    """
+    ptychography.py:791-847 (distribution_mode=None, common_probe_pos=True).  Uses the legacy
+    global NumPy RNG exactly like the reference (np.random.seed(i_epoch); shuffle; choice).
+    Returns the list of global batches, each an int array [<= n_ranks*mb, 2] of (i_theta, i_pos).
+    """
+    n_tot_per_batch = minibatch_size * n_ranks
+    np.random.seed(i_epoch)
+    if not two_d_mode:
+        theta_ind_ls = np.arange(n_theta)
+        np.random.shuffle(theta_ind_ls)
+    else:
+        theta_ind_ls = np.array([0])
+    ind_list_rand = None
+    for i, i_theta in enumerate(theta_ind_ls):
+        spots_ls = range(n_pos)
+        if randomize_probe_pos:
+            spots_ls = np.random.choice(spots_ls, len(spots_ls), replace=False)
+        if update_scheme == 'immediate' and n_pos % minibatch_size != 0:
+            spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % minibatch_size],
+                                                            minibatch_size - (n_pos % minibatch_size),
+                                                            replace=False))
+        elif update_scheme == 'per angle' and n_pos % n_tot_per_batch != 0:
+            spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % n_tot_per_batch],
+                                                            n_tot_per_batch - (n_pos % n_tot_per_batch),
+                                                            replace=False))
+        if i == 0:
+            ind_list_rand = np.zeros([len(theta_ind_ls) * len(spots_ls), 2], dtype='int32')
+        temp = np.stack([np.array([i_theta] * len(spots_ls)), spots_ls], axis=1)
+        ind_list_rand[i * len(spots_ls):(i + 1) * len(spots_ls), :] = temp
+    return split_tasks(ind_list_rand, n_tot_per_batch)
+
+
+def rank_batch(batches, i_batch, rank, minibatch_size, n_ranks=1):
+    """ptychography.py:901-908: short last batch is topped up from batch 0; each rank takes its
+    contiguous slice; tile indices are sorted."""
+    n_tot = minibatch_size * n_ranks
+    b = batches[i_batch]
+    if len(b) < n_tot:
+        b = np.concatenate([b, batches[0][:n_tot - len(b)]])
+    i_theta = int(b[rank * minibatch_size, 0])
+    ind = np.sort(b[rank * minibatch_size:(rank + 1) * minibatch_size, 1])
+    return i_theta, ind
+
+
+# --------------------------------------------------------------------------------------
+# end-to-end DP-mode reconstruction (oracle of reconstruct_ptychography, hot path only)
+# --------------------------------------------------------------------------------------
+def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, minibatch_size=1,
+                optimizer='adam', learning_rate=1e-5, alpha_d=None, alpha_b=None, gamma=None,
+                update_scheme='immediate', optimizer_batch_number_increment='angle',
+                non_negativity=False, object_type='normal', mask=None, dtype='float64',
+                n_ranks=1, two_d_mode=False, raw_data_type='magnitude', gd_options=None,
+                return_trace=False):
+    """
+    Control flow of reconstruct_ptychography (ptychography.py:783-1295) restricted to
+    distribution_mode=None, shared probe, fixed probe, AD path.  ``n_ranks>1`` emulates
+    `mpirun -n R`: per-rank gradients (each with its own regulariser term, forward_model.py:138)
+    are summed (ptychography.py:1113-1114).
+    """
+    dt = np.dtype(dtype)
+    obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
+    m = np.zeros_like(obj)
+    v = np.zeros_like(obj)
+    n_theta = len(theta_ls)
+    n_pos = len(probe_pos)
+    probe_pos_int = np.round(np.asarray(probe_pos)).astype(int)
+    tables = {}
+    losses = []
+    first_grad = None
+    gd_options = gd_options or {'dynamic_rate': True, 'first_downrate_iteration': 20}
+    for i_epoch in range(n_epochs):
+        batches = epoch_task_list(i_epoch, n_theta, n_pos, minibatch_size, n_ranks, update_scheme,
+                                  two_d_mode=two_d_mode)
+        n_batch = len(batches)
+        i_opt_batch = 0   # starting_epoch * n_batch + starting_batch (ptychography.py:848), no checkpoint
+        grad_acc = None
+        for i_batch in range(n_batch):
+            g_sum = None
+            for rank in range(n_ranks):
+                i_theta, ind = rank_batch(batches, i_batch, rank, minibatch_size, n_ranks)
+                coords = None
+                if not two_d_mode:
+                    if i_theta not in tables:
+                        tables[i_theta] = rotation_coords(obj.shape[:3], theta_ls[i_theta], dt)
+                    coords = tables[i_theta]
+                pos = probe_pos_int[ind]
+                meas = np.abs(prj[i_theta, ind])
+                loss, pred, g, _ = forward_adjoint_object(obj, coords, probe, pos, meas, phys, dt,
+                                                          raw_data_type=raw_data_type)
+                if alpha_d not in (None, 0) or alpha_b not in (None, 0):
+                    rv, rg = l1_value_grad(obj, alpha_d, alpha_b)
+                    loss += rv; g = g + rg
+                if gamma not in (None, 0):
+                    rv, rg = tv_value_grad(obj, gamma)
+                    loss += rv; g = g + rg
+                if rank == 0:
+                    loss_rank0 = float(loss)
+                g_sum = g if g_sum is None else g_sum + g
+            if first_grad is None:
+                first_grad = g_sum.copy()
+            grad_acc = g_sum if grad_acc is None else grad_acc + g_sum
+            cur_theta = int(batches[i_batch][0, 0])
+            last_of_theta = i_batch == n_batch - 1 or int(batches[i_batch + 1][0, 0]) != cur_theta
+            if not (update_scheme == 'per angle' and not last_of_theta):
+                if optimizer == 'adam':
+                    obj, m, v = adam_step(obj, grad_acc.astype(dt), m, v, i_opt_batch, step_size=learning_rate)
+                else:
+                    obj = gd_step(obj, grad_acc.astype(dt), i_opt_batch, step_size=learning_rate, **gd_options)
+                obj = apply_constraints(obj, non_negativity, object_type, mask)
+                grad_acc = None
+                # the convergence log is only written when the loop body is not cut short by the
+                # 'per angle' `continue` (ptychography.py:1095-1099 vs :1261)
+                losses.append(loss_rank0)
+            if optimizer_batch_number_increment == 'angle':
+                if last_of_theta:
+                    i_opt_batch += 1
+            else:
+                i_opt_batch += 1
+    if return_trace:
+        return obj, losses, first_grad
+    return obj

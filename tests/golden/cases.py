@@ -1,0 +1,125 @@
+"""
+Deterministic input builders shared by the golden generator (gen_goldens.py, runs only in the
+development container where /root/reference exists) and by the parity tests (run anywhere).
+Fixtures (*.npz) therefore hold reference OUTPUTS plus the few inputs that are themselves
+produced by the reference-side setup; everything else is rebuilt from these seeds.
+"""
+import numpy as np
+
+ENERGY_EV = 5000.
+PSIZE_CM = 1e-7
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def smooth_field(shape, seed, cutoff=0.25):
+    """Band-limited random field in [0, 1] (structured object / initial guess)."""
+    r = rng(seed)
+    a = r.standard_normal(shape)
+    f = np.fft.fftn(a)
+    grids = np.meshgrid(*[np.fft.fftfreq(n) for n in shape], indexing='ij')
+    rad = np.sqrt(sum(g ** 2 for g in grids))
+    f = f * (rad <= cutoff)
+    a = np.real(np.fft.ifftn(f))
+    a = a - a.min()
+    return a / a.max()
+
+
+# ---------------------------------------------------------------- F2 / F3 tile-level cases
+# name: (P, S, free_prop_cm, sigma, binning, n_modes, probe kind, normalize_fft, fresnel_approx, dscale)
+TILE_CASES = {
+    'p12_s9_far_pos':      (12, 9, 'inf', 1, 1, 1, 'random', False, True, 2e-3),
+    'p12_s9_far_neg':      (12, 9, 'inf', -1, 1, 1, 'random', False, True, 2e-3),
+    'p12_s9_near':         (12, 9, 0, 1, 1, 1, 'random', False, True, 2e-3),
+    'p12_s9_fresnel':      (12, 9, 1e-4, 1, 1, 1, 'random', False, True, 2e-3),
+    'p16_s32_far_bin4':    (16, 32, 'inf', 1, 4, 1, 'random', False, True, 2e-3),
+    'p16_s10_far_bin4':    (16, 10, 'inf', 1, 4, 1, 'random', False, True, 2e-3),
+    'p12_s9_far_modes3':   (12, 9, 'inf', 1, 1, 3, 'random', False, True, 2e-3),
+    'p12_s1_far':          (12, 1, 'inf', 1, 1, 1, 'random', False, True, 2e-3),
+    'p12_s9_far_ortho':    (12, 9, 'inf', 1, 1, 1, 'random', True, True, 2e-3),
+    'p12_s9_far_nofresnel': (12, 9, 'inf', 1, 1, 1, 'random', False, False, 2e-3),
+    'p64_s8_near_plane':   (64, 8, 0, 1, 1, 1, 'plane', False, True, 2e-3),
+    'p72_s9_far_gauss':    (72, 9, 'inf', 1, 1, 1, 'gaussian', False, True, 2e-3),
+    'p72_s9_far_random':   (72, 9, 'inf', 1, 1, 1, 'random', False, True, 2e-3),
+}
+TILE_B = 3
+
+
+def tile_case_inputs(name):
+    P, S, fp, sigma, binning, n_modes, pkind, norm, fa, dscale = TILE_CASES[name]
+    seed = abs(hash_name(name)) % (2 ** 31)
+    r = rng(seed)
+    shape = (TILE_B, P, P, S)
+    # guess != truth; strong object (delta ~ 2e-3, beta ~ 2e-4) => total phase O(1 rad), well conditioned
+    guess = np.stack([r.uniform(0, dscale, shape), r.uniform(0, dscale * 0.1, shape)], -1)
+    truth = np.stack([r.uniform(0, dscale, shape), r.uniform(0, dscale * 0.1, shape)], -1)
+    probes = []
+    for m in range(n_modes):
+        if pkind == 'random':
+            mag = 0.5 + r.uniform(0, 1, (P, P))
+            ph = r.uniform(-np.pi, np.pi, (P, P))
+            probes.append(mag * np.exp(1j * ph))
+        elif pkind == 'plane':
+            probes.append(np.ones((P, P), dtype=complex))
+        else:
+            py = np.arange(P) - (P - 1.) / 2
+            xx, yy = np.meshgrid(py, py)
+            mag = np.exp(-(xx ** 2 + yy ** 2) / (2 * 6. ** 2))
+            ph = 0.5 * np.exp(-(xx ** 2 + yy ** 2) / (2 * 6. ** 2))
+            probes.append(mag * np.exp(1j * ph))
+    probes = np.stack(probes)
+    return dict(P=P, S=S, free_prop_cm=fp, sigma=sigma, binning=binning, n_modes=n_modes,
+                normalize_fft=norm, fresnel_approx=fa, guess=guess, truth=truth, probes=probes)
+
+
+def hash_name(name):
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % 1000003
+    return h
+
+
+# ---------------------------------------------------------------- F4 rotation cases
+ROT_CASES = {
+    'n12_t0.3':     ((5, 12, 12), 0.3),
+    'n12_halfpi':   ((5, 12, 12), np.pi / 2),
+    'n12_t3.44159': ((5, 12, 12), 3.44159),
+    'n16_twopi':    ((4, 16, 16), 2 * np.pi),
+    'n16_t1.0':     ((4, 16, 16), 1.0),
+}
+
+
+def rot_case_inputs(name):
+    size, theta = ROT_CASES[name]
+    r = rng(hash_name(name))
+    obj = 0.5 + r.standard_normal(size + (2,))
+    cot = r.standard_normal(size + (2,))
+    return size, np.float32(theta), obj, cot
+
+
+# ---------------------------------------------------------------- F6 end-to-end driver case
+E2E = dict(N=32, P=16, n_theta=4, grid=3, step=8, origin=-4, energy_ev=ENERGY_EV, psize_cm=PSIZE_CM,
+           minibatch_size=3)
+
+
+def e2e_inputs():
+    N = E2E['N']
+    truth_d = 1.0e-3 * smooth_field((N, N, N), 11)
+    truth_b = 1.0e-4 * smooth_field((N, N, N), 12)
+    # structured initial guess: blurred truth * 0.5 + small noise
+    guess_d = 0.5e-3 * smooth_field((N, N, N), 11, cutoff=0.1) + 1e-6 * rng(13).standard_normal((N, N, N))
+    guess_b = 0.5e-4 * smooth_field((N, N, N), 12, cutoff=0.1) + 1e-7 * rng(14).standard_normal((N, N, N))
+    g = E2E['grid']
+    ys = np.arange(g) * E2E['step'] + E2E['origin']
+    probe_pos = np.array([(y, x) for y in ys for x in ys], dtype=float)
+    theta_ls = np.linspace(0, 2 * np.pi, E2E['n_theta'], dtype='float32')
+    P = E2E['P']
+    py = np.arange(P) - (P - 1.) / 2
+    xx, yy = np.meshgrid(py, py)
+    r = rng(15)
+    mag = np.exp(-(xx ** 2 + yy ** 2) / (2 * 5. ** 2))
+    ph = r.uniform(-np.pi, np.pi, (P, P))          # random-phase probe => well-conditioned far field
+    return dict(truth=(truth_d, truth_b), guess=(guess_d, guess_b), probe_pos=probe_pos, theta_ls=theta_ls,
+                probe_mag=mag, probe_phase=ph)

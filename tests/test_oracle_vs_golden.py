@@ -1,0 +1,234 @@
+"""
+Pins the CPU oracle (oracle/adorym_oracle.py) against outputs of the imported reference
+(tests/golden/*.npz, produced by tests/golden/gen_goldens.py).  CPU-only.
+"""
+import os
+import numpy as np
+import pytest
+
+import cases
+from oracle import adorym_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name + '.npz'))
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+# ------------------------------------------------------------------ F1
+def test_f1_kernel():
+    g = load('F1_kernel')
+    lm = 1240. / cases.ENERGY_EV
+    vox = np.array([cases.PSIZE_CM] * 3) * 1e7
+    for key in g.files:
+        P, d, s, f = [int(t[1:]) for t in key.replace('s-1', 's-1').split('_')]
+        H = O.get_kernel(float(d), lm, vox, (P, P), fresnel_approx=bool(f), sign_convention=s)
+        assert np.array_equal(H, g[key]), key
+
+
+# ------------------------------------------------------------------ F2 / F3
+def _phys(c):
+    return O.Physics((c['P'], c['P']), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=c['free_prop_cm'],
+                     binning=c['binning'], fresnel_approx=c['fresnel_approx'], sign_convention=c['sigma'],
+                     normalize_fft=c['normalize_fft'])
+
+
+@pytest.mark.parametrize('name', list(cases.TILE_CASES))
+def test_f2_forward_fp64(name):
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    pred, fields = O.predict(c['guess'], c['probes'], _phys(c), 'float64')
+    ex = np.stack(fields)
+    assert rel(ex.real, g['ex_real_64']) < 1e-12
+    assert rel(ex.imag, g['ex_imag_64']) < 1e-12
+    assert rel(pred, g['pred_64']) < 1e-12
+    loss = O.mismatch_loss(pred, g['meas'])
+    assert abs(loss - g['loss_64']) <= 1e-12 * abs(g['loss_64'])
+
+
+@pytest.mark.parametrize('name', list(cases.TILE_CASES))
+def test_f2_forward_fp32(name):
+    """fp32 oracle vs reference fp32: same algorithm, different FFT library => rounding-level."""
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    pred, _ = O.predict(c['guess'], c['probes'], _phys(c), 'float32')
+    assert rel(pred, g['pred_32']) < 3e-6
+    assert rel(pred, g['pred_64']) < 3e-6
+    assert abs(O.mismatch_loss(pred, g['meas'].astype(np.float32)) - g['loss_32']) <= 1e-4 * abs(g['loss_32'])
+
+
+@pytest.mark.parametrize('name', list(cases.TILE_CASES))
+def test_f3_adjoint_fp64(name):
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    loss, pred, gt, gp = O.forward_adjoint_tiles(c['guess'], c['probes'], g['meas'], _phys(c), 'float64')
+    assert abs(loss - g['loss_64']) <= 1e-12 * abs(g['loss_64'])
+    tol = 1e-6 if c['P'] >= 64 else 1e-11     # big-case gradients are stored as fp32
+    assert rel(gt, g['grad_tiles_64']) < tol
+    assert rel(gp.real, g['grad_probe_real_64']) < 1e-11
+    assert rel(gp.imag, g['grad_probe_imag_64']) < 1e-11
+
+
+@pytest.mark.parametrize('name', [n for n in cases.TILE_CASES if cases.TILE_CASES[n][0] < 64])
+def test_f3_adjoint_fp32_within_3x_reference(name):
+    """The fp32 oracle's gradient error vs fp64 is no worse than 3x the reference's own fp32 error."""
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    _, _, gt, _ = O.forward_adjoint_tiles(c['guess'], c['probes'], g['meas'], _phys(c), 'float32')
+    e_ref = rel(g['grad_tiles_32'], g['grad_tiles_64'])
+    e_us = rel(gt, g['grad_tiles_64'])
+    assert e_us <= max(3 * e_ref, 1e-5), (e_us, e_ref)
+
+
+# ------------------------------------------------------------------ F4
+@pytest.mark.parametrize('name', list(cases.ROT_CASES))
+def test_f4_rotation(name):
+    g = load('F4_rotation')
+    size, theta, obj, cot = cases.rot_case_inputs(name)
+    coords = O.rotation_coords(size, theta)
+    assert coords.dtype == np.float16
+    assert np.array_equal(coords, g[name + '_coords']), 'fp16 lookup table must be bit-exact'
+    inv = O.rotation_coords(size, -theta)
+    assert np.array_equal(inv, g[name + '_coords_inv'])
+    rot = O.rotate_fwd(obj, coords, 'float64')
+    assert np.abs(rot - g[name + '_rot_64']).max() < 1e-12
+    adj = O.rotate_adj(cot, coords, 'float64')
+    assert np.abs(adj - g[name + '_adj_64']).max() < 1e-11
+    rot32 = O.rotate_fwd(obj.astype(np.float32), coords, 'float32')
+    assert np.abs(rot32 - g[name + '_rot_32']).max() < 2e-6
+    adj32 = O.rotate_adj(cot.astype(np.float32), coords, 'float32')
+    assert np.abs(adj32 - g[name + '_adj_32']).max() < 2e-5
+
+
+def test_f4_pad_len():
+    g = load('F4_rotation')
+    pos = np.array([(y, x) for y in np.arange(23) * 12 - 36 for x in np.arange(23) * 12 - 36])
+    assert np.array_equal(O.calculate_pad_len([256, 256, 256], pos, [72, 72]), g['pad_c3_full'])
+    assert np.array_equal(O.calculate_pad_len([256, 256, 256], pos[:32], [72, 72]), g['pad_c3_first32'])
+    assert np.array_equal(O.calculate_pad_len([256, 256, 256], pos[-32:], [72, 72]), g['pad_c3_last32'])
+
+
+def test_tiles_adjoint_pair():
+    r = cases.rng(3)
+    obj = r.standard_normal((10, 11, 3, 2))
+    pos = np.array([(-2, -3), (4, 6), (0, 0), (5, 7)])
+    tiles, _ = O.extract_tiles(obj, pos, (6, 5))
+    cot = r.standard_normal(tiles.shape)
+    lhs = np.sum(tiles * cot)
+    rhs = np.sum(obj * O.scatter_tiles_adj(cot, pos, obj.shape))
+    assert abs(lhs - rhs) < 1e-10 * abs(lhs)
+
+
+# ------------------------------------------------------------------ F5
+def test_f5_adam_gd():
+    g = load('F5_optimizers')
+    for tag, dt, tol in (('64', np.float64, 1e-13), ('32', np.float32, 2e-6)):
+        x = g['x0'].astype(dt)
+        m = np.zeros_like(x); v = np.zeros_like(x)
+        for k, t in enumerate((0, 0, 1, 1)):
+            x, m, v = O.adam_step(x, g['gseq'][k].astype(dt), m, v, t, step_size=1e-4)
+            assert rel(x, g['adam_x_' + tag][k]) < tol
+            assert rel(m, g['adam_m_' + tag][k]) < tol
+            assert rel(v, g['adam_v_' + tag][k]) < tol
+        x = g['x0'].astype(dt)
+        for k, t in enumerate((0, 25, 70, 200)):
+            x = O.gd_step(x, g['gseq'][k].astype(dt), t, step_size=1e-2, dynamic_rate=True, first_downrate_iteration=20)
+            assert rel(x, g['gd_x_' + tag][k]) < tol
+
+
+# ------------------------------------------------------------------ F7
+def test_f7_regularizers():
+    g = load('F7_regularizers')
+    val, grad = O.l1_value_grad(g['obj'], 1.5, 0.7)
+    assert abs(val - g['l1_val']) < 1e-14 and rel(grad, g['l1_grad']) < 1e-13
+    val, grad = O.tv_value_grad(g['obj'], 2.0)
+    assert abs(val - g['tv_val']) < 1e-13 and rel(grad, g['tv_grad']) < 1e-12
+
+
+# ------------------------------------------------------------------ F8
+def test_f8_task_lists():
+    g = load('F8_tasks')
+    n_theta, n_pos, mb = 5, 7, 3
+    for n_ranks in (1, 2):
+        seen_theta, seen_ind = [], []
+        for e in (0, 1):
+            batches = O.epoch_task_list(e, n_theta, n_pos, mb, n_ranks)
+            assert len(batches) == int(g['r%d_e%d_ntask' % (n_ranks, e)])
+            for k, b in enumerate(batches):
+                assert np.array_equal(b, g['r%d_e%d_task_%d' % (n_ranks, e, k)])
+            for k in range(len(batches)):
+                th, ind = O.rank_batch(batches, k, 0, mb, n_ranks)
+                seen_theta.append(th); seen_ind.append(ind)
+        assert np.array_equal(np.array(seen_theta), g['r%d_rank0_theta' % n_ranks])
+        assert np.array_equal(np.stack(seen_ind), g['r%d_rank0_ind' % n_ranks])
+
+
+def test_f8_c3_padding_is_deterministic_set():
+    b = O.epoch_task_list(0, 2, 529, 32, 1)
+    last = b[16]
+    assert sorted(last[:, 1].tolist()) == list(range(0, 15)) + list(range(512, 529))
+
+
+# ------------------------------------------------------------------ F6 end-to-end
+def _e2e(run, dtype, **kw):
+    g = load('F6_e2e')
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    phys = O.Physics((E['P'], E['P']), E['energy_ev'], E['psize_cm'], free_prop_cm='inf')
+    probe = inp['probe_mag'] * np.exp(1j * inp['probe_phase'])
+    return g, O.reconstruct(g['prj'].astype(np.float64), inp['guess'], probe, inp['probe_pos'], inp['theta_ls'], phys,
+                            minibatch_size=E['minibatch_size'], dtype=dtype, return_trace=True, **kw)
+
+
+E2E_RUNS = {
+    'adam_e1': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6),
+    'adam_e2': dict(n_epochs=2, optimizer='adam', learning_rate=1e-6),
+    'gd_e1': dict(n_epochs=1, optimizer='gd', learning_rate=1e-9),
+    'adam_e1_reg': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5),
+    'adam_e1_perangle': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, update_scheme='per angle'),
+    'adam_e1_nonneg': dict(n_epochs=1, optimizer='adam', learning_rate=1e-5, non_negativity=True),
+}
+
+
+@pytest.mark.parametrize('run', list(E2E_RUNS))
+def test_f6_end_to_end_fp64(run):
+    g, (obj, losses, first_grad) = _e2e(run, 'float64', **E2E_RUNS[run])
+    tag = run + '_64'
+    assert np.allclose(losses, g['losses_' + tag], rtol=1e-9, atol=0)
+    tol = 1e-11 if run == 'adam_e1' else 1e-7      # other runs are stored as fp32
+    upd_d = np.linalg.norm(obj[..., 0] - cases.e2e_inputs()['guess'][0])
+    assert np.linalg.norm(obj[..., 0] - g['delta_' + tag]) <= tol * np.linalg.norm(g['delta_' + tag]) + 1e-6 * upd_d
+    assert np.linalg.norm(obj[..., 1] - g['beta_' + tag]) <= tol * np.linalg.norm(g['beta_' + tag]) + 1e-6 * upd_d
+    if 'first_grad_' + tag in g.files:
+        assert rel(first_grad, g['first_grad_' + tag]) < (1e-10 if run == 'adam_e1' else 1e-6)
+    # BASELINE's criterion
+    rmse = np.sqrt(np.mean((obj[..., 0] - g['delta_' + tag]) ** 2))
+    assert rmse < 1e-5
+
+
+def test_f6_batch_order():
+    g = load('F6_e2e')
+    E = cases.E2E
+    th, ind = [], []
+    for e in (0, 1):
+        b = O.epoch_task_list(e, E['n_theta'], E['grid'] ** 2, E['minibatch_size'])
+        for k in range(len(b)):
+            t, i = O.rank_batch(b, k, 0, E['minibatch_size'])
+            th.append(t); ind.append(i)
+    assert np.array_equal(np.array(th), g['batches_theta'])
+    assert np.array_equal(np.stack(ind), g['batches_ind'])
+
+
+def test_f6_end_to_end_fp32_within_3x_reference():
+    g, (obj, losses, _) = _e2e('adam_e1', 'float32', **E2E_RUNS['adam_e1'])
+    x64 = np.stack([g['delta_adam_e1_64'], g['beta_adam_e1_64']], -1)
+    xr32 = np.stack([g['delta_adam_e1_32'], g['beta_adam_e1_32']], -1)
+    e_ref = np.linalg.norm(xr32 - x64)
+    e_us = np.linalg.norm(obj - x64)
+    assert np.sqrt(np.mean((obj - x64) ** 2)) < 1e-5
+    assert e_us <= 3 * e_ref + 1e-12, (e_us, e_ref)
