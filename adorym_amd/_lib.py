@@ -1,0 +1,88 @@
+"""ctypes binding of libadm.so (include/adm.h).  No fallback: if the HIP library is missing or
+cannot be loaded this module raises -- the product path never runs on a CPU substitute."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libadm.so')
+
+ADM_OK, ADM_ERR_INVALID, ADM_ERR_HIP, ADM_ERR_UNSUPPORTED, ADM_ERR_NOMEM = 0, -1, -2, -3, -4
+DET_NONE, DET_FARFIELD, DET_FRESNEL = 0, 1, 2
+FLAG_NONNEG, FLAG_ZERO_CH0, FLAG_ZERO_CH1 = 1, 2, 4
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [('obj_y', C.c_int32), ('obj_x', C.c_int32), ('obj_z', C.c_int32),
+                ('probe_y', C.c_int32), ('probe_x', C.c_int32),
+                ('pad_y0', C.c_int32), ('pad_y1', C.c_int32), ('pad_x0', C.c_int32), ('pad_x1', C.c_int32),
+                ('binning', C.c_int32), ('n_modes', C.c_int32), ('sign_convention', C.c_int32),
+                ('det_mode', C.c_int32), ('normalize_fft', C.c_int32), ('k1', C.c_float),
+                ('h_re', C.POINTER(C.c_float)), ('h_im', C.POINTER(C.c_float)),
+                ('hfree_re', C.POINTER(C.c_float)), ('hfree_im', C.POINTER(C.c_float))]
+
+
+_VP, _SZ, _I, _F = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/adm.h declares
+SIGNATURES = {
+    'adm_version': (_I, []),
+    'adm_last_error': (C.c_char_p, []),
+    'adm_ctx_create': (_I, [_I, _VP, C.POINTER(_VP)]),
+    'adm_ctx_destroy': (_I, [_VP]),
+    'adm_ctx_sync': (_I, [_VP]),
+    'adm_ctx_stream': (_VP, [_VP]),
+    'adm_ctx_device': (_I, [_VP]),
+    'adm_malloc': (_I, [_VP, _SZ, C.POINTER(_VP)]),
+    'adm_free': (_I, [_VP, _VP]),
+    'adm_memset': (_I, [_VP, _VP, _I, _SZ]),
+    'adm_h2d': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_d2h': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_d2d': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_event_create': (_I, [_VP, C.POINTER(_VP)]),
+    'adm_event_destroy': (_I, [_VP, _VP]),
+    'adm_event_record': (_I, [_VP, _VP]),
+    'adm_event_elapsed_ms': (_I, [_VP, _VP, _VP, C.POINTER(_F)]),
+    'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
+    'adm_plan_destroy': (_I, [_VP]),
+    'adm_plan_rot_elems': (_SZ, [_VP]),
+    'adm_plan_workspace_bytes': (_SZ, [_VP, _I]),
+    'adm_rotate_fwd': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
+    'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
+    'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
+    'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _F, _F, _F, _F, _I, _VP]),
+    'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _F, _I, _VP]),
+    'adm_axpy': (_I, [_VP, _VP, _VP, _F, _SZ]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libadm.so (building nothing: run `python adorym_amd/csrc/build.py` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libadm.so is missing (%s). Build it with `python adorym_amd/csrc/build.py`; '
+                           'adorym_amd has no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == ADM_OK:
+        return
+    msg = load().adm_last_error().decode('utf-8', 'replace')
+    if rc == ADM_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ADM_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ADM_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError('libadm: %s (code %d)' % (msg, rc))

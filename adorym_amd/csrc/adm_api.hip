@@ -1,0 +1,256 @@
+// C-ABI entry points: context, memory, events, plan, multislice launcher.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <vector>
+#include <cstring>
+#include "adm_common.h"
+
+namespace adm {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return ADM_ERR_HIP;
+}
+}  // namespace adm
+using namespace adm;
+
+extern "C" int adm_version(void) { return ADM_VERSION; }
+extern "C" const char* adm_last_error(void) { return g_err.c_str(); }
+
+extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
+    if (!out) return fail(ADM_ERR_INVALID, "adm_ctx_create: out is null");
+    int n = 0;
+    ADM_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(ADM_ERR_INVALID, "adm_ctx_create: no such device");
+    ADM_HIP(hipSetDevice(device));
+    adm_ctx* c = new adm_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return hip_fail(e, "hipStreamCreate");
+        }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return ADM_OK;
+}
+
+extern "C" int adm_ctx_destroy(adm_ctx* ctx) {
+    if (!ctx) return ADM_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ADM_OK;
+}
+extern "C" int adm_ctx_sync(adm_ctx* ctx) {
+    if (!ctx) return fail(ADM_ERR_INVALID, "adm_ctx_sync: null ctx");
+    ADM_HIP(hipStreamSynchronize(ctx->stream));
+    return ADM_OK;
+}
+extern "C" void* adm_ctx_stream(adm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int adm_ctx_device(adm_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int adm_malloc(adm_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return fail(ADM_ERR_INVALID, "adm_malloc: null argument");
+    ADM_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 4);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return fail(ADM_ERR_NOMEM, "adm_malloc: out of device memory");
+    }
+    ADM_HIP(e);
+    return ADM_OK;
+}
+extern "C" int adm_free(adm_ctx* ctx, void* dptr) {
+    if (!ctx) return fail(ADM_ERR_INVALID, "adm_free: null ctx");
+    if (dptr) {
+        ADM_HIP(hipStreamSynchronize(ctx->stream));
+        ADM_HIP(hipFree(dptr));
+    }
+    return ADM_OK;
+}
+extern "C" int adm_memset(adm_ctx* ctx, void* dptr, int value, size_t bytes) {
+    if (!ctx || !dptr) return fail(ADM_ERR_INVALID, "adm_memset: null argument");
+    if (bytes) ADM_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return ADM_OK;
+}
+extern "C" int adm_h2d(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(ADM_ERR_INVALID, "adm_h2d: null argument");
+    if (bytes) {
+        ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        ADM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ADM_OK;
+}
+extern "C" int adm_d2h(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(ADM_ERR_INVALID, "adm_d2h: null argument");
+    if (bytes) {
+        ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ADM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return ADM_OK;
+}
+extern "C" int adm_d2d(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(ADM_ERR_INVALID, "adm_d2d: null argument");
+    if (bytes) ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_event_create(adm_ctx* ctx, void** ev) {
+    if (!ctx || !ev) return fail(ADM_ERR_INVALID, "adm_event_create: null argument");
+    hipEvent_t e;
+    ADM_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return ADM_OK;
+}
+extern "C" int adm_event_destroy(adm_ctx* ctx, void* ev) {
+    if (ev) ADM_HIP(hipEventDestroy((hipEvent_t)ev));
+    return ADM_OK;
+}
+extern "C" int adm_event_record(adm_ctx* ctx, void* ev) {
+    if (!ctx || !ev) return fail(ADM_ERR_INVALID, "adm_event_record: null argument");
+    ADM_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return ADM_OK;
+}
+extern "C" int adm_event_elapsed_ms(adm_ctx* ctx, void* a, void* b, float* ms) {
+    if (!a || !b || !ms) return fail(ADM_ERR_INVALID, "adm_event_elapsed_ms: null argument");
+    ADM_HIP(hipEventSynchronize((hipEvent_t)b));
+    ADM_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return ADM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- plan
+static int upload_c(adm_ctx* ctx, const float* re, const float* im, size_t n, float2** out) {
+    std::vector<float2> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = make_float2(re[i], im[i]);
+    void* d = nullptr;
+    int rc = adm_malloc(ctx, n * sizeof(float2), &d);
+    if (rc) return rc;
+    rc = adm_h2d(ctx, d, tmp.data(), n * sizeof(float2));
+    if (rc) return rc;
+    *out = (float2*)d;
+    return ADM_OK;
+}
+
+extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out) {
+    if (!ctx || !desc || !out) return fail(ADM_ERR_INVALID, "adm_plan_create: null argument");
+    const adm_plan_desc& d = *desc;
+    if (d.obj_y <= 0 || d.obj_x <= 0 || d.obj_z <= 0 || d.probe_y <= 0 || d.probe_x <= 0)
+        return fail(ADM_ERR_INVALID, "adm_plan_create: non-positive dimension");
+    if (d.pad_y0 < 0 || d.pad_y1 < 0 || d.pad_x0 < 0 || d.pad_x1 < 0) return fail(ADM_ERR_INVALID, "adm_plan_create: negative pad");
+    if (d.binning < 1) return fail(ADM_ERR_INVALID, "adm_plan_create: binning must be >= 1");
+    if (d.sign_convention != 1 && d.sign_convention != -1) return fail(ADM_ERR_INVALID, "adm_plan_create: sign_convention must be +-1");
+    if (d.det_mode < 0 || d.det_mode > 2) return fail(ADM_ERR_INVALID, "adm_plan_create: bad det_mode");
+    if (!d.h_re || !d.h_im) return fail(ADM_ERR_INVALID, "adm_plan_create: transfer function missing");
+    if (d.det_mode == ADM_DET_FRESNEL && (!d.hfree_re || !d.hfree_im))
+        return fail(ADM_ERR_INVALID, "adm_plan_create: det_mode fresnel needs hfree");
+    if (d.probe_y != d.probe_x)
+        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: non-square probes are not implemented yet");
+    if (ms_threads_for(d.probe_x) == 0)
+        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size not in the compiled set {12,16,32,64,72}");
+    if (d.n_modes != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: n_probe_modes > 1 is not implemented yet");
+    if (d.pad_y0 + d.obj_y + d.pad_y1 < d.probe_y || d.pad_x0 + d.obj_x + d.pad_x1 < d.probe_x)
+        return fail(ADM_ERR_INVALID, "adm_plan_create: padded object smaller than the probe");
+    ADM_HIP(hipSetDevice(ctx->device));
+    adm_plan* p = new adm_plan();
+    p->ctx = ctx;
+    p->d = d;
+    p->d.h_re = p->d.h_im = p->d.hfree_re = p->d.hfree_im = nullptr;
+    p->Yp = d.pad_y0 + d.obj_y + d.pad_y1;
+    p->Xp = d.pad_x0 + d.obj_x + d.pad_x1;
+    p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
+    p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
+    const size_t npx = (size_t)d.probe_y * d.probe_x;
+    int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
+    if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
+    if (!rc) {
+        const int N = d.probe_x;
+        std::vector<float> re(N), im(N);
+        for (int j = 0; j < N; ++j) {
+            const double a = -2.0 * M_PI * (double)j / (double)N;
+            re[j] = (float)std::cos(a);
+            im[j] = (float)std::sin(a);
+        }
+        rc = upload_c(ctx, re.data(), im.data(), N, &p->twid_dev);
+    }
+    if (rc) {
+        adm_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return ADM_OK;
+}
+
+extern "C" int adm_plan_destroy(adm_plan* plan) {
+    if (!plan) return ADM_OK;
+    if (plan->h_dev) adm_free(plan->ctx, plan->h_dev);
+    if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
+    if (plan->twid_dev) adm_free(plan->ctx, plan->twid_dev);
+    delete plan;
+    return ADM_OK;
+}
+
+extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
+    if (!plan) return 0;
+    return (size_t)plan->d.obj_z * plan->Yp * plan->Xp * 2;
+}
+
+extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
+    if (!plan || batch <= 0) return 0;
+    return (size_t)batch * plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x) * sizeof(float2);
+}
+
+extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                                      const float* target, float* grad_rot, float* grad_probe, float* pred, float* loss_sum,
+                                      float grad_scale, void* workspace, size_t workspace_bytes) {
+    if (!plan || !obj_rot || !probe || !pos || !target || !loss_sum)
+        return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: batch must be positive");
+    const adm_plan_desc& d = plan->d;
+    if (grad_rot) {
+        if (!workspace || workspace_bytes < adm_plan_workspace_bytes(plan, batch))
+            return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: workspace too small");
+    }
+    MsParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.obj_rot = (const float2*)obj_rot;
+    p.grad_rot = (float2*)grad_rot;
+    p.probe = (const float2*)probe;
+    p.grad_probe = (float2*)grad_probe;
+    p.pos = (const int2*)pos;
+    p.target = target;
+    p.pred = pred;
+    p.loss_sum = loss_sum;
+    p.stash = (float2*)workspace;
+    p.h = plan->h_dev;
+    p.hfree = plan->hfree_dev;
+    p.twid = plan->twid_dev;
+    p.Z = d.obj_z;
+    p.Yp = plan->Yp;
+    p.Xp = plan->Xp;
+    p.pad_y0 = d.pad_y0;
+    p.pad_x0 = d.pad_x0;
+    p.binning = d.binning;
+    p.n_steps = plan->n_steps;
+    p.det_mode = d.det_mode;
+    p.det_inverse = (d.sign_convention == -1) ? 1 : 0;
+    const double npx = (double)d.probe_y * d.probe_x;
+    if (d.normalize_fft) p.det_scale = (float)(1.0 / std::sqrt(npx));        // norm='ortho'
+    else p.det_scale = p.det_inverse ? (float)(1.0 / npx) : 1.0f;             // ifft2 carries 1/N, fft2 none
+    p.k1 = d.k1;
+    p.sigma = (float)d.sign_convention;
+    p.grad_scale = grad_scale;
+    ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    return ADM_OK;
+}

@@ -1,0 +1,62 @@
+// Internal definitions shared by the libadm translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <cstdio>
+#include "../../include/adm.h"
+
+#define ADM_DET_NONE_ 0
+#define ADM_DET_FARFIELD_ 1
+#define ADM_DET_FRESNEL_ 2
+
+struct adm_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+};
+
+struct adm_plan {
+    adm_ctx* ctx;
+    adm_plan_desc d;       // host pointers inside are NOT kept valid; see device copies below
+    int Yp, Xp;            // padded rotated-frame extents
+    int n_steps;           // ceil(obj_z / binning)
+    float2* h_dev;         // [Py*Px] slice transfer function
+    float2* hfree_dev;     // [Py*Px] or nullptr
+    float2* twid_dev;      // [Px] exp(-2 pi i j / N)
+};
+
+namespace adm {
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+struct MsParams {
+    const float2* obj_rot;     // [Z][Yp][Xp] (delta, beta)
+    float2* grad_rot;          // same layout, atomically accumulated; nullptr = forward only
+    const float2* probe;       // [P][P]
+    float2* grad_probe;        // [P][P] or nullptr
+    const int2* pos;           // [B] (y, x) in object coordinates
+    const float* target;       // [B][P][P]
+    float* pred;               // [B][P][P] or nullptr
+    float* loss_sum;           // [B]
+    float2* stash;             // [B][n_steps][R1][NT]
+    const float2* h;           // [P][P] natural order, unscaled
+    const float2* hfree;       // [P][P] or nullptr
+    const float2* twid;        // [N] exp(-2 pi i j / N)
+    int Z, Yp, Xp, pad_y0, pad_x0;
+    int binning, n_steps;
+    int det_mode, det_inverse;     // det_inverse: far field uses the inverse transform (sign_convention -1)
+    float det_scale;               // far-field scale: 1, 1/N^2, or 1/N (ortho)
+    float k1, sigma;
+    float grad_scale;
+};
+int ms_threads_for(int n);
+int ms_r1_for(int n);
+hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
+}  // namespace adm
+
+#define ADM_HIP(call)                                          \
+    do {                                                       \
+        hipError_t e__ = (call);                               \
+        if (e__ != hipSuccess) return adm::hip_fail(e__, #call); \
+    } while (0)

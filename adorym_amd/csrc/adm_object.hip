@@ -1,0 +1,265 @@
+// Whole-object passes: rotation gather / scatter (R2), regulariser gradient (R9),
+// fused Adam / GD + constraints (R13-R15), axpy.  All HBM-bound streaming kernels.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "adm_common.h"
+
+namespace adm {
+
+// --------------------------------------------------------------------------------------------
+// Rotation about axis 0.  Reference: apply_rotation -> w.grid_sample (adorym/util.py:536-552,
+// adorym/wrappers.py:1105-1147), torch grid_sampler bilinear / border / align_corners=False.
+// One thread owns one rotated-frame (x', z') and loops over the y planes, so the coordinate
+// pipeline (fp16 table -> fp64 normalise -> fp32 un-normalise -> clamp -> weights) runs once per
+// thread.  A 16x16 (x', z') patch per block keeps the source footprint compact for any angle;
+// writes are 128-B row segments of the slice-major [Z][Yp][Xp][2] layout.
+// --------------------------------------------------------------------------------------------
+struct RotGeom {
+    int Y, X, Z, Yp, Xp, pad_y0, pad_x0;
+};
+
+struct Bilin {
+    int i00, i01, i10, i11;   // float2 offsets inside one y plane of obj ([X][Z])
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Bilin make_bilin(const uint16_t* coords, int xr, int zr, int X, int Z) {
+    Bilin b;
+    if (coords == nullptr) {
+        b.i00 = b.i01 = b.i10 = b.i11 = xr * Z + zr;
+        b.w00 = 1.f; b.w01 = b.w10 = b.w11 = 0.f;
+        return b;
+    }
+    const __half* ch = reinterpret_cast<const __half*>(coords) + 2 * ((size_t)xr * Z + zr);
+    const double x_old = (double)__half2float(ch[0]);
+    const double z_old = (double)__half2float(ch[1]);
+    // wrappers.py:1137: grid = -1 + 2*grid/arr_shape + 1/arr_shape on the flipped (z, x) pair, arr_shape = (X, Z)
+    const float gz = (float)(-1.0 + 2.0 * z_old / (double)X + 1.0 / (double)X);
+    const float gx = (float)(-1.0 + 2.0 * x_old / (double)Z + 1.0 / (double)Z);
+    float iz = ((gz + 1.f) * (float)Z - 1.f) / 2.f;
+    float ix = ((gx + 1.f) * (float)X - 1.f) / 2.f;
+    iz = fminf((float)(Z - 1), fmaxf(iz, 0.f));
+    ix = fminf((float)(X - 1), fmaxf(ix, 0.f));
+    const float fz = floorf(iz), fx = floorf(ix);
+    const float tz = iz - fz, tx = ix - fx;
+    const int z0 = (int)fz, x0 = (int)fx;
+    const bool vz = (z0 + 1 <= Z - 1), vx = (x0 + 1 <= X - 1);
+    const int z1 = vz ? z0 + 1 : z0, x1 = vx ? x0 + 1 : x0;
+    b.i00 = x0 * Z + z0; b.i01 = x0 * Z + z1; b.i10 = x1 * Z + z0; b.i11 = x1 * Z + z1;
+    b.w00 = (1.f - tx) * (1.f - tz);
+    b.w01 = vz ? (1.f - tx) * tz : 0.f;
+    b.w10 = vx ? tx * (1.f - tz) : 0.f;
+    b.w11 = (vx && vz) ? tx * tz : 0.f;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restrict__ obj, const uint16_t* __restrict__ coords,
+                                                         float2* __restrict__ rot, RotGeom g, int y_lo, int y_hi, int y_chunk) {
+    const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (xr >= g.X || zr >= g.Z) return;
+    const Bilin b = make_bilin(coords, xr, zr, g.X, g.Z);
+    const int ya = y_lo + blockIdx.z * y_chunk;
+    const int yb = min(ya + y_chunk, y_hi);
+    const size_t plane = (size_t)g.X * g.Z;
+    for (int y = ya; y < yb; ++y) {
+        const float2* o = obj + (size_t)y * plane;
+        const float2 v00 = o[b.i00], v01 = o[b.i01], v10 = o[b.i10], v11 = o[b.i11];
+        float2 r;
+        r.x = v00.x * b.w00 + v01.x * b.w01 + v10.x * b.w10 + v11.x * b.w11;
+        r.y = v00.y * b.w00 + v01.y * b.w01 + v10.y * b.w10 + v11.y * b.w11;
+        rot[((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void rotate_adj_kernel(const float2* __restrict__ grot, const uint16_t* __restrict__ coords,
+                                                         float* __restrict__ gobj, RotGeom g, int y_lo, int y_hi, int y_chunk) {
+    const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (xr >= g.X || zr >= g.Z) return;
+    const Bilin b = make_bilin(coords, xr, zr, g.X, g.Z);
+    const int ya = y_lo + blockIdx.z * y_chunk;
+    const int yb = min(ya + y_chunk, y_hi);
+    const size_t plane = (size_t)g.X * g.Z;
+    for (int y = ya; y < yb; ++y) {
+        const float2 v = grot[((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr];
+        float* o = gobj + 2 * (size_t)y * plane;
+        if (b.w00 != 0.f) { atomicAdd(o + 2 * b.i00, v.x * b.w00); atomicAdd(o + 2 * b.i00 + 1, v.y * b.w00); }
+        if (b.w01 != 0.f) { atomicAdd(o + 2 * b.i01, v.x * b.w01); atomicAdd(o + 2 * b.i01 + 1, v.y * b.w01); }
+        if (b.w10 != 0.f) { atomicAdd(o + 2 * b.i10, v.x * b.w10); atomicAdd(o + 2 * b.i10 + 1, v.y * b.w10); }
+        if (b.w11 != 0.f) { atomicAdd(o + 2 * b.i11, v.x * b.w11); atomicAdd(o + 2 * b.i11 + 1, v.y * b.w11); }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Regulariser gradient.  L1Regularizer (adorym/regularizers.py:30-46): alpha_c * mean|x_c|;
+// TVRegularizer (regularizers.py:95-110 -> util.py:1427-1440): gamma * sum_axes sum|roll(a,1)-a| / V.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
+
+__global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__ x, float* __restrict__ g, int Y, int X, int Z,
+                                                       float a_d, float a_b, float gamma, float* reg_value) {
+    const size_t n = (size_t)Y * X * Z * 2;
+    const float invV = 1.0f / (float)((size_t)Y * X * Z);
+    float val = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i & 1);
+        size_t vox = i >> 1;
+        const int z = (int)(vox % Z);
+        vox /= Z;
+        const int xx = (int)(vox % X);
+        const int y = (int)(vox / X);
+        const float v = x[i];
+        float gr = 0.f;
+        const float al = c ? a_b : a_d;
+        if (al != 0.f) { gr += al * sgn(v) * invV; val += al * fabsf(v) * invV; }
+        if (gamma != 0.f) {
+            const size_t sz = 2, sx = 2 * (size_t)Z, sy = 2 * (size_t)Z * X;
+            const float zm = x[i - (size_t)z * sz + (size_t)((z + Z - 1) % Z) * sz];
+            const float zp = x[i - (size_t)z * sz + (size_t)((z + 1) % Z) * sz];
+            const float xm = x[i - (size_t)xx * sx + (size_t)((xx + X - 1) % X) * sx];
+            const float xp = x[i - (size_t)xx * sx + (size_t)((xx + 1) % X) * sx];
+            const float ym = x[i - (size_t)y * sy + (size_t)((y + Y - 1) % Y) * sy];
+            const float yp = x[i - (size_t)y * sy + (size_t)((y + 1) % Y) * sy];
+            gr += gamma * invV * ((sgn(v - zp) - sgn(zm - v)) + (sgn(v - xp) - sgn(xm - v)) + (sgn(v - yp) - sgn(ym - v)));
+            val += gamma * invV * (fabsf(zm - v) + fabsf(xm - v) + fabsf(ym - v));
+        }
+        g[i] += gr;
+    }
+    if (reg_value) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reg_value, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Fused optimiser steps.  AdamOptimizer.apply_gradient (adorym/optimizers.py:309-318):
+//   m = b1*m; m = m + (1-b1)*g; v = b2*v; v = v + (1-b2)*g^2;
+//   x = x - step*(m/q1) / (sqrt(v/q2) + eps),  q = 1 - b^(i_batch+1)
+// followed by the constraints of adorym/ptychography.py:1135-1158 and the support mask
+// (adorym/array_ops.py:239-251).  Same operation order as the reference, fp32.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float constrain(float xv, size_t i, int flags, const float* mask) {
+    if ((flags & ADM_FLAG_NONNEG) && xv < 0.f) xv = 0.f;
+    if ((flags & ADM_FLAG_ZERO_CH0) && !(i & 1)) xv *= 0.f;
+    if ((flags & ADM_FLAG_ZERO_CH1) && (i & 1)) xv *= 0.f;
+    if (mask) xv *= mask[i >> 1];
+    return xv;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t lo, size_t hi, float step, float b1, float b2,
+                                                   float omb1, float omb2, float q1, float q2, float eps, int flags,
+                                                   const float* __restrict__ mask) {
+#pragma clang fp contract(off)
+    for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
+        const float gv = g[i];
+        float mv = b1 * m[i];
+        mv = mv + omb1 * gv;
+        float vv = b2 * v[i];
+        vv = vv + omb2 * (gv * gv);
+        const float mhat = mv / q1;
+        const float vhat = vv / q2;
+        const float d = step * mhat / (sqrtf(vhat) + eps);
+        m[i] = mv;
+        v[i] = vv;
+        x[i] = constrain(x[i] - d, i, flags, mask);
+    }
+}
+
+__global__ __launch_bounds__(256) void gd_kernel(float* __restrict__ x, const float* __restrict__ g, size_t lo, size_t hi,
+                                                 float step, int flags, const float* __restrict__ mask) {
+#pragma clang fp contract(off)
+    for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = constrain(x[i] - step * g[i], i, flags, mask);
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+
+static inline int stream_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+}  // namespace adm
+
+using namespace adm;
+
+extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* coords, float* obj_rot, int y_lo, int y_hi) {
+    if (!plan || !obj || !obj_rot) return fail(ADM_ERR_INVALID, "adm_rotate_fwd: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_fwd: bad y range");
+    if (y_lo == y_hi) return ADM_OK;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    const int y_chunk = 32;
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
+    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, (float2*)obj_rot, g,
+                       y_lo, y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords, float* grad_obj, int y_lo, int y_hi) {
+    if (!plan || !grad_rot || !grad_obj) return fail(ADM_ERR_INVALID, "adm_rotate_adj: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_adj: bad y range");
+    if (y_lo == y_hi) return ADM_OK;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    const int y_chunk = 32;
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
+    hipLaunchKernelGGL(rotate_adj_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, coords, grad_obj, g, y_lo,
+                       y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                            float* reg_value) {
+    if (!plan || !obj || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad: null argument");
+    const adm_plan_desc& d = plan->d;
+    const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
+    hipLaunchKernelGGL(reg_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, plan->ctx->stream, obj, grad_obj, d.obj_y, d.obj_x,
+                       d.obj_z, alpha_d, alpha_b, gamma, reg_value);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
+                             float step_size, float b1, float b2, float eps, int flags, const float* mask) {
+    if (!ctx || !x || !g || !m || !v) return fail(ADM_ERR_INVALID, "adm_adam_step: null argument");
+    if (hi <= lo) return ADM_OK;
+    // the reference evaluates the scalars in Python doubles and torch casts them to fp32 at the op
+    const double b1d = (double)b1, b2d = (double)b2;
+    const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    double p1 = 1.0, p2 = 1.0;
+    for (int k = 0; k < i_batch + 1; ++k) { p1 *= b1d; p2 *= b2d; }
+    const float q1 = (float)(1.0 - p1), q2 = (float)(1.0 - p2);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi, step_size, b1, b2,
+                       omb1, omb2, q1, q2, eps, flags, mask);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, float step_size, int flags,
+                           const float* mask) {
+    if (!ctx || !x || !g) return fail(ADM_ERR_INVALID, "adm_gd_step: null argument");
+    if (hi <= lo) return ADM_OK;
+    hipLaunchKernelGGL(gd_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, lo, hi, step_size, flags, mask);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n) {
+    if (!ctx || !y || !x) return fail(ADM_ERR_INVALID, "adm_axpy: null argument");
+    if (!n) return ADM_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n)), dim3(256), 0, ctx->stream, y, x, a, n);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Build libadm.so (gfx950) in-tree with hipcc.  Usage: python adorym_amd/csrc/build.py [--force] [--safe-sync]"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, 'libadm.so')
+SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip']
+HDRS = ['adm_common.h', 'adm_fft.h', os.path.join('..', '..', 'include', 'adm.h')]
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ['build.py'])
+
+
+def build(force=False, extra=()):
+    if not force and not needs_build():
+        return OUT
+    objs = []
+    for s in SRCS:
+        o = os.path.join(HERE, s.replace('.hip', '.o'))
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+               '-Wno-unused-result', '-c', os.path.join(HERE, s), '-o', o] + list(extra)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    extra = ['-DADM_SAFE_SYNC'] if '--safe-sync' in sys.argv else []
+    print(build(force='--force' in sys.argv or bool(extra), extra=extra))

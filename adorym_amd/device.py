@@ -1,0 +1,165 @@
+"""Thin Python objects over the libadm C ABI: Context (GPU + stream), DeviceArray (typed device
+buffer), Plan (static geometry/physics) and Event.  NumPy is the only host-side array type."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class Context(object):
+    """One GPU + one HIP stream.  ``stream`` may be an existing hipStream_t handle (int), e.g.
+    ``torch.cuda.current_stream().cuda_stream``, so that torch.distributed collectives and libadm
+    kernels are ordered on the same stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.adm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def sync(self):
+        check(self.lib.adm_ctx_sync(self.handle))
+
+    @property
+    def stream(self):
+        return self.lib.adm_ctx_stream(self.handle)
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32):
+        a = DeviceArray(self, shape, dtype)
+        a.zero_()
+        return a
+
+    def array(self, host, dtype=None):
+        host = np.ascontiguousarray(host, dtype=dtype)
+        a = DeviceArray(self, host.shape, host.dtype)
+        a.set(host)
+        return a
+
+    def event(self):
+        return Event(self)
+
+    def close(self):
+        if self.handle:
+            self.lib.adm_ctx_destroy(self.handle)
+            self.handle = None
+
+
+class DeviceArray(object):
+    """A typed, shaped view of device memory.  Owns the allocation unless built with ``ptr=``."""
+
+    def __init__(self, ctx, shape, dtype=np.float32, ptr=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if np.ndim(shape) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owns = ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            check(ctx.lib.adm_malloc(ctx.handle, self.nbytes, C.byref(p)))
+            self.ptr = p.value
+        else:
+            self.ptr = int(ptr)
+
+    def zero_(self):
+        check(self.ctx.lib.adm_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+        return self
+
+    def set(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError('size mismatch: device %s vs host %s' % (self.shape, host.shape))
+        check(self.ctx.lib.adm_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx.lib.adm_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError('size mismatch')
+        check(self.ctx.lib.adm_d2d(self.ctx.handle, self.ptr, other.ptr, self.nbytes))
+        return self
+
+    def view(self, offset_elems, shape):
+        """A non-owning sub-view starting ``offset_elems`` elements in."""
+        return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr + offset_elems * self.dtype.itemsize)
+
+    def free(self):
+        if self._owns and self.ptr:
+            self.ctx.lib.adm_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            if self._owns and self.ptr and self.ctx.handle:
+                self.ctx.lib.adm_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
+class Event(object):
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(ctx.lib.adm_event_create(ctx.handle, C.byref(h)))
+        self.handle = h
+
+    def record(self):
+        check(self.ctx.lib.adm_event_record(self.ctx.handle, self.handle))
+        return self
+
+    def elapsed_ms(self, end):
+        ms = C.c_float()
+        check(self.ctx.lib.adm_event_elapsed_ms(self.ctx.handle, self.handle, end.handle, C.byref(ms)))
+        return ms.value
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Plan(object):
+    """adm_plan: object/probe geometry, padding, physics constants and transfer functions."""
+
+    def __init__(self, ctx, obj_size, probe_size, pads, k1, h, binning=1, n_modes=1, sign_convention=1,
+                 det_mode=_lib.DET_FARFIELD, normalize_fft=False, h_free=None):
+        self.ctx = ctx
+        d = _lib.PlanDesc()
+        d.obj_y, d.obj_x, d.obj_z = [int(v) for v in obj_size]
+        d.probe_y, d.probe_x = [int(v) for v in probe_size]
+        (d.pad_y0, d.pad_y1), (d.pad_x0, d.pad_x1) = [(int(a), int(b)) for a, b in pads]
+        d.binning, d.n_modes, d.sign_convention = int(binning), int(n_modes), int(sign_convention)
+        d.det_mode, d.normalize_fft, d.k1 = int(det_mode), int(bool(normalize_fft)), float(k1)
+        h = np.asarray(h)
+        # h_real / h_imag are cast separately to fp32, as in adorym/propagate.py:202-204
+        self._h = (np.ascontiguousarray(h.real, dtype=np.float32), np.ascontiguousarray(h.imag, dtype=np.float32))
+        d.h_re, d.h_im = _fptr(self._h[0]), _fptr(self._h[1])
+        if h_free is not None:
+            hf = np.asarray(h_free)
+            self._hf = (np.ascontiguousarray(hf.real, dtype=np.float32), np.ascontiguousarray(hf.imag, dtype=np.float32))
+            d.hfree_re, d.hfree_im = _fptr(self._hf[0]), _fptr(self._hf[1])
+        p = C.c_void_p()
+        check(ctx.lib.adm_plan_create(ctx.handle, C.byref(d), C.byref(p)))
+        self.handle = p
+        self.desc = d
+        self.obj_size = (d.obj_y, d.obj_x, d.obj_z)
+        self.probe_size = (d.probe_y, d.probe_x)
+        self.pads = ((d.pad_y0, d.pad_y1), (d.pad_x0, d.pad_x1))
+        self.rot_shape = (d.obj_z, d.obj_y + d.pad_y0 + d.pad_y1, d.obj_x + d.pad_x0 + d.pad_x1, 2)
+        assert int(np.prod(self.rot_shape)) == ctx.lib.adm_plan_rot_elems(p)
+
+    def workspace_bytes(self, batch):
+        return int(self.ctx.lib.adm_plan_workspace_bytes(self.handle, int(batch)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.adm_plan_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,166 @@
+"""
+Fresnel transfer functions (host, setup time) and the MultisliceEngine that drives the HIP
+kernels for one minibatch: rotate -> multislice forward + loss + adjoint -> rotate-adjoint.
+
+Reference: adorym/propagate.py (get_kernel :62-81, gen_freq_mesh :54-60,
+multislice_propagate_batch :131-288).
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .constants import PI
+from .device import Context, DeviceArray, Plan
+from .util import calculate_pad_len
+
+
+def gen_freq_mesh(voxel_nm, shape):
+    """adorym/propagate.py:54-60."""
+    u = np.fft.fftfreq(shape[0])
+    v = np.fft.fftfreq(shape[1])
+    vv, uu = np.meshgrid(v, u)
+    vv = vv / voxel_nm[1]
+    uu = uu / voxel_nm[0]
+    return uu, vv
+
+
+def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, fresnel_approx=True, sign_convention=1):
+    """Unshifted Fresnel transfer function, complex128 (adorym/propagate.py:62-81)."""
+    u, v = gen_freq_mesh(voxel_nm, grid_shape[0:2])
+    if fresnel_approx:
+        H = np.exp(-sign_convention * 1j * PI * lmbda_nm * dist_nm * (u ** 2 + v ** 2))
+    else:
+        quad = 1 - lmbda_nm ** 2 * (u ** 2 + v ** 2)
+        quad_inner = np.clip(quad, 0, None)
+        quad_mask = (quad > 0)
+        H = np.exp(sign_convention * 1j * 2 * PI * dist_nm / lmbda_nm * np.sqrt(quad_inner))
+        H = H * quad_mask
+    return H
+
+
+class MultisliceEngine(object):
+    """
+    Device-resident state for the accelerated path of one reconstruction:
+
+      obj [Y,X,Z,2] --adm_rotate_fwd--> obj_rot [Z][Yp][Xp][2] --adm_multislice_fwd_adj-->
+      grad_rot --adm_rotate_adj--> grad_obj [Y,X,Z,2]
+
+    ``probe_pos`` is the list of ALL probe positions (top-left corners, object coordinates); it
+    fixes the zero padding of the rotated-frame buffers (adorym/util.py:1374-1406 applied once).
+    """
+
+    def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
+                 fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
+                 n_probe_modes=1, max_batch=None):
+        self.ctx = ctx
+        self.obj_size = tuple(int(v) for v in obj_size)
+        self.probe_size = tuple(int(v) for v in probe_size)
+        probe_pos = np.round(np.asarray(probe_pos)).astype(int).reshape(-1, 2)
+        pads = calculate_pad_len(self.obj_size, probe_pos, self.probe_size)
+        # adorym/propagate.py:143-153, 215
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        delta_nm = voxel_nm[-1]
+        self.k1 = 2. * PI * delta_nm / lmbda_nm if scale_ri_by_k else 1.
+        if kernel is None:
+            kernel = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, self.probe_size, fresnel_approx=fresnel_approx,
+                                sign_convention=sign_convention)
+        h_free = None
+        if free_prop_cm in (0, None):
+            det = _lib.DET_NONE
+        elif isinstance(free_prop_cm, str) and free_prop_cm == 'inf':
+            det = _lib.DET_FARFIELD
+        else:
+            det = _lib.DET_FRESNEL
+            # fresnel_propagate always builds the Fresnel-approx kernel (adorym/propagate.py:537-546)
+            h_free = get_kernel(float(free_prop_cm) * 1e7, lmbda_nm, voxel_nm, self.probe_size,
+                                sign_convention=sign_convention)
+        self.plan = Plan(ctx, self.obj_size, self.probe_size, pads, self.k1, kernel, binning=binning,
+                         n_modes=n_probe_modes, sign_convention=sign_convention, det_mode=det,
+                         normalize_fft=normalize_fft, h_free=h_free)
+        self.pads = pads
+        self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
+        self.grad_rot = ctx.zeros(self.plan.rot_shape)
+        self.max_batch = 0
+        self._ws = self._pos = self._target = self._pred = self._loss = None
+        if max_batch:
+            self._reserve(max_batch)
+
+    # -------------------------------------------------------------------------------- buffers
+    def _reserve(self, batch):
+        if batch <= self.max_batch:
+            return
+        Py, Px = self.probe_size
+        self._ws = DeviceArray(self.ctx, (self.plan.workspace_bytes(batch),), np.uint8)
+        self._pos = DeviceArray(self.ctx, (batch, 2), np.int32)
+        self._target = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
+        self._pred = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
+        self._loss = DeviceArray(self.ctx, (batch,), np.float32)
+        self.max_batch = batch
+
+    def y_footprint(self, pos_batch):
+        pos = np.round(np.asarray(pos_batch)).astype(int).reshape(-1, 2)
+        lo = max(0, int(pos[:, 0].min()))
+        hi = min(self.obj_size[0], int(pos[:, 0].max()) + self.probe_size[0])
+        return lo, max(lo, hi)
+
+    # -------------------------------------------------------------------------------- stages
+    def rotate(self, obj, coords, y_range=None):
+        """obj: DeviceArray [Y,X,Z,2]; coords: DeviceArray uint16 [X*Z,2] or None (no rotation)."""
+        lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
+        check(self.ctx.lib.adm_rotate_fwd(self.plan.handle, obj.ptr, coords.ptr if coords is not None else None,
+                                          self.obj_rot.ptr, lo, hi))
+
+    def rotate_adjoint(self, grad_obj, coords, y_range=None):
+        lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
+        check(self.ctx.lib.adm_rotate_adj(self.plan.handle, self.grad_rot.ptr, coords.ptr if coords is not None else None,
+                                          grad_obj.ptr, lo, hi))
+
+    def set_batch(self, pos_batch, target):
+        """Upload the probe positions [B,2] and target magnitudes [B,Py,Px] of the next minibatch
+        (target may already be a DeviceArray)."""
+        pos = np.ascontiguousarray(np.round(np.asarray(pos_batch)).astype(np.int32).reshape(-1, 2))
+        B = len(pos)
+        self._reserve(B)
+        self._pos.view(0, (B, 2)).set(pos)
+        if isinstance(target, DeviceArray):
+            self._cur_target = target
+        else:
+            self._cur_target = self._target.view(0, (B,) + self.probe_size)
+            self._cur_target.set(np.asarray(target, dtype=np.float32))
+        self._B = B
+        return B
+
+    def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, zero_grad_rot=True):
+        """Launch the fused kernel on the batch given to set_batch().  Returns nothing; read
+        results with loss() / pred()."""
+        B = self._B
+        Py, Px = self.probe_size
+        if grad_scale is None:
+            grad_scale = 2.0 / (B * Py * Px)          # d mean((pred-target)^2) / d pred
+        if want_grad and zero_grad_rot:
+            self.grad_rot.zero_()
+        check(self.ctx.lib.adm_multislice_fwd_adj(
+            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._pos.ptr, B, self._cur_target.ptr,
+            self.grad_rot.ptr if want_grad else None, grad_probe.ptr if grad_probe is not None else None,
+            self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
+
+    def loss(self):
+        """mean((pred - target)^2) over the batch (adorym/forward_model.py:91) -- blocks."""
+        B = self._B
+        s = self._loss.view(0, (B,)).get().astype(np.float64).sum()
+        return float(s / (B * self.probe_size[0] * self.probe_size[1]))
+
+    def pred(self):
+        return self._pred.view(0, (self._B,) + self.probe_size).get()
+
+    # -------------------------------------------------------------------------------- whole step
+    def loss_and_grad(self, obj, grad_obj, coords, probe, pos_batch, target, grad_probe=None, footprint=True):
+        """One minibatch: grad_obj += d loss / d obj; returns the (host) loss."""
+        self.set_batch(pos_batch, target)
+        yr = self.y_footprint(pos_batch) if footprint else None
+        self.rotate(obj, coords, yr)
+        self.multislice(probe, grad_probe=grad_probe)
+        self.rotate_adjoint(grad_obj, coords, yr)
+        return self.loss()

@@ -1,0 +1,158 @@
+/*
+ * adm.h -- C ABI of libadm.so: the MI355X (gfx950) implementation of Adorym's multislice
+ * forward model + hand-derived adjoint + object update.
+ *
+ * The reference (mdw771/adorym) is 100 % Python and has no FFI; this header defines the
+ * boundary a reference maintainer would bind with ctypes.  Each entry
+ * point names the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, every function returns 0 on success and a negative adm_status otherwise;
+ *     adm_last_error() returns a thread-local, library-owned message for the last failure.
+ *   - "device pointer" = memory of the context's GPU (hipMalloc'ed by adm_malloc or by anybody
+ *     else in the process, e.g. torch); "host pointer" = borrowed for the duration of the call.
+ *   - all work is enqueued on the context's HIP stream; calls are asynchronous unless noted.
+ *   - fp32 arithmetic throughout (the reference's default dtype).
+ *   - a context is not thread-safe.
+ */
+#ifndef ADM_H
+#define ADM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADM_VERSION 100
+
+typedef enum {
+    ADM_OK = 0,
+    ADM_ERR_INVALID = -1,     /* bad argument                                   */
+    ADM_ERR_HIP = -2,         /* HIP runtime error (message has the hipError)    */
+    ADM_ERR_UNSUPPORTED = -3, /* valid in the reference, not implemented here    */
+    ADM_ERR_NOMEM = -4
+} adm_status;
+
+typedef struct adm_ctx adm_ctx;
+typedef struct adm_plan adm_plan;
+
+/* ---- library / context ------------------------------------------------------------ */
+int adm_version(void);
+const char* adm_last_error(void);
+
+/* One context = one GPU + one stream.  `stream` may be an existing hipStream_t (e.g.
+ * torch.cuda.current_stream().cuda_stream) or NULL to let the context own a new one.
+ * Replaces: the device selection of reconstruct_ptychography (adorym/ptychography.py:203-205). */
+int adm_ctx_create(int device, void* stream, adm_ctx** out);
+int adm_ctx_destroy(adm_ctx* ctx);
+int adm_ctx_sync(adm_ctx* ctx);                 /* blocks until the stream is idle */
+void* adm_ctx_stream(adm_ctx* ctx);             /* the hipStream_t in use */
+int adm_ctx_device(adm_ctx* ctx);
+
+/* ---- device memory (replaces w.create_variable / w.zeros / w.to_numpy on device tensors,
+ *      adorym/wrappers.py:121-147, 186-205) -------------------------------------------- */
+int adm_malloc(adm_ctx* ctx, size_t bytes, void** dptr);
+int adm_free(adm_ctx* ctx, void* dptr);
+int adm_memset(adm_ctx* ctx, void* dptr, int byte_value, size_t bytes);       /* async */
+int adm_h2d(adm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* blocking */
+int adm_d2h(adm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* blocking */
+int adm_d2d(adm_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /* async */
+
+/* ---- events: kernel timing on the context's stream --------------------------------- */
+int adm_event_create(adm_ctx* ctx, void** ev);
+int adm_event_destroy(adm_ctx* ctx, void* ev);
+int adm_event_record(adm_ctx* ctx, void* ev);
+int adm_event_elapsed_ms(adm_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* blocks on ev_stop */
+
+/* ---- plan: static geometry + physics of one reconstruction ------------------------- */
+typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;
+
+typedef struct {
+    int32_t obj_y, obj_x, obj_z;      /* object [Y, X, Z, 2] (delta, beta interleaved, z fastest)    */
+    int32_t probe_y, probe_x;         /* tile / probe / detector size                                 */
+    int32_t pad_y0, pad_y1;           /* zero padding of the rotated-frame buffers so every tile fits */
+    int32_t pad_x0, pad_x1;           /*   (adorym/util.py:1374-1406 applied to ALL probe positions)  */
+    int32_t binning;                  /* slices summed per modulation (adorym/propagate.py:207-241)   */
+    int32_t n_modes;                  /* probe modes (adorym/forward_model.py:354-375)                */
+    int32_t sign_convention;          /* +1 / -1 (adorym/propagate.py:241)                            */
+    int32_t det_mode;                 /* adm_det_mode: free_prop_cm 0/None, 'inf', finite             */
+    int32_t normalize_fft;            /* far field with norm='ortho' (adorym/wrappers.py:725-770)     */
+    float   k1;                       /* 2*PI*delta_nm/lmbda_nm (adorym/propagate.py:215)             */
+    const float* h_re;                /* host [probe_y*probe_x] slice-to-slice transfer function,     */
+    const float* h_im;                /*   unshifted, = get_kernel() cast to fp32 (propagate.py:62-81, 202-204) */
+    const float* hfree_re;            /* host, detector-plane Fresnel kernel for ADM_DET_FRESNEL      */
+    const float* hfree_im;            /*   (adorym/propagate.py:537-553), else NULL                   */
+} adm_plan_desc;
+
+int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out);
+int adm_plan_destroy(adm_plan* plan);
+/* number of floats of one rotated-frame buffer: obj_z * (obj_y+pads) * (obj_x+pads) * 2.
+ * Internal layout is slice-major [Z][Yp][Xp][2] so that a tile slice is Py contiguous rows. */
+size_t adm_plan_rot_elems(const adm_plan* plan);
+/* bytes of scratch adm_multislice_fwd_adj needs for `batch` positions (stored post-modulation wavefields) */
+size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch);
+
+/* ---- R1/R2  rotation ----------------------------------------------------------------
+ * adm_rotate_fwd replaces apply_rotation -> w.grid_sample (adorym/util.py:536-552,
+ * adorym/wrappers.py:1105-1147) and pad_object (adorym/util.py:1327-1351):
+ *   obj [Y,X,Z,2] --bilinear gather, border clamp--> interior of obj_rot [Z][Yp][Xp][2]
+ * for y-planes y_lo <= y < y_hi (planes are independent under a rotation about axis 0).
+ * coords: device uint16 (IEEE fp16 bits) [X*Z, 2] = the reference's lookup table
+ * (adorym/util.py:492-516); NULL = no rotation (two_d_mode / theta-independent copy).
+ * adm_rotate_adj is its transpose (autograd of grid_sampler_2d): grad_obj += R^T grad_rot. */
+int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* coords, float* obj_rot, int y_lo, int y_hi);
+int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords, float* grad_obj, int y_lo, int y_hi);
+
+/* ---- R3,R5-R8,R10  multislice forward + loss + adjoint ------------------------------
+ * Replaces, for one minibatch of `batch` probe positions of one rotation angle:
+ *   tile extraction            adorym/forward_model.py:313-331
+ *   multislice_propagate_batch adorym/propagate.py:195-280 (delta_beta, non-projection branch)
+ *   w.norm / mode sum          adorym/forward_model.py:337-375
+ *   LSQ magnitude loss         adorym/forward_model.py:88-93
+ *   torch.autograd.grad        adorym/wrappers.py:322   (hand-derived adjoint)
+ * obj_rot   device [Z][Yp][Xp][2]
+ * probe     device [n_modes][Py][Px][2] (real, imag interleaved)
+ * pos       device int32 [batch][2] = (y, x) top-left corner of each tile in OBJECT coordinates
+ *           (may be negative / overhang: the pads cover it)
+ * target    device [batch][Py][Px] target magnitude abs(prj) (sqrt(abs(prj)) for intensity data),
+ *           in the reference's fftshift-ed detector layout
+ * grad_rot  device [Z][Yp][Xp][2], accumulated into (+=); NULL = forward only
+ * grad_probe device [n_modes][Py][Px][2], accumulated into; may be NULL
+ * pred      device [batch][Py][Px] predicted magnitude (reference layout); may be NULL
+ * loss_sum  device [batch] : per-position sum over pixels of (pred-target)^2 (overwritten)
+ * grad_scale multiplies d loss/d pred: 2/(batch*Py*Px) for the reference's mean()
+ * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when grad_rot==NULL) */
+int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                           const float* target, float* grad_rot, float* grad_probe, float* pred, float* loss_sum,
+                           float grad_scale, void* workspace, size_t workspace_bytes);
+
+/* ---- R9  regulariser gradients --------------------------------------------------------
+ * L1Regularizer / TVRegularizer (adorym/regularizers.py:30-46, 95-110; adorym/util.py:1427-1440):
+ * grad_obj += d/dobj [ alpha_d*mean|delta| + alpha_b*mean|beta| + gamma*(TV(delta)+TV(beta)) ];
+ * reg_value (device float[1], may be NULL) += the regulariser value. */
+int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                 float* reg_value);
+
+/* ---- R13-R15  fused optimiser step + constraints on elements [lo, hi) of flat arrays -----
+ * AdamOptimizer.apply_gradient math (adorym/optimizers.py:309-318), then non-negativity clip,
+ * phase/absorption-only (adorym/ptychography.py:1135-1158) and the finite-support mask
+ * (adorym/array_ops.py:239-251).  Channel = flat index & 1 (delta even, beta odd).
+ * flags: bit0 non_negativity, bit1 zero channel 0 (absorption_only), bit2 zero channel 1 (phase_only).
+ * mask: device float [n/2] per-voxel multiplier or NULL.  grad_mult scales g on the fly. */
+#define ADM_FLAG_NONNEG 1
+#define ADM_FLAG_ZERO_CH0 2
+#define ADM_FLAG_ZERO_CH1 4
+int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
+                  float step_size, float b1, float b2, float eps, int flags, const float* mask);
+/* GDOptimizer.apply_gradient (adorym/optimizers.py:440-464); step_size already scheduled by the host */
+int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, float step_size, int flags,
+                const float* mask);
+/* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
+int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADM_H */

@@ -1,0 +1,285 @@
+"""
+Parity of the HIP path (through the C ABI) against the reference's golden vectors and the
+pinned CPU oracle.  All tests here need a real MI355X:  pytest -m gpu
+Tolerances follow SURVEY.md section 8(c):
+  forward |Psi|  : rel-L2 vs the fp64 reference <= 2e-6 (small S) / 5e-6 (S >= 32: 1e-7 * sqrt(#FFTs) growth)
+  loss           : rel <= 1e-5
+  gradient       : rel-L2 vs the fp64 reference <= 1e-4 and <= 3x the reference's own fp32 error (+ floor 1e-5)
+  Adam / GD      : rel 2e-6
+"""
+import os
+import numpy as np
+import pytest
+
+import cases
+from oracle import adorym_oracle as O      # checker only
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(G, name + '.npz'))
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) / np.linalg.norm(np.asarray(b, dtype=np.float64))
+
+
+@pytest.fixture(scope='module')
+def A():
+    import adorym_amd
+    return adorym_amd
+
+
+@pytest.fixture(scope='module')
+def ctx(A):
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+def c2(z):
+    return np.stack([z.real, z.imag], -1).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- F2/F3 tile level
+SINGLE_MODE = [n for n in cases.TILE_CASES if cases.TILE_CASES[n][5] == 1]
+
+
+@pytest.mark.parametrize('name', SINGLE_MODE)
+def test_tiles_forward_adjoint_vs_reference(A, ctx, name):
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    P, S, B = c['P'], c['S'], cases.TILE_B
+    # the B tiles stacked along y form an object [B*P, P, S, 2]; no rotation; positions (b*P, 0)
+    obj = c['guess'].reshape(B * P, P, S, 2)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM,
+                             free_prop_cm=c['free_prop_cm'], binning=c['binning'], fresnel_approx=c['fresnel_approx'],
+                             sign_convention=c['sigma'], normalize_fft=c['normalize_fft'])
+    d_obj = ctx.array(obj, np.float32)
+    d_grad = ctx.zeros(obj.shape)
+    d_probe = ctx.array(c2(c['probes'][0]))
+    d_gp = ctx.zeros((P, P, 2))
+    eng.set_batch(pos, g['meas'])
+    eng.rotate(d_obj, None)
+    eng.multislice(d_probe, grad_probe=d_gp, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    loss = eng.loss()
+    pred = eng.pred()
+    grad = d_grad.get().reshape(B, P, P, S, 2)
+    gp = d_gp.get()
+
+    tol_fwd = 2e-6 if S < 32 else 5e-6
+    assert rel(pred, g['pred_64']) < tol_fwd
+    assert abs(loss - g['loss_64']) <= 1e-5 * abs(g['loss_64'])
+    if 'grad_tiles_32' in g.files:
+        e_ref = rel(g['grad_tiles_32'], g['grad_tiles_64'])
+    else:
+        e_ref = float(g['grad_tiles_relerr_32'])
+    e = rel(grad, g['grad_tiles_64'])
+    assert e < 1e-4, e
+    assert e <= 3 * e_ref + 1e-5, (e, e_ref)
+    gp64 = np.stack([g['grad_probe_real_64'][0], g['grad_probe_imag_64'][0]], -1)
+    assert rel(gp, gp64) < 1e-4
+
+
+def test_forward_only_matches_full(A, ctx):
+    """grad_rot == NULL (predict-only) gives the same pred / loss as the full call."""
+    name = 'p16_s32_far_bin4'
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    P, S, B = c['P'], c['S'], cases.TILE_B
+    obj = c['guess'].reshape(B * P, P, S, 2)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, binning=c['binning'])
+    d_obj = ctx.array(obj, np.float32)
+    d_probe = ctx.array(c2(c['probes'][0]))
+    eng.set_batch(pos, g['meas'])
+    eng.rotate(d_obj, None)
+    eng.multislice(d_probe, want_grad=False, want_pred=True)
+    assert rel(eng.pred(), g['pred_64']) < 5e-6
+    assert abs(eng.loss() - g['loss_64']) <= 1e-5 * abs(g['loss_64'])
+
+
+def test_unsupported_configs_raise(A, ctx):
+    pos = np.array([(0, 0)])
+    with pytest.raises(NotImplementedError):
+        A.MultisliceEngine(ctx, (20, 20, 4), (20, 20), pos, 5000., 1e-7)            # size not compiled
+    with pytest.raises(NotImplementedError):
+        A.MultisliceEngine(ctx, (16, 16, 4), (16, 16), pos, 5000., 1e-7, n_probe_modes=3)
+    with pytest.raises(NotImplementedError):
+        A.MultisliceEngine(ctx, (16, 12, 4), (16, 12), pos, 5000., 1e-7)            # non-square
+
+
+# --------------------------------------------------------------------------- F4 rotation
+@pytest.mark.parametrize('name', list(cases.ROT_CASES))
+def test_rotation_vs_reference(A, ctx, name):
+    g = load('F4_rotation')
+    size, theta, obj, cot = cases.rot_case_inputs(name)
+    Y, X, Z = size
+    from adorym_amd.util import rotation_lookup
+    coords = rotation_lookup(size, theta)
+    assert np.array_equal(coords, g[name + '_coords'])
+    eng = A.MultisliceEngine(ctx, size, (X, X), np.array([(0, 0)]), 5000., 1e-7)   # no pads (Y may be < P: tile unused)
+    d_obj = ctx.array(obj, np.float32)
+    d_coords = ctx.array(coords.view(np.uint16))
+    eng.rotate(d_obj, d_coords)
+    rot = eng.obj_rot.get()                                   # [Z][Yp][Xp][2]
+    (py0, _), (px0, _) = eng.pads
+    rot = rot[:, py0:py0 + Y, px0:px0 + X, :].transpose(1, 2, 0, 3)       # -> [Y,X,Z,2]
+    assert np.abs(rot - g[name + '_rot_64']).max() < 5e-6
+    # adjoint: grad_rot := cot, grad_obj += R^T cot
+    full = np.zeros(eng.plan.rot_shape, np.float32)
+    full[:, py0:py0 + Y, px0:px0 + X, :] = cot.transpose(2, 0, 1, 3)
+    eng.grad_rot.set(full)
+    d_g = ctx.zeros(obj.shape)
+    eng.rotate_adjoint(d_g, d_coords)
+    assert np.abs(d_g.get() - g[name + '_adj_64']).max() < 3e-5
+
+
+# --------------------------------------------------------------------------- F5 optimisers
+def test_adam_gd_vs_reference(A, ctx):
+    from adorym_amd._lib import check
+    g = load('F5_optimizers')
+    x = ctx.array(g['x0'], np.float32)
+    m = ctx.zeros(g['x0'].shape)
+    v = ctx.zeros(g['x0'].shape)
+    n = x.size
+    for k, t in enumerate((0, 0, 1, 1)):
+        gk = ctx.array(g['gseq'][k], np.float32)
+        check(ctx.lib.adm_adam_step(ctx.handle, x.ptr, gk.ptr, m.ptr, v.ptr, 0, n, t, 1e-4, 0.9, 0.999, 1e-7, 0, None))
+        assert rel(x.get(), g['adam_x_32'][k]) < 2e-6
+        assert rel(m.get(), g['adam_m_32'][k]) < 2e-6
+        assert rel(v.get(), g['adam_v_32'][k]) < 2e-6
+        assert rel(x.get(), g['adam_x_64'][k]) < 2e-6
+    x = ctx.array(g['x0'], np.float32)
+    for k, t in enumerate((0, 25, 70, 200)):
+        gk = ctx.array(g['gseq'][k], np.float32)
+        step = O.gd_step_size(t, 1e-2, True, 20)
+        check(ctx.lib.adm_gd_step(ctx.handle, x.ptr, gk.ptr, 0, n, step, 0, None))
+        assert rel(x.get(), g['gd_x_32'][k]) < 2e-6
+
+
+def test_adam_shard_range_and_constraints(A, ctx):
+    """[lo,hi) sharding (multi-GPU ZeRO-style update), non-negativity, channel zeroing and mask."""
+    from adorym_amd._lib import check, FLAG_NONNEG, FLAG_ZERO_CH1
+    r = cases.rng(21)
+    shape = (4, 5, 6, 2)
+    x0 = r.standard_normal(shape).astype(np.float32) * 1e-3
+    gr = r.standard_normal(shape).astype(np.float32)
+    mask = (r.uniform(size=shape[:-1]) > 0.3).astype(np.float32)
+    xe, me, ve = O.adam_step(x0.copy(), gr, np.zeros_like(x0), np.zeros_like(x0), 3, step_size=1e-3)
+    xe = O.apply_constraints(xe, non_negativity=True, object_type='phase_only', mask=mask)
+    x = ctx.array(x0); m = ctx.zeros(shape); v = ctx.zeros(shape); gd = ctx.array(gr); dm = ctx.array(mask)
+    n = x.size
+    cut = 2 * 37          # shard boundary on a voxel boundary
+    for lo, hi in ((0, cut), (cut, n)):
+        check(ctx.lib.adm_adam_step(ctx.handle, x.ptr, gd.ptr, m.ptr, v.ptr, lo, hi, 3, 1e-3, 0.9, 0.999, 1e-7,
+                                    FLAG_NONNEG | FLAG_ZERO_CH1, dm.ptr))
+    assert np.allclose(x.get(), xe, rtol=2e-6, atol=1e-12)
+    assert np.allclose(m.get(), me, rtol=2e-6, atol=0)
+
+
+# --------------------------------------------------------------------------- F7 regularisers
+def test_reg_grad_vs_reference(A, ctx):
+    from adorym_amd._lib import check
+    g = load('F7_regularizers')
+    obj = g['obj']
+    eng = A.MultisliceEngine(ctx, obj.shape[:3], (12, 12), np.array([(0, 0)]), 5000., 1e-7)
+    d_obj = ctx.array(obj, np.float32)
+    for (ad, ab, gm, gref, vref) in ((1.5, 0.7, 0.0, g['l1_grad'], g['l1_val']), (0.0, 0.0, 2.0, g['tv_grad'], g['tv_val'])):
+        d_g = ctx.zeros(obj.shape)
+        d_v = ctx.zeros((1,))
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, d_obj.ptr, ad, ab, gm, d_g.ptr, d_v.ptr))
+        assert rel(d_g.get(), gref) < 1e-6
+        assert abs(d_v.get()[0] - vref) <= 1e-5 * abs(vref)
+
+
+# --------------------------------------------------------------------------- whole step vs oracle
+@pytest.mark.parametrize('free_prop_cm', ['inf', 0])
+def test_full_step_rotation_overlap_padding(A, ctx, free_prop_cm):
+    """rotate -> overlapping, overhanging tiles -> multislice -> adjoint -> rotate^T, vs the fp64 oracle."""
+    r = cases.rng(31)
+    N, P, S = 32, 16, 32
+    obj = np.stack([1e-3 * cases.smooth_field((N, N, S), 5), 1e-4 * cases.smooth_field((N, N, S), 6)], -1)
+    pos = np.array([(-4, -4), (-4, 4), (4, 4), (12, 12), (20, 20), (20, 12), (4, 20)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    theta = np.float32(1.234)
+    coords = O.rotation_coords((N, N, S), theta)
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=free_prop_cm)
+    truth = obj * 1.3
+    tiles, _ = O.extract_tiles(O.rotate_fwd(truth, coords, 'float64'), pos, (P, P))
+    target = np.abs(O.multislice_forward(tiles, probe, phys, 'float64'))
+    loss_o, pred_o, g_o, gp_o = O.forward_adjoint_object(obj, coords, probe, pos, target, phys, 'float64')
+    _, _, g32, _ = O.forward_adjoint_object(obj.astype(np.float32), coords, probe, pos, target, phys, 'float32')
+
+    eng = A.MultisliceEngine(ctx, (N, N, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=free_prop_cm)
+    d_obj = ctx.array(obj, np.float32)
+    d_coords = ctx.array(coords.view(np.uint16))
+    d_probe = ctx.array(c2(probe))
+    for footprint in (True, False):
+        d_grad = ctx.zeros(obj.shape)
+        d_gp = ctx.zeros((P, P, 2))
+        loss = eng.loss_and_grad(d_obj, d_grad, d_coords, d_probe, pos, target, grad_probe=d_gp, footprint=footprint)
+        assert abs(loss - loss_o) <= 1e-5 * abs(loss_o)
+        e = rel(d_grad.get(), g_o)
+        assert e < 1e-4 and e <= 3 * rel(g32, g_o) + 1e-5, (e, rel(g32, g_o))
+        assert rel(d_gp.get(), c2(gp_o[0])) < 1e-4
+
+
+def test_full_depth_256_slices_vs_oracle(A, ctx):
+    """Config-3 depth (P=72, S=256, far field) on a small lateral object: forward and gradient vs the fp64 oracle."""
+    r = cases.rng(41)
+    P, S, Y, X = 72, 256, 84, 84
+    obj = np.stack([3e-4 * cases.smooth_field((Y, X, S), 7, cutoff=0.15), 1.5e-5 * cases.smooth_field((Y, X, S), 8, cutoff=0.15)], -1)
+    pos = np.array([(0, 0), (12, 12), (-6, 5)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm='inf')
+    tiles, _ = O.extract_tiles(obj * 1.2, pos, (P, P))
+    target = np.abs(O.multislice_forward(tiles, probe, phys, 'float64'))
+    loss_o, pred_o, g_o, _ = O.forward_adjoint_object(obj, None, probe, pos, target, phys, 'float64')
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM)
+    d_obj = ctx.array(obj, np.float32)
+    d_grad = ctx.zeros(obj.shape)
+    d_probe = ctx.array(c2(probe))
+    eng.set_batch(pos, target)
+    eng.rotate(d_obj, None)
+    eng.multislice(d_probe, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    assert rel(eng.pred(), pred_o) < 2e-5          # 511 FFT pairs deep: fp32 growth ~1e-7*sqrt(#ops)
+    assert abs(eng.loss() - loss_o) <= 1e-4 * abs(loss_o)
+    assert rel(d_grad.get(), g_o) < 5e-4
+
+
+def test_c3_shape_energy_conservation(A, ctx):
+    """Full BASELINE size (256^3 object, 72x72 probe, 256 slices, minibatch 32): with beta = 0 the
+    multislice operator is unitary (|H| = 1, |c| = 1), so by Parseval sum(pred^2) = Py*Px*sum|probe|^2
+    for every position -- a size-independent property of the forward path at full scale."""
+    N, P, B = 256, 72, 32
+    r = cases.rng(51)
+    ys = np.arange(23) * 12 - 36
+    allpos = np.array([(y, x) for y in ys for x in ys])
+    pos = allpos[200:200 + B]
+    eng = A.MultisliceEngine(ctx, (N, N, N), (P, P), allpos, cases.ENERGY_EV, cases.PSIZE_CM)
+    obj = np.zeros((N, N, N, 2), np.float32)
+    obj[..., 0] = (3e-4 * r.uniform(size=(N, N, N))).astype(np.float32)
+    d_obj = ctx.array(obj)
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    d_probe = ctx.array(c2(probe))
+    target = np.zeros((B, P, P), np.float32)
+    from adorym_amd.util import rotation_lookup
+    d_coords = ctx.array(rotation_lookup((N, N, N), np.float32(0.4)).view(np.uint16))
+    d_grad = ctx.zeros(obj.shape)
+    loss = eng.loss_and_grad(d_obj, d_grad, d_coords, d_probe, pos, target)
+    eng.multislice(d_probe, want_grad=False, want_pred=True)
+    pred = eng.pred().astype(np.float64)
+    e_in = P * P * np.sum(np.abs(probe) ** 2)
+    e_out = (pred ** 2).sum(axis=(1, 2))
+    assert np.all(np.abs(e_out / e_in - 1) < 2e-5), np.abs(e_out / e_in - 1).max()
+    assert np.isfinite(loss) and abs(loss - (pred ** 2).mean()) <= 1e-5 * loss
+    gg = d_grad.get()
+    assert np.all(np.isfinite(gg)) and np.abs(gg).max() > 0
+    # beta-gradient identity for target = 0 : dL/dbeta_s summed over a tile = -2*k1*mean-energy ... (sign check)
+    assert gg[..., 1].sum() < 0
