@@ -21,7 +21,7 @@ class PlanDesc(C.Structure):
                 ('hfree_re', C.POINTER(C.c_float)), ('hfree_im', C.POINTER(C.c_float))]
 
 
-_VP, _SZ, _I, _F = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+_VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol include/adm.h declares
 SIGNATURES = {
@@ -50,8 +50,8 @@ SIGNATURES = {
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
-    'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _F, _F, _F, _F, _I, _VP]),
-    'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _F, _I, _VP]),
+    'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
+    'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
     'adm_axpy': (_I, [_VP, _VP, _VP, _F, _SZ]),
 }
 

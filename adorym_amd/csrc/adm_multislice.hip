@@ -234,12 +234,15 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 #pragma unroll
     for (int k = 0; k < R1; ++k) c.tw[k] = p.twid[(c.t * k) % N];
     const int kx = freq_of_pos<R1, R2>(c.line);
-    const float inv_n2 = 1.0f / (float)(N * N);
+    // 1/N^2 of the inverse transform is folded into H with ONE rounding per element (divide in
+    // double): multiplying by fl(1/N^2) would scale every propagation by the same (1+eps) and the
+    // bias would grow linearly with the number of slices.
+    const double n2 = (double)(N * N);
 #pragma unroll
     for (int k = 0; k < R2; ++k) {
         int ky = (c.t % R1) + R1 * k;
         cf h = p.h[ky * N + kx];
-        c.hs[k] = make_float2(h.x * inv_n2, h.y * inv_n2);
+        c.hs[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
     }
 
     const int2 ps = p.pos[b];
@@ -281,7 +284,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         for (int k = 0; k < R2; ++k) {
             int ky = (c.t % R1) + R1 * k;
             cf h = p.hfree[ky * N + kx];
-            hf[k] = make_float2(h.x * inv_n2, h.y * inv_n2);
+            hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
         }
         convolve<N, R1, R2, false>(c, a, hf);
     }
@@ -337,7 +340,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             for (int k = 0; k < R2; ++k) {
                 int ky = (c.t % R1) + R1 * k;
                 cf h = p.hfree[ky * N + kx];
-                hf[k] = make_float2(h.x * inv_n2, h.y * inv_n2);
+                hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
             }
             convolve<N, R1, R2, true>(c, a, hf);
         }

@@ -232,26 +232,26 @@ extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, flo
 }
 
 extern "C" int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
-                             float step_size, float b1, float b2, float eps, int flags, const float* mask) {
+                             double step_size, double b1, double b2, double eps, int flags, const float* mask) {
     if (!ctx || !x || !g || !m || !v) return fail(ADM_ERR_INVALID, "adm_adam_step: null argument");
     if (hi <= lo) return ADM_OK;
     // the reference evaluates the scalars in Python doubles and torch casts them to fp32 at the op
-    const double b1d = (double)b1, b2d = (double)b2;
+    const double b1d = b1, b2d = b2;
     const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     double p1 = 1.0, p2 = 1.0;
     for (int k = 0; k < i_batch + 1; ++k) { p1 *= b1d; p2 *= b2d; }
     const float q1 = (float)(1.0 - p1), q2 = (float)(1.0 - p2);
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi, step_size, b1, b2,
-                       omb1, omb2, q1, q2, eps, flags, mask);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi, (float)step_size,
+                       (float)b1, (float)b2, omb1, omb2, q1, q2, (float)eps, flags, mask);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }
 
-extern "C" int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, float step_size, int flags,
+extern "C" int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, double step_size, int flags,
                            const float* mask) {
     if (!ctx || !x || !g) return fail(ADM_ERR_INVALID, "adm_gd_step: null argument");
     if (hi <= lo) return ADM_OK;
-    hipLaunchKernelGGL(gd_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, lo, hi, step_size, flags, mask);
+    hipLaunchKernelGGL(gd_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, lo, hi, (float)step_size, flags, mask);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

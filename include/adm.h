@@ -140,14 +140,15 @@ int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b,
  * phase/absorption-only (adorym/ptychography.py:1135-1158) and the finite-support mask
  * (adorym/array_ops.py:239-251).  Channel = flat index & 1 (delta even, beta odd).
  * flags: bit0 non_negativity, bit1 zero channel 0 (absorption_only), bit2 zero channel 1 (phase_only).
- * mask: device float [n/2] per-voxel multiplier or NULL.  grad_mult scales g on the fly. */
+ * mask: device float [n/2] per-voxel multiplier or NULL.  Hyper-parameters are doubles because the
+ * reference forms 1-b1, 1-b1^(t+1) ... in Python doubles before torch casts them to fp32. */
 #define ADM_FLAG_NONNEG 1
 #define ADM_FLAG_ZERO_CH0 2
 #define ADM_FLAG_ZERO_CH1 4
 int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
-                  float step_size, float b1, float b2, float eps, int flags, const float* mask);
+                  double step_size, double b1, double b2, double eps, int flags, const float* mask);
 /* GDOptimizer.apply_gradient (adorym/optimizers.py:440-464); step_size already scheduled by the host */
-int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, float step_size, int flags,
+int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, double step_size, int flags,
                 const float* mask);
 /* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
 int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);
