@@ -1,0 +1,111 @@
+"""
+Data-parallel object state: the replicated object, its gradient buffer and the (sharded) optimiser
+moments, plus the exchange + update step that replaces
+
+    gradient.arr = comm.allreduce(gradient.arr)                 adorym/ptychography.py:1113-1114
+    obj.arr = opt.apply_gradient(obj.arr, gradient, i, **opts)  adorym/ptychography.py:1120-1129
+    constraints / mask                                          adorym/ptychography.py:1135-1158, 1210-1215
+
+with  reduce_scatter(sum) -> fused Adam/GD + constraints on the owned shard -> all_gather.
+The element-wise kernels come from an ``ops`` object: HipOps (libadm; the product) -- tests inject a
+NumPy stand-in to exercise the sharding logic on CPU with the gloo backend.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .device import DeviceArray
+
+
+class HipOps(object):
+    """Element-wise update kernels of libadm on flat fp32 device buffers."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def wrap(self, tensor, n):
+        """Non-owning DeviceArray over a torch CUDA tensor (kept alive by the caller)."""
+        return DeviceArray(self.ctx, (n,), np.float32, ptr=tensor.data_ptr())
+
+    def alloc(self, n):
+        return self.ctx.zeros((n,))
+
+    def zero(self, buf):
+        buf.zero_()
+
+    def copy(self, dst, dst_off, src, src_off, n):
+        check(self.ctx.lib.adm_d2d(self.ctx.handle, dst.ptr + 4 * dst_off, src.ptr + 4 * src_off, 4 * n))
+
+    def adam(self, x, g, g_base, m, v, mv_base, lo, hi, i_batch, step_size, b1, b2, eps, flags, mask):
+        """x indexed absolutely over [lo,hi); g at (i - g_base); m, v at (i - mv_base)."""
+        check(self.ctx.lib.adm_adam_step(self.ctx.handle, x.ptr, g.ptr - 4 * g_base, m.ptr - 4 * mv_base, v.ptr - 4 * mv_base,
+                                         lo, hi, int(i_batch), float(step_size), float(b1), float(b2), float(eps), int(flags),
+                                         mask.ptr if mask is not None else None))
+
+    def gd(self, x, g, g_base, lo, hi, step_size, flags, mask):
+        check(self.ctx.lib.adm_gd_step(self.ctx.handle, x.ptr, g.ptr - 4 * g_base, lo, hi, float(step_size), int(flags),
+                                       mask.ptr if mask is not None else None))
+
+
+def constraint_flags(non_negativity=False, object_type='normal'):
+    f = 0
+    if non_negativity:
+        f |= _lib.FLAG_NONNEG
+    if object_type == 'absorption_only':
+        f |= _lib.FLAG_ZERO_CH0
+    if object_type == 'phase_only':
+        f |= _lib.FLAG_ZERO_CH1
+    return f
+
+
+class DataParallelObject(object):
+    """Replicated object [Y,X,Z,2] + gradient + sharded moments across ``comm.size`` ranks."""
+
+    def __init__(self, ops, comm, shape, n_moments=2):
+        self.ops = ops
+        self.comm = comm
+        self.shape = tuple(int(s) for s in shape)
+        self.n = int(np.prod(self.shape))
+        R = comm.size
+        self.n_pad = -(-self.n // (2 * R)) * (2 * R)
+        self.per = self.n_pad // R
+        self.lo = comm.rank * self.per
+        self.hi = min(self.lo + self.per, self.n)
+        self._keep = []
+        if R > 1:
+            t_obj, t_grad = comm.alloc(self.n_pad), comm.alloc(self.n_pad)
+            self.t_obj, self.t_grad = t_obj, t_grad
+            self.t_gshard, self.t_xshard = comm.alloc(self.per), comm.alloc(self.per)
+            self.obj = ops.wrap(t_obj, self.n_pad)
+            self.grad = ops.wrap(t_grad, self.n_pad)
+            self.gshard = ops.wrap(self.t_gshard, self.per)
+            self.xshard = ops.wrap(self.t_xshard, self.per)
+        else:
+            self.obj = ops.alloc(self.n_pad)
+            self.grad = ops.alloc(self.n_pad)
+        self.moments = [ops.alloc(self.per) for _ in range(n_moments)]   # ZeRO-1: only the owned shard
+
+    # gradient exchange + update ------------------------------------------------------------
+    def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None):
+        """optimizer: 'adam' | 'gd'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict."""
+        R = self.comm.size
+        if R > 1:
+            self.comm.reduce_scatter_sum(self.t_grad, self.t_gshard)
+            g, g_base = self.gshard, self.lo
+        else:
+            g, g_base = self.grad, 0
+        if self.hi > self.lo:
+            if optimizer == 'adam':
+                self.ops.adam(self.obj, g, g_base, self.moments[0], self.moments[1], self.lo, self.lo, self.hi, i_batch,
+                              options.get('step_size', 0.001), options.get('b1', 0.9), options.get('b2', 0.999),
+                              options.get('eps', 1e-7), flags, mask)
+            elif optimizer == 'gd':
+                self.ops.gd(self.obj, g, g_base, self.lo, self.hi, options['step_size'], flags, mask)
+            else:
+                raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
+        if R > 1:
+            self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
+            self.comm.all_gather(self.t_obj, self.t_xshard)
+
+    def zero_grad(self):
+        self.ops.zero(self.grad)

@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""
+Benchmark of the hot path on BASELINE.json's metric: probe-positions/s (forward + gradient),
+256^3 multislice ptychotomography (config 3), minibatch 32 per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one minibatch iteration of reconstruct_ptychography (update_scheme='immediate'):
+rotate object to theta (footprint planes) -> multislice forward + far-field LSQ loss + adjoint for the
+32 positions -> rotate gradient back -> L1+TV regulariser gradient -> [reduce-scatter over ranks] ->
+fused Adam (+ all-gather).  Nothing is skipped inside the timed region.  With N ranks the global batch
+is N x 32 positions (the reference's `mpirun -n N` semantics): weak scaling.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
+    """SURVEY.md 8(d) / BASELINE.md 3: tile data read fwd + read bwd + gradient written once,
+    measured magnitudes once, object read once + object gradient written once."""
+    return 4 * (3 * B * Py * Px * S * 2 + B * Py * Px + 2 * (2 * V))
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The pinned NumPy oracle (fp32, the reference's dtype) timed on this host: forward + hand adjoint
+    of the multislice chain for a bounded sample of probe positions (rotation excluded => favours the CPU)."""
+    from oracle import adorym_oracle as O
+    P = cfg['probe_size'][0]
+    S = cfg['obj_size'][2]
+    phys = O.Physics(cfg['probe_size'], cfg['energy_ev'], cfg['psize_cm'], free_prop_cm=cfg['free_prop_cm'])
+    r = np.random.default_rng(0)
+    from adorym_amd.workloads import probe_array
+    pa = probe_array(cfg)
+    probe = pa[..., 0] + 1j * pa[..., 1]
+    nb, done, t_used = 2, 0, 0.0
+    while True:
+        tiles = np.stack([r.normal(8.7e-7, 1e-7, (nb, P, P, S)), r.normal(5.1e-8, 1e-8, (nb, P, P, S))], -1).astype(np.float32)
+        meas = np.abs(r.standard_normal((nb, P, P))).astype(np.float32)
+        t0 = time.perf_counter()
+        O.forward_adjoint_tiles(tiles, probe, meas, phys, 'float32')
+        t_used += time.perf_counter() - t0
+        done += nb
+        if t_used > 0.5 * seconds_budget or done >= 64:
+            break
+    return {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
+                      '(oracle/adorym_oracle.py), rotation and optimiser excluded, %.1f s of CPU work, host has %d cores'
+                      % (done, P, S, t_used, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--minibatch', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import adorym_amd as A
+    from adorym_amd import comm as C, workloads as W
+    from adorym_amd.dp import DataParallelObject, HipOps
+    from adorym_amd.util import rotation_lookup
+    from adorym_amd._lib import check
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    comm = C.TorchComm('nccl', device_index=local_rank) if world > 1 else C.LocalComm()
+    rank = comm.rank
+    stream = int(torch.cuda.current_stream().cuda_stream)
+    ctx = A.Context(local_rank, stream=stream if stream else None)
+
+    cfg = W.c3_config()
+    B = args.minibatch
+    Y, X, Z = cfg['obj_size']
+    Py, Px = cfg['probe_size']
+    eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'],
+                             free_prop_cm=cfg['free_prop_cm'], binning=cfg['binning'], max_batch=B)
+    ops = HipOps(ctx)
+    state = DataParallelObject(ops, comm, (Y, X, Z, 2))
+    # reference-default Gaussian random initial guess (throughput is data independent)
+    state.obj.view(0, (Y, X, Z, 2)).set(W.random_guess((Y, X, Z), seed=1))
+    probe = ctx.array(W.probe_array(cfg))
+    n_theta_used = max(2, min(8, args.steps + args.warmup))
+    thetas = np.linspace(cfg['theta_st'], cfg['theta_end'], cfg['n_theta'], dtype='float32')[:: cfg['n_theta'] // n_theta_used][:n_theta_used]
+    tables = [ctx.array(rotation_lookup(cfg['obj_size'], th).view(np.uint16)) for th in thetas]
+    pos_all = cfg['probe_pos']
+    n_pos = len(pos_all)
+
+    # synthetic measurements: the forward model itself applied to a foam phantom ("data": "synthetic")
+    truth = ctx.array(W.foam_object(cfg['obj_size'], seed=0))
+    total = args.steps + args.warmup
+    plan_batches = []
+    for k in range(total):
+        it = k % n_theta_used
+        start = ((k // n_theta_used) * world * B + rank * B) % (n_pos - B + 1)
+        plan_batches.append((it, np.arange(start, start + B)))
+    targets = {}
+    for it, ind in plan_batches:
+        key = (it, int(ind[0]))
+        if key in targets:
+            continue
+        eng.set_batch(pos_all[ind], np.zeros((B, Py, Px), np.float32))
+        eng.rotate(truth, tables[it], eng.y_footprint(pos_all[ind]))
+        eng.multislice(probe, want_grad=False, want_pred=True)
+        t = ctx.empty((B, Py, Px))
+        t.copy_from(eng._pred.view(0, (B, Py, Px)))
+        targets[key] = t
+    truth.free()
+    ctx.sync()
+
+    opt_options = {'step_size': cfg['learning_rate']}
+    ev_ms = [ctx.event(), ctx.event()]
+    ms_kernel_total = [0.0]
+    loss_box = [0.0]
+
+    def step(k, timed):
+        it, ind = plan_batches[k]
+        pos = pos_all[ind]
+        state.zero_grad()
+        eng.set_batch(pos, targets[(it, int(ind[0]))])
+        yr = eng.y_footprint(pos)
+        eng.rotate(state.obj, tables[it], yr)
+        eng.grad_rot.zero_()
+        if timed:
+            ev_ms[0].record()
+        eng.multislice(probe, zero_grad_rot=False)
+        if timed:
+            ev_ms[1].record()
+        eng.rotate_adjoint(state.grad, tables[it], yr)
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
+                                   state.grad.ptr, None))
+        state.exchange_and_update('adam', k, opt_options)
+        if timed:
+            ms_kernel_total[0] += ev_ms[0].elapsed_ms(ev_ms[1])   # blocks on the kernel only; the rest stays queued
+        loss_box[0] = eng.loss()
+
+    for k in range(args.warmup):
+        step(k, False)
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, total):
+        step(k, True)
+    comm.barrier()
+    torch.cuda.synchronize()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = world * B * args.steps / dt
+        kern_ms = ms_kernel_total[0] / args.steps
+        alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get('ms_fwd_adj_kernel_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'probe-positions/sec (fwd+grad), 256^3 multislice ptycho', 'value': value, 'unit': 'probe-positions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': cfg['name'], 'object': [Y, X, Z], 'probe': [Py, Px], 'slices': Z,
+                       'minibatch_per_gpu': B, 'global_batch': world * B, 'update_scheme': 'immediate', 'optimizer': 'adam',
+                       'regularizers': 'L1+TV', 'far_field': True, 'parallelism': 'dp%d' % world,
+                       'step': 'rotate_fwd + multislice fwd/loss/adjoint + rotate_adj + reg_grad + (reduce_scatter) + adam (+all_gather)'},
+            'roofline': {'bound': 'hbm', 'kernel': 'ms_fwd_adj_kernel<72,8,9>', 'achieved': achieved, 'peak': PEAK_HBM_GBS,
+                         'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': alg, 'kernel_ms': kern_ms,
+                         'whole_step_frac': alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            'loss_last': loss_box[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        comm.close()
+
+
+if __name__ == '__main__':
+    main()
