@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libadm.so')
+LIB_PATH = os.environ.get('ADM_LIB_PATH') or os.path.join(_HERE, 'libadm.so')   # ADM_LIB_PATH: experiment builds only
 
 ADM_OK, ADM_ERR_INVALID, ADM_ERR_HIP, ADM_ERR_UNSUPPORTED, ADM_ERR_NOMEM = 0, -1, -2, -3, -4
 DET_NONE, DET_FARFIELD, DET_FRESNEL = 0, 1, 2
@@ -48,7 +48,8 @@ SIGNATURES = {
     'adm_plan_workspace_bytes': (_SZ, [_VP, _I]),
     'adm_rotate_fwd': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
-    'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_tile_grad_accumulate': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),

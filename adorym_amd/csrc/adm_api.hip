@@ -208,24 +208,26 @@ extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
 
 extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
     if (!plan || batch <= 0) return 0;
-    return (size_t)batch * plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x) * sizeof(float2);
+    // [stash | tile gradients | cover lists (Yp*Xp*(1+48) u32) | overflow flag]
+    const size_t per = (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x) * sizeof(float2);
+    return 2 * (size_t)batch * per + (size_t)plan->Yp * plan->Xp * 49 * sizeof(unsigned) + 64;
 }
 
 extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                                      const float* target, float* grad_rot, float* grad_probe, float* pred, float* loss_sum,
+                                      const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                                       float grad_scale, void* workspace, size_t workspace_bytes) {
     if (!plan || !obj_rot || !probe || !pos || !target || !loss_sum)
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: batch must be positive");
     const adm_plan_desc& d = plan->d;
-    if (grad_rot) {
+    if (want_grad) {
         if (!workspace || workspace_bytes < adm_plan_workspace_bytes(plan, batch))
             return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: workspace too small");
     }
     MsParams p;
     std::memset(&p, 0, sizeof(p));
     p.obj_rot = (const float2*)obj_rot;
-    p.grad_rot = (float2*)grad_rot;
+    p.want_grad = want_grad ? 1 : 0;
     p.probe = (const float2*)probe;
     p.grad_probe = (float2*)grad_probe;
     p.pos = (const int2*)pos;
@@ -233,6 +235,7 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
     p.pred = pred;
     p.loss_sum = loss_sum;
     p.stash = (float2*)workspace;
+    p.gtile = (float2*)workspace + (size_t)batch * plan->n_steps * ms_r1_for(d.probe_x) * ms_threads_for(d.probe_x);
     p.h = plan->h_dev;
     p.hfree = plan->hfree_dev;
     p.twid = plan->twid_dev;

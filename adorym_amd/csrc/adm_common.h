@@ -32,14 +32,15 @@ int hip_fail(hipError_t e, const char* what);
 
 struct MsParams {
     const float2* obj_rot;     // [Z][Yp][Xp] (delta, beta)
-    float2* grad_rot;          // same layout, atomically accumulated; nullptr = forward only
+    int want_grad;             // 0 = forward only
     const float2* probe;       // [P][P]
     float2* grad_probe;        // [P][P] or nullptr
     const int2* pos;           // [B] (y, x) in object coordinates
     const float* target;       // [B][P][P]
     float* pred;               // [B][P][P] or nullptr
     float* loss_sum;           // [B]
-    float2* stash;             // [B][n_steps][R1][NT]
+    float2* stash;             // [B][n_steps][R1][NT] post-modulation wavefields
+    float2* gtile;             // [B][n_steps][R1][NT] per-position tile gradients (d/ddelta, d/dbeta)
     const float2* h;           // [P][P] natural order, unscaled
     const float2* hfree;       // [P][P] or nullptr
     const float2* twid;        // [N] exp(-2 pi i j / N)
@@ -51,6 +52,7 @@ struct MsParams {
     float grad_scale;
 };
 int ms_threads_for(int n);
+int ms_r2_for(int n);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 }  // namespace adm

@@ -18,8 +18,9 @@
 //     values (pre-divided by Py*Px) in VGPRs for the whole kernel: H costs no memory traffic;
 //   * post-modulation wavefields psi'_s are stashed to HBM in thread-native order (perfectly
 //     coalesced 8-B/lane stores) and read back in the reverse sweep;
-//   * delta/beta tile slices are read straight from the slice-major rotated object
-//     [Z][Yp][Xp][2]; tile gradients go back with global float atomics (tiles overlap).
+//   * delta/beta tile slices are read straight from the slice-major rotated object [Z][Yp][Xp][2];
+//     tile gradients are stored per position in the same thread-native order and overlap-added by a
+//     separate streaming kernel (tile_accumulate_kernel): no atomics in the slice loop.
 #include <hip/hip_runtime.h>
 #include "adm_common.h"
 #include "adm_fft.h"
@@ -203,15 +204,76 @@ __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], 
 
 __device__ __forceinline__ cf conjf2(cf a) { return make_float2(a.x, -a.y); }
 
+// Branch-free single-precision sin/cos: 3-term Cody-Waite reduction by pi/2 (exact product steps via
+// fma, good for |x| < ~1e5) + Cephes minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ocml's sincosf
+// is equally accurate but costs several hundred instructions and dozens of branches per call, which
+// made the slice modulation as expensive as the FFTs.
+__device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
+    const float q = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(q, -1.57079601287841796875f, x);
+    r = fmaf(q, -3.1391647326017846353e-7f, r);
+    r = fmaf(q, -5.3903025299577647655e-15f, r);
+    const int iq = (int)q;
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    const bool swap = (iq & 1) != 0;
+    const float s0 = swap ? cp : sp;
+    const float c0 = swap ? sp : cp;
+    sn = (iq & 2) ? -s0 : s0;
+    cs = ((iq + 1) & 2) ? -c0 : c0;
+}
+// exp(x) ~1 ulp: 2^(x*log2e) with the product's rounding error and the low part of log2(e)
+// re-injected to first order; v_exp_f32 itself is a 1-ulp instruction.
+__device__ __forceinline__ float exp_fast(float x) {
+    const float L2E = 1.44269502162933349609375f;
+    const float t = x * L2E;
+    float e = fmaf(x, L2E, -t);
+    e = fmaf(x, 1.925963033500e-8f, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * 0.69314718055994530942f, r);
+}
+
 // exp(-k1*beta) * (cos, sin)(-sigma*k1*delta)      (adorym/wrappers.py:600-608)
 __device__ __forceinline__ cf modulator(float2 db, float k1, float sigma) {
-    float e = expf(-k1 * db.y);
+    const float e = exp_fast(-k1 * db.y);
     float sn, cs;
-    sincosf(-sigma * k1 * db.x, &sn, &cs);
+    sincos_fast(-sigma * k1 * db.x, sn, cs);
     return make_float2(e * cs, e * sn);
 }
 
-template <int N, int R1, int R2>
+// sum of the (delta, beta) pairs of the slices of one modulation step for this thread's R1 pixels.
+// BIN1 (binning == 1): pure loads, so the caller can issue them one step ahead and let the
+// propagation hide their latency.
+template <int R1, int R2, bool BIN1>
+__device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restrict__ base, size_t slice_stride, int step,
+                                        int binning, int Z) {
+    if (BIN1) {
+        const float2* q = base + (size_t)step * slice_stride;
+#pragma unroll
+        for (int k = 0; k < R1; ++k) db[k] = q[k * R2];
+    } else {
+        const int s_lo = step * binning;
+        const int s_hi = min(s_lo + binning, Z);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) db[k] = make_float2(0.f, 0.f);
+        for (int s = s_lo; s < s_hi; ++s) {
+            const float2* q = base + (size_t)s * slice_stride;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const float2 v = q[k * R2];
+                db[k].x += v.x;
+                db[k].y += v.y;
+            }
+        }
+    }
+}
+
+template <int N, int R1, int R2, bool BIN1>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[N * GE::PITCH];
@@ -250,30 +312,37 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     // element n1 of this thread: pixel (row = line, col = n1*R2 + t) of the tile
     const size_t slice_stride = (size_t)p.Yp * p.Xp;
     const size_t tile_off = (size_t)(py + c.line) * p.Xp + px + c.t;   // + n1*R2 + slice*slice_stride
-    const bool do_grad = (p.grad_rot != nullptr);
+    const bool do_grad = (p.want_grad != 0);
     float2* stash = p.stash + (size_t)b * p.n_steps * R1 * GE::NT + tid;
+    float2* gtile = p.gtile + (size_t)b * p.n_steps * R1 * GE::NT + tid;
 
     cf a[R1];
 #pragma unroll
     for (int k = 0; k < R1; ++k) a[k] = c.act1 ? p.probe[c.line * N + k * R2 + c.t] : make_float2(0.f, 0.f);
 
     // ================= forward sweep =================
+    const float2* tile_base = p.obj_rot + tile_off;
+    float2 db[R1];
+    if (c.act1) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, 0, p.binning, p.Z);
     for (int step = 0; step < p.n_steps; ++step) {
         if (c.act1) {
-            const int s_lo = step * p.binning;
-            const int s_hi = min(s_lo + p.binning, p.Z);
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                float2 db = make_float2(0.f, 0.f);
-                for (int s = s_lo; s < s_hi; ++s) {
-                    float2 v = p.obj_rot[s * slice_stride + tile_off + k * R2];
-                    db.x += v.x; db.y += v.y;
-                }
-                a[k] = cmul(a[k], modulator(db, p.k1, p.sigma));
+#ifndef ADM_ABL_NOMOD
+                a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
+#else
+                a[k] = cmul(a[k], db[k]);
+#endif
+#ifndef ADM_ABL_NOSTASH
                 if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
+#endif
             }
+            // next step's tile slice is requested before the propagation so its latency is hidden
+            if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
         }
+#ifndef ADM_ABL_NOCONV
         if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, c.hs);
+#endif
     }
 
     // ================= detector plane: loss and dL/dpsi_exit =================
@@ -359,32 +428,43 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 
     // ================= reverse sweep =================
     const float sk1 = p.sigma * p.k1;
+    cf psi[R1];
+    if (c.act1) {
+        load_db<R1, R2, BIN1>(db, tile_base, slice_stride, p.n_steps - 1, p.binning, p.Z);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((p.n_steps - 1) * R1 + k) * GE::NT];
+    }
     for (int step = p.n_steps - 1; step >= 0; --step) {
         if (c.act1) {
-            const int s_lo = step * p.binning;
-            const int s_hi = min(s_lo + p.binning, p.Z);
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                float2 db = make_float2(0.f, 0.f);
-                for (int s = s_lo; s < s_hi; ++s) {
-                    float2 v = p.obj_rot[s * slice_stride + tile_off + k * R2];
-                    db.x += v.x; db.y += v.y;
-                }
-                cf psi = stash[(size_t)(step * R1 + k) * GE::NT];
                 // z = conj(G) * psi'
-                float zr = a[k].x * psi.x + a[k].y * psi.y;
-                float zi = a[k].x * psi.y - a[k].y * psi.x;
-                float gd = sk1 * zi;
-                float gb = -p.k1 * zr;
-                for (int s = s_lo; s < s_hi; ++s) {
-                    float* gp = reinterpret_cast<float*>(p.grad_rot + s * slice_stride + tile_off + k * R2);
-                    atomicAdd(gp, gd);
-                    atomicAdd(gp + 1, gb);
-                }
-                a[k] = cmulc(a[k], modulator(db, p.k1, p.sigma));
+                const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
+                const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
+                const float gd = sk1 * zi;
+                const float gb = -p.k1 * zr;
+                // tile gradient of this modulation step, thread-native layout (coalesced 8-B/lane store);
+                // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
+                gtile[(size_t)(step * R1 + k) * GE::NT] = make_float2(gd, gb);
+#ifndef ADM_ABL_NOMOD
+                a[k] = cmulc(a[k], modulator(db[k], p.k1, p.sigma));
+#else
+                a[k] = cmulc(a[k], db[k]);
+#endif
+            }
+            if (step > 0) {
+                load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
+#pragma unroll
+#ifndef ADM_ABL_NOSTASH
+                for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((step - 1) * R1 + k) * GE::NT];
+#else
+                for (int k = 0; k < R1; ++k) psi[k] = a[k];
+#endif
             }
         }
+#ifndef ADM_ABL_NOCONV
         if (step > 0) convolve<N, R1, R2, true>(c, a, c.hs);
+#endif
     }
     if (p.grad_probe && c.act1) {
 #pragma unroll
@@ -398,7 +478,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
-    hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2>), dim3(batch), dim3(GE::NT), 0, st, p);
+    if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true>), dim3(batch), dim3(GE::NT), 0, st, p);
+    else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false>), dim3(batch), dim3(GE::NT), 0, st, p);
     return hipGetLastError();
 }
 
@@ -409,6 +490,16 @@ int ms_threads_for(int n) {
         case 32: return Geo<32, 4, 8>::NT;
         case 64: return Geo<64, 8, 8>::NT;
         case 72: return Geo<72, 8, 9>::NT;
+        default: return 0;
+    }
+}
+int ms_r2_for(int n) {
+    switch (n) {
+        case 12: return 4;
+        case 16: return 4;
+        case 32: return 8;
+        case 64: return 8;
+        case 72: return 9;
         default: return 0;
     }
 }

@@ -92,6 +92,70 @@ __global__ __launch_bounds__(256) void rotate_adj_kernel(const float2* __restric
 }
 
 // --------------------------------------------------------------------------------------------
+// Overlap-add of the per-position tile gradients written by the multislice kernel (adjoint of the
+// tile gather, adorym/forward_model.py:313-331).  Tiles overlap, so this is a gather per rotated-frame
+// pixel over the positions that cover it: deterministic, no atomics.
+//   cover_build_kernel : per padded pixel (y, x) the list of (position, element) sources
+//   tile_accumulate_kernel : grad_rot[s][y][x] = sum of the sources, for every slice
+// gtile layout per position: [step][k][tid] with pixel (row, col) -> k = col / R2,
+// tid = (row / LPW) * 64 + (row % LPW) * G + col % R2   (the multislice kernel's thread-native order).
+// --------------------------------------------------------------------------------------------
+#define ADM_MAXCOVER 48
+
+struct TileGeom {
+    int Yp, Xp, pad_y0, pad_x0, P, R1, R2, G, LPW, NT, n_steps, binning, Z;
+    int row0, nrows;      // padded-row window touched by the batch
+};
+
+__global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict__ pos, int B, TileGeom g,
+                                                          unsigned* __restrict__ cover, int* __restrict__ overflow) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= g.Xp || r >= g.nrows) return;
+    const int y = g.row0 + r;
+    unsigned* out = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
+    int cnt = 0;
+    const unsigned per_pos = (unsigned)g.n_steps * g.R1 * g.NT;
+    for (int b = 0; b < B; ++b) {
+        const int2 p = pos[b];
+        const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
+        if (row >= 0 && row < g.P && col >= 0 && col < g.P) {
+            if (cnt < ADM_MAXCOVER) {
+                const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
+                out[1 + cnt] = (unsigned)b * per_pos + (unsigned)((col / g.R2) * g.NT + tid);
+            }
+            ++cnt;
+        }
+    }
+    if (cnt > ADM_MAXCOVER) { atomicExch(overflow, 1); cnt = ADM_MAXCOVER; }
+    out[0] = (unsigned)cnt;
+}
+
+__global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
+                                                              float2* __restrict__ grad_rot, TileGeom g, int steps_per_block) {
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= g.Xp || r >= g.nrows) return;
+    const unsigned* cv = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
+    const int cnt = (int)cv[0];
+    const size_t step_stride = (size_t)g.R1 * g.NT;
+    const size_t slice_stride = (size_t)g.Yp * g.Xp;
+    float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
+    const int st0 = blockIdx.z * steps_per_block;
+    const int st1 = min(st0 + steps_per_block, g.n_steps);
+    for (int st = st0; st < st1; ++st) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int c = 0; c < cnt; ++c) {
+            const float2 v = gtile[(size_t)cv[1 + c] + (size_t)st * step_stride];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        const int s_lo = st * g.binning, s_hi = min(s_lo + g.binning, g.Z);
+        for (int sl = s_lo; sl < s_hi; ++sl) out[(size_t)sl * slice_stride] = acc;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // Regulariser gradient.  L1Regularizer (adorym/regularizers.py:30-46): alpha_c * mean|x_c|;
 // TVRegularizer (regularizers.py:95-110 -> util.py:1427-1440): gamma * sum_axes sum|roll(a,1)-a| / V.
 // --------------------------------------------------------------------------------------------
@@ -216,6 +280,40 @@ extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint1
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
     hipLaunchKernelGGL(rotate_adj_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, coords, grad_obj, g, y_lo,
                        y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                       const int32_t* pos_host, float* grad_rot) {
+    if (!plan || !workspace || !pos || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: batch must be positive");
+    if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: workspace too small");
+    const adm_plan_desc& d = plan->d;
+    const int N = d.probe_x;
+    TileGeom g;
+    g.Yp = plan->Yp; g.Xp = plan->Xp; g.pad_y0 = d.pad_y0; g.pad_x0 = d.pad_x0; g.P = N;
+    g.R1 = ms_r1_for(N); g.R2 = ms_r2_for(N); g.G = g.R1 > g.R2 ? g.R1 : g.R2; g.LPW = 64 / g.G; g.NT = ms_threads_for(N);
+    g.n_steps = plan->n_steps; g.binning = d.binning; g.Z = d.obj_z;
+    int ymin = pos_host[0], ymax = pos_host[0];
+    for (int b = 1; b < batch; ++b) { ymin = pos_host[2 * b] < ymin ? pos_host[2 * b] : ymin; ymax = pos_host[2 * b] > ymax ? pos_host[2 * b] : ymax; }
+    g.row0 = ymin + d.pad_y0;
+    g.nrows = ymax - ymin + N;
+    if (g.row0 < 0 || g.row0 + g.nrows > g.Yp) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: a position lies outside the padded frame");
+    const size_t per = (size_t)plan->n_steps * g.R1 * g.NT;
+    if ((size_t)batch * per >= 0xFFFFFFFFull) return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate: batch too large for 32-bit tile offsets");
+    char* ws = (char*)workspace;
+    const float2* gtile = (const float2*)(ws + (size_t)batch * per * sizeof(float2));
+    unsigned* cover = (unsigned*)(ws + 2 * (size_t)batch * per * sizeof(float2));
+    int* overflow = (int*)(cover + (size_t)g.Yp * g.Xp * (ADM_MAXCOVER + 1));
+    hipStream_t st = plan->ctx->stream;
+    ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
+    hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
+    ADM_HIP(hipGetLastError());
+    const int spb = 16;
+    grid.z = (plan->n_steps + spb - 1) / spb;
+    hipLaunchKernelGGL(tile_accumulate_kernel, grid, dim3(256), 0, st, gtile, (const unsigned*)cover, (float2*)grad_rot, g, spb);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

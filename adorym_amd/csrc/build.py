@@ -25,20 +25,27 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ['build.py'])
 
 
-def build(force=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, extra=(), out=None, tag=''):
+    out = out or OUT
+    if not force and out == OUT and not needs_build():
         return OUT
     objs = []
     for s in SRCS:
-        o = os.path.join(HERE, s.replace('.hip', '.o'))
+        o = os.path.join(HERE, s.replace('.hip', tag + '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
                '-Wno-unused-result', '-c', os.path.join(HERE, s), '-o', o] + list(extra)
         subprocess.check_call(cmd)
         objs.append(o)
-    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
-    return OUT
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
 
 
 if __name__ == '__main__':
-    extra = ['-DADM_SAFE_SYNC'] if '--safe-sync' in sys.argv else []
-    print(build(force='--force' in sys.argv or bool(extra), extra=extra))
+    # experiment builds: python build.py --variant NAME -DFLAG ...  -> adorym_amd/libadm_NAME.so
+    if '--variant' in sys.argv:
+        name = sys.argv[sys.argv.index('--variant') + 1]
+        flags = [a for a in sys.argv[1:] if a.startswith('-D') or a.startswith('-m') or a.startswith('-f')]
+        print(build(force=True, extra=flags, out=os.path.join(PKG, 'libadm_%s.so' % name), tag='_' + name))
+    else:
+        extra = ['-DADM_SAFE_SYNC'] if '--safe-sync' in sys.argv else []
+        print(build(force='--force' in sys.argv or bool(extra), extra=extra))

@@ -81,7 +81,7 @@ class MultisliceEngine(object):
                          normalize_fft=normalize_fft, h_free=h_free)
         self.pads = pads
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
-        self.grad_rot = ctx.zeros(self.plan.rot_shape)
+        self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
         self.max_batch = 0
         self._ws = self._pos = self._target = self._pred = self._loss = None
         if max_batch:
@@ -124,6 +124,7 @@ class MultisliceEngine(object):
         B = len(pos)
         self._reserve(B)
         self._pos.view(0, (B, 2)).set(pos)
+        self._pos_host = pos
         if isinstance(target, DeviceArray):
             self._cur_target = target
         else:
@@ -132,19 +133,24 @@ class MultisliceEngine(object):
         self._B = B
         return B
 
-    def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, zero_grad_rot=True):
+    def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, accumulate=True):
         """Launch the fused kernel on the batch given to set_batch().  Returns nothing; read
         results with loss() / pred()."""
         B = self._B
         Py, Px = self.probe_size
         if grad_scale is None:
             grad_scale = 2.0 / (B * Py * Px)          # d mean((pred-target)^2) / d pred
-        if want_grad and zero_grad_rot:
-            self.grad_rot.zero_()
         check(self.ctx.lib.adm_multislice_fwd_adj(
             self.plan.handle, self.obj_rot.ptr, probe.ptr, self._pos.ptr, B, self._cur_target.ptr,
-            self.grad_rot.ptr if want_grad else None, grad_probe.ptr if grad_probe is not None else None,
+            1 if want_grad else 0, grad_probe.ptr if grad_probe is not None else None,
             self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
+        if want_grad and accumulate:
+            self.accumulate_tiles()
+
+    def accumulate_tiles(self):
+        """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
+        check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._pos.ptr, self._B,
+                                                    self._pos_host.ctypes.data, self.grad_rot.ptr))
 
     def loss(self):
         """mean((pred - target)^2) over the batch (adorym/forward_model.py:91) -- blocks."""
@@ -159,8 +165,9 @@ class MultisliceEngine(object):
     def loss_and_grad(self, obj, grad_obj, coords, probe, pos_batch, target, grad_probe=None, footprint=True):
         """One minibatch: grad_obj += d loss / d obj; returns the (host) loss."""
         self.set_batch(pos_batch, target)
-        yr = self.y_footprint(pos_batch) if footprint else None
-        self.rotate(obj, coords, yr)
+        yr = self.y_footprint(pos_batch)
+        self.rotate(obj, coords, yr if footprint else None)
         self.multislice(probe, grad_probe=grad_probe)
+        # outside the batch's y-footprint the gradient is identically zero (and grad_rot rows there are stale)
         self.rotate_adjoint(grad_obj, coords, yr)
         return self.loss()

