@@ -11,3 +11,14 @@ from .device import Context, DeviceArray, Plan, Event  # noqa: F401
 from .propagate import MultisliceEngine, get_kernel, gen_freq_mesh  # noqa: F401
 
 __version__ = '0.1.0'
+
+# ---- the reference's public names for this path (adorym/__init__.py:1-11 star-exports) ----
+from .forward_model import (ForwardModel, PtychographyModel, SingleBatchFullfieldModel,  # noqa: F401,E402
+                            SingleBatchPtychographyModel, SparseMultisliceModel, MultiDistModel)
+from .differentiator import Differentiator  # noqa: F401,E402
+from .optimizers import (Optimizer, AdamOptimizer, GDOptimizer, MomentumOptimizer, CurveballOptimizer,  # noqa: F401,E402
+                         CGOptimizer, ScipyOptimizer)
+from .regularizers import (Regularizer, L1Regularizer, TVRegularizer, ReweightedL1Regularizer,  # noqa: F401,E402
+                           CorrRegularizer, GradCorrRegularizer)
+from .array_ops import ObjectFunction, Gradient, Mask  # noqa: F401,E402
+from .ptychography import reconstruct_ptychography  # noqa: F401,E402

@@ -1,0 +1,226 @@
+"""
+Forward models with the reference's plugin interface (adorym/forward_model.py:28-175, 164-401):
+``predict`` / ``get_data`` / ``loss`` / ``get_loss_function`` keep their names, argument order and
+meaning; the arithmetic runs in libadm's HIP kernels through a MultisliceEngine.
+
+Differences that follow from having no autograd: the closure returned by ``get_loss_function`` carries
+a reference to its model (``calculate_loss.forward_model``) so that ``Differentiator.get_gradients`` can
+call the hand-derived adjoint (``loss_and_gradients``) instead of ``torch.autograd.grad``.
+"""
+import inspect
+import numpy as np
+
+from ._lib import check
+from .device import DeviceArray
+from .regularizers import combined_weights
+
+
+class ForwardModel(object):
+    """adorym/forward_model.py:28-161."""
+
+    def __init__(self, loss_function_type='lsq', distribution_mode=None, device=None, common_vars_dict=None,
+                 raw_data_type='magnitude', simulation_mode=False):
+        if distribution_mode is not None:
+            raise NotImplementedError("distribution_mode '%s' is outside the accelerated path (DP only)" % distribution_mode)
+        if loss_function_type != 'lsq':
+            raise NotImplementedError("loss_function_type '%s' is not implemented on the HIP path yet (SURVEY 8 f4)"
+                                      % loss_function_type)
+        if raw_data_type not in ('magnitude', 'intensity'):
+            raise ValueError("raw_data_type must be 'magnitude' or 'intensity'")
+        self.loss_function_type = loss_function_type
+        self.argument_ls = []
+        self.regularizer_dict = {}
+        self.distribution_mode = distribution_mode
+        self.device = device                      # adorym_amd.Context
+        self.simulation_mode = simulation_mode
+        self.current_loss = 0
+        self.raw_data_type = raw_data_type
+        self.i_call = 0
+        self.common_vars = common_vars_dict
+        if common_vars_dict is not None:
+            for k in ('unknown_type', 'normalize_fft', 'sign_convention', 'rotate_out_of_loop', 'scale_ri_by_k',
+                      'is_minus_logged', 'forward_algorithm', 'stdout_options', 'poisson_multiplier', 'common_probe_pos',
+                      'binning', 'prj'):
+                setattr(self, k, common_vars_dict.get(k))
+        self.loss_args = {}
+        self.reg_list = []
+
+    def update_loss_args(self, kwargs):
+        self.loss_args = kwargs
+
+    def add_regularizers(self, reg_list):
+        self.reg_list = reg_list
+
+    def get_argument_index(self, arg):
+        for i, a in enumerate(self.argument_ls):
+            if a == arg:
+                return i
+        raise ValueError('{} is not in the argument list.'.format(arg))
+
+    def get_data(self, this_i_theta, this_ind_batch, theta_downsample=None, ds_level=1):
+        """abs(prj[i_theta*theta_downsample, ind_batch]) (forward_model.py:113-119); sqrt of it for intensity
+        data (the sqrt of get_mismatch_loss, :92-93, folded in here).  Returns a float32 host array."""
+        if theta_downsample is None:
+            theta_downsample = 1
+        if ds_level not in (1, None):
+            raise NotImplementedError('multiscale (ds_level > 1) is outside the accelerated path')
+        t = np.abs(np.asarray(self.prj[int(this_i_theta) * theta_downsample, np.asarray(this_ind_batch)]))
+        if self.raw_data_type == 'intensity':
+            t = np.sqrt(t)
+        return np.ascontiguousarray(t, dtype=np.float32)
+
+    def predict(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def get_loss_function(self):
+        raise NotImplementedError
+
+
+class PtychographyModel(ForwardModel):
+    """
+    adorym/forward_model.py:164-401.  Also serves the reference's SingleBatchFullfieldModel and
+    SingleBatchPtychographyModel (:404-586): they compute the same function with fewer stacking steps.
+    """
+
+    def __init__(self, loss_function_type='lsq', distribution_mode=None, device=None, common_vars_dict=None,
+                 raw_data_type='magnitude', simulation_mode=False, run_bfloat16=False, run_float64=False):
+        super(PtychographyModel, self).__init__(loss_function_type, distribution_mode, device, common_vars_dict,
+                                                raw_data_type, simulation_mode=simulation_mode)
+        if run_bfloat16 or run_float64:
+            raise NotImplementedError('the HIP path computes in fp32 (the reference default); bf16/fp64 runs are not provided')
+        args = inspect.getfullargspec(self.predict).args
+        args.pop(0)
+        self.argument_ls = args
+        self.engine = common_vars_dict['engine'] if common_vars_dict else None
+        self._probe_dev = None
+        self._grad_probe_dev = None
+        self._reg_val = None
+
+    # ------------------------------------------------------------------ helpers
+    def _check_static(self, probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset):
+        cv = self.common_vars
+        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset',
+                     'optimize_all_probe_pos', 'optimize_tilt'):
+            if cv.get(flag):
+                raise NotImplementedError('%s is outside the accelerated path (SURVEY section 8 f2)' % flag)
+        if probe_pos_correction is not None and np.any(np.asarray(probe_pos_correction) > 1e-3):
+            # forward_model.py:298 -- fractional positions shift the probe in Fourier space
+            raise NotImplementedError('sub-pixel probe position corrections are outside the accelerated path (f2)')
+
+    def _coords(self, this_i_theta):
+        cv = self.common_vars
+        if cv.get('two_d_mode') or self.rotate_out_of_loop:
+            return None
+        return cv['rotation_tables'](int(this_i_theta))
+
+    def _probe(self, probe_real, probe_imag):
+        """probe_real/imag: host arrays [n_modes,Py,Px] or a DeviceArray [n_modes,Py,Px,2] passed as probe_real."""
+        if isinstance(probe_real, DeviceArray):
+            return probe_real
+        pr = np.asarray(probe_real, dtype=np.float32)
+        pi = np.asarray(probe_imag, dtype=np.float32)
+        host = np.ascontiguousarray(np.stack([pr, pi], -1))
+        if self._probe_dev is None or self._probe_dev.shape != host.shape:
+            self._probe_dev = self.device.empty(host.shape)
+        self._probe_dev.set(host)
+        return self._probe_dev
+
+    def _run(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad, grad_obj=None,
+             want_probe_grad=False, want_pred=False):
+        eng = self.engine
+        probe = self._probe(probe_real, probe_imag)
+        coords = self._coords(this_i_theta)
+        eng.set_batch(this_pos_batch, target)
+        yr = eng.y_footprint(this_pos_batch)
+        eng.rotate(obj, coords, yr)
+        gp = None
+        if want_probe_grad:
+            if self._grad_probe_dev is None or self._grad_probe_dev.shape != probe.shape:
+                self._grad_probe_dev = self.device.empty(probe.shape)
+            gp = self._grad_probe_dev.zero_()
+        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred)
+        if want_grad:
+            eng.rotate_adjoint(grad_obj, coords, yr)
+        return gp
+
+    def _regularize(self, obj, grad_obj):
+        """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value."""
+        ad, ab, gm = combined_weights(self.reg_list)
+        if ad == 0 and ab == 0 and gm == 0:
+            return 0.0
+        if self._reg_val is None:
+            self._reg_val = self.device.zeros((1,))
+        self._reg_val.zero_()
+        if grad_obj is None:
+            if getattr(self, '_scratch_grad', None) is None or self._scratch_grad.size != obj.size:
+                self._scratch_grad = self.device.empty((obj.size,))
+            grad_obj = self._scratch_grad
+        check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad, ab, gm, grad_obj.ptr, self._reg_val.ptr))
+        return float(self._reg_val.get()[0])
+
+    # ------------------------------------------------------------------ reference interface
+    def predict(self, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
+                probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset):
+        """Predicted detector magnitudes [minibatch, Py, Px] (host float32), adorym/forward_model.py:179-387."""
+        self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
+        B = len(this_pos_batch)
+        zeros = np.zeros((B,) + tuple(self.engine.probe_size), np.float32)
+        self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, zeros, want_grad=False, want_pred=True)
+        self.i_call += 1
+        return self.engine.pred()
+
+    def get_loss_function(self):
+        def calculate_loss(obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
+                           probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset):
+            self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
+            target = self.get_data(this_i_theta, this_ind_batch, theta_downsample=self.common_vars.get('theta_downsample'),
+                                   ds_level=self.common_vars.get('ds_level', 1))
+            self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=False)
+            loss = self.engine.loss() + self._regularize(obj, None)
+            self.current_loss = float(loss)
+            return self.current_loss
+        calculate_loss.forward_model = self
+        return calculate_loss
+
+    def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
+                           this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset):
+        """
+        The hand-derived replacement of ``torch.autograd.grad(loss, [args in opt_args_ls])``
+        (adorym/wrappers.py:300-331): accumulates d loss/d obj into ``grad_obj`` (DeviceArray) and returns
+        the gradients ordered like opt_args_ls: index 0 -> grad_obj, probe_real/probe_imag indices -> host arrays.
+        """
+        self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
+        target = self.get_data(this_i_theta, this_ind_batch, theta_downsample=self.common_vars.get('theta_downsample'),
+                               ds_level=self.common_vars.get('ds_level', 1))
+        i_pr, i_pi = self.get_argument_index('probe_real'), self.get_argument_index('probe_imag')
+        want_probe = (i_pr in opt_args_ls) or (i_pi in opt_args_ls)
+        gp = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
+                       want_probe_grad=want_probe)
+        reg = self._regularize(obj, grad_obj)
+        self.current_loss = float(self.engine.loss() + reg)
+        out = []
+        gph = gp.get() if gp is not None else None
+        for i in opt_args_ls:
+            if i == 0:
+                out.append(grad_obj)
+            elif i == i_pr:
+                out.append(gph[..., 0])
+            elif i == i_pi:
+                out.append(gph[..., 1])
+            else:
+                raise NotImplementedError("gradient w.r.t. '%s' is outside the accelerated path" % self.argument_ls[i])
+        return tuple(out)
+
+
+SingleBatchFullfieldModel = PtychographyModel
+SingleBatchPtychographyModel = PtychographyModel
+
+
+class SparseMultisliceModel(ForwardModel):
+    def __init__(self, *a, **k):
+        raise NotImplementedError('SparseMultisliceModel is outside the accelerated path (not in BASELINE configs)')
+
+
+class MultiDistModel(ForwardModel):
+    def __init__(self, *a, **k):
+        raise NotImplementedError('MultiDistModel is a "next" row (SURVEY section 8 f1), not implemented yet')

@@ -1,0 +1,526 @@
+"""
+reconstruct_ptychography -- the reference's entry point (adorym/ptychography.py:54-1296), data-parallel
+mode (``distribution_mode=None``), driving the HIP path.  The keyword surface is the reference's,
+verbatim; combinations outside the accelerated path raise NotImplementedError instead of silently doing
+something else.  Control flow (epoch / batching / update / constraints / logging order) follows the
+reference line by line so that runs are comparable minibatch for minibatch:
+
+    :783-847   epoch task list (np.random.seed(i_epoch), theta shuffle, padding of the spot list)
+    :901-912   this rank's slice of the global batch, sorted
+    :1017-1039 gradient of the loss   -> Differentiator.get_gradients -> hand adjoint (HIP)
+    :1063-1066 gradient accumulation  -> fused into the adjoint's output buffer
+    :1095-1099 'per angle' update scheme
+    :1113-1129 allreduce + optimiser  -> reduce_scatter + fused Adam/GD on the shard + all_gather
+    :1135-1158 constraints, :1210-1215 support mask -> fused into the optimiser kernel
+    :1254-1271 throughput print, convergence log, optimiser step counter
+"""
+import datetime
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from . import global_settings
+from .array_ops import ObjectFunction, Gradient, Mask
+from .comm import LocalComm, from_env
+from .constants import PI
+from .device import Context
+from .differentiator import Differentiator
+from .dp import DataParallelObject, HipOps, constraint_flags
+from .forward_model import ForwardModel, PtychographyModel
+from .optimizers import Optimizer, AdamOptimizer, GDOptimizer
+from .propagate import MultisliceEngine, get_kernel
+from .regularizers import L1Regularizer, TVRegularizer, ReweightedL1Regularizer
+from .util import rotation_lookup, split_tasks, initialize_probe
+from ._io import DataFile, write_tiff, read_tiff
+
+
+def print_flush(a, designate_rank=None, this_rank=None, save_stdout=False, output_folder='', timestamp='', **kwargs):
+    """adorym/misc.py:233-257."""
+    a = '[{}][{}] '.format(str(datetime.datetime.today())[:-3], this_rank) + a
+    if designate_rank is None or this_rank == designate_rank:
+        print(a)
+        if save_stdout:
+            with open(os.path.join(output_folder, 'stdout_{}.txt'.format(timestamp)), 'a') as f:
+                f.write(a + '\n')
+    sys.stdout.flush()
+
+
+def _not_implemented(cond, what):
+    if cond:
+        raise NotImplementedError(what + ' is outside the accelerated path of adorym_amd (see DESIGN.md, out of scope)')
+
+
+def reconstruct_ptychography(
+        # |Raw data and experimental parameters|
+        fname, obj_size, probe_pos=None, theta_st=0, theta_end=PI, n_theta=None, theta_downsample=None,
+        energy_ev=None, psize_cm=None, free_prop_cm=None,
+        raw_data_type='magnitude', is_minus_logged=False, slice_pos_cm_ls=None,
+        # |Reconstruction parameters|
+        n_epochs='auto', crit_conv_rate=0.03, max_nepochs=200,
+        regularizers=None, alpha_d=None, alpha_b=None, gamma=1e-6,
+        minibatch_size=None, multiscale_level=1, n_epoch_final_pass=None,
+        initial_guess=None, random_guess_means_sigmas=(8.7e-7, 5.1e-8, 1e-7, 1e-8),
+        n_batch_per_update=1, reweighted_l1=False, interpolation='bilinear',
+        update_scheme='immediate', unknown_type='delta_beta', randomize_probe_pos=False,
+        common_probe_pos=True, fix_object=False,
+        # |Object optimizer options|
+        optimize_object=True, optimizer='adam', learning_rate=1e-5, update_using_external_algorithm=None,
+        optimizer_batch_number_increment='angle',
+        # |Finite support constraint|
+        finite_support_mask_path=None, shrink_cycle=None, shrink_threshold=1e-9,
+        # |Object contraints|
+        object_type='normal', non_negativity=False,
+        # |Forward model|
+        forward_model='auto', forward_algorithm='fresnel', ctf_lg_kappa=1.7,
+        binning=1, fresnel_approx=True, pure_projection=False, two_d_mode=False,
+        probe_type='gaussian', probe_initial=None, probe_extra_defocus_cm=None, n_probe_modes=1,
+        shared_probe_among_angles=True, rescale_probe_intensity=False,
+        loss_function_type='lsq', poisson_multiplier=1., beamstop=None, normalize_fft=False, safe_zone_width=0,
+        scale_ri_by_k=True, sign_convention=1, fourier_disparity=False,
+        # |I/O|
+        save_path='.', output_folder=None, save_intermediate=False, save_intermediate_level='batch', save_history=False,
+        store_checkpoint=True, use_checkpoint=True, force_to_use_checkpoint=False, n_batch_per_checkpoint=10,
+        save_stdout=False,
+        # |Performance|
+        cpu_only=False, core_parallelization=True, gpu_index=0, n_dp_batch=20,
+        distribution_mode=None, dist_mode_n_batch_per_update=None, precalculate_rotation_coords=True,
+        cache_dtype='float32', rotate_out_of_loop=False, n_split_mpi_ata='auto',
+        # |Other optimizer options|
+        optimize_probe=False, probe_learning_rate=1e-5, optimizer_probe=None,
+        probe_update_delay=0, probe_update_limit=None,
+        optimize_probe_defocusing=False, probe_defocusing_learning_rate=1e-5, optimizer_probe_defocusing=None,
+        optimize_probe_pos_offset=False, probe_pos_offset_learning_rate=1e-2, optimizer_probe_pos_offset=None,
+        optimize_prj_pos_offset=False, prj_pos_offset_learning_rate=1e-2, optimizer_prj_pos_offset=None,
+        optimize_all_probe_pos=False, all_probe_pos_learning_rate=1e-2, optimizer_all_probe_pos=None,
+        optimize_slice_pos=False, slice_pos_learning_rate=1e-4, optimizer_slice_pos=None,
+        optimize_free_prop=False, free_prop_learning_rate=1e-2, optimizer_free_prop=None,
+        optimize_prj_affine=False, prj_affine_learning_rate=1e-3, optimizer_prj_affine=None,
+        optimize_tilt=False, tilt_learning_rate=1e-3, optimizer_tilt=None, initial_tilt=None,
+        optimize_ctf_lg_kappa=False, ctf_lg_kappa_learning_rate=1e-3, optimizer_ctf_lg_kappa=None,
+        other_params_update_delay=0,
+        # |Alternative algorithms|
+        use_epie=False, epie_alpha=0.8,
+        # |Other settings|
+        dynamic_rate=True, pupil_function=None, probe_circ_mask=0.9, dynamic_dropping=False, dropping_threshold=8e-5,
+        backend='hip', debug=False, t_max_min=None, xpu=False, run_bfloat16=False, run_float64=False,
+        **kwargs):
+    """
+    Same contract as the reference: returns None; results are files under ``save_path/output_folder``
+    (delta_ds_1.tiff, beta_ds_1.tiff, probe_mag_ds_1.tiff, probe_phase_ds_1.tiff, convergence/loss_rank_*.txt).
+    ``fname`` may also be a NumPy array / dict holding 'exchange/data' (no file needed), and ``kwargs`` may
+    carry ``comm=`` (an adorym_amd.comm object) and ``return_state=True`` (returns a dict of final arrays).
+    ``backend`` accepts 'hip' (and, for script compatibility, the reference's 'pytorch' / 'autograd' names,
+    which are mapped to 'hip' with a warning).
+    """
+    t_zero = time.time()
+    comm = kwargs.pop('comm', None) or from_env()
+    return_state = kwargs.pop('return_state', False)
+    n_ranks, rank = comm.size, comm.rank
+    if backend != 'hip':
+        warnings.warn("adorym_amd has a single backend ('hip'); backend='%s' is ignored." % backend)
+    global_settings.backend = 'hip'
+
+    # ---- combinations outside the accelerated path: fail loudly -------------------------------------
+    _not_implemented(distribution_mode is not None, "distribution_mode='%s'" % distribution_mode)
+    _not_implemented(cpu_only, 'cpu_only=True (there is no CPU fallback)')
+    _not_implemented(run_bfloat16 or run_float64, 'run_bfloat16 / run_float64')
+    _not_implemented(unknown_type != 'delta_beta', "unknown_type='%s'" % unknown_type)
+    _not_implemented(multiscale_level != 1, 'multiscale_level > 1')
+    _not_implemented(pure_projection or forward_algorithm != 'fresnel', 'pure_projection / CTF forward algorithm')
+    _not_implemented(use_epie, 'ePIE')
+    _not_implemented(is_minus_logged, 'is_minus_logged')
+    _not_implemented(beamstop is not None, 'beamstop')
+    _not_implemented(loss_function_type != 'lsq', "loss_function_type='%s'" % loss_function_type)
+    _not_implemented(not common_probe_pos, 'common_probe_pos=False')
+    _not_implemented(not shared_probe_among_angles, 'shared_probe_among_angles=False')
+    _not_implemented(rescale_probe_intensity or probe_extra_defocus_cm is not None, 'probe rescaling / extra defocus')
+    _not_implemented(update_using_external_algorithm is not None, 'update_using_external_algorithm')
+    _not_implemented(shrink_cycle is not None, 'shrink-wrap mask updates')
+    _not_implemented(initial_tilt is not None, 'initial_tilt')
+    _not_implemented(interpolation != 'bilinear', "interpolation='%s'" % interpolation)
+    for nm, flag in (('optimize_probe_defocusing', optimize_probe_defocusing), ('optimize_probe_pos_offset', optimize_probe_pos_offset),
+                     ('optimize_prj_pos_offset', optimize_prj_pos_offset), ('optimize_all_probe_pos', optimize_all_probe_pos),
+                     ('optimize_slice_pos', optimize_slice_pos), ('optimize_free_prop', optimize_free_prop),
+                     ('optimize_prj_affine', optimize_prj_affine), ('optimize_tilt', optimize_tilt),
+                     ('optimize_ctf_lg_kappa', optimize_ctf_lg_kappa)):
+        _not_implemented(flag, nm)
+    if update_scheme not in ('immediate', 'per angle'):
+        raise ValueError("update_scheme must be 'immediate' or 'per angle'")
+
+    # ---- device -----------------------------------------------------------------------------------
+    stream = comm.stream_handle() if hasattr(comm, 'stream_handle') else None
+    dev_index = getattr(comm, 'device_index', None)
+    ctx = Context(gpu_index if dev_index is None else dev_index, stream=stream)
+
+    if rank == 0:
+        timestr = str(datetime.datetime.today())
+        timestr = timestr[:timestr.find('.')]
+        for i in [':', '-', ' ']:
+            timestr = timestr.replace(i, '_' if i == ' ' else '')
+    else:
+        timestr = None
+    timestr = comm.bcast_object(timestr, root=0)
+    if output_folder is None:
+        output_folder = 'recon_{}'.format(timestr)
+    if save_path != '.':
+        output_folder = os.path.join(save_path, output_folder)
+    stdout_options = {'save_stdout': save_stdout, 'output_folder': output_folder, 'timestamp': timestr}
+    sto_rank = 0 if not debug else rank
+    print_flush('Output folder is {}'.format(output_folder), sto_rank, rank, **stdout_options)
+
+    # ---- data and metadata (ptychography.py:237-323) ------------------------------------------------
+    t0 = time.time()
+    f = DataFile(fname if not isinstance(fname, str) else os.path.join(save_path, fname))
+    prj = f.data
+    obj_size = [int(v) for v in obj_size]
+    if obj_size[-1] == 1:
+        two_d_mode = True
+    if n_theta is None:
+        n_theta = prj.shape[0]
+    if two_d_mode:
+        n_theta = 1
+    try:
+        theta_ls = np.asarray(f.get('metadata/theta'))
+    except Exception:
+        theta_ls = np.linspace(theta_st, theta_end, n_theta, dtype='float32')
+    if theta_downsample is not None:
+        theta_ls = theta_ls[::theta_downsample]
+        n_theta = len(theta_ls)
+    if probe_pos is None:
+        probe_pos = np.array(f.get('metadata/probe_pos_px')).astype(float)
+    else:
+        probe_pos = np.array(probe_pos).astype(float)
+    if energy_ev is None:
+        energy_ev = float(f.get('metadata/energy_ev'))
+    if psize_cm is None:
+        psize_cm = float(f.get('metadata/psize_cm'))
+    _not_implemented(slice_pos_cm_ls is not None and len(slice_pos_cm_ls) > 1, 'sparse multislice (slice_pos_cm_ls)')
+    if free_prop_cm is None:
+        free_prop_cm = f.get('metadata/free_prop_cm')
+    if np.array(free_prop_cm).size != 1:
+        _not_implemented(True, 'multi-distance holography (MultiDistModel)')
+    if isinstance(free_prop_cm, np.ndarray):
+        free_prop_cm = free_prop_cm.reshape(-1)[0]
+        free_prop_cm = free_prop_cm if isinstance(free_prop_cm, str) else float(free_prop_cm)
+    probe_size = [int(v) for v in prj.shape[-2:]]
+    print_flush('Data reading: {} s'.format(time.time() - t0), sto_rank, rank, **stdout_options)
+    print_flush('Data shape: {}'.format([n_theta, *prj.shape[1:]]), sto_rank, rank, **stdout_options)
+    kwargs.pop('probe_size', None)
+
+    if minibatch_size is None:
+        minibatch_size = len(probe_pos)
+    if minibatch_size > 1 and len(probe_pos) == 1:
+        warnings.warn('Undivided fullfield data with minibatch > 1: setting minibatch_size to 1 (ptychography.py:342-346).')
+        minibatch_size = 1
+
+    ds_level = 1
+    this_obj_size = obj_size
+    if rank == 0:
+        os.makedirs(output_folder, exist_ok=True)
+    comm.barrier()
+
+    # ---- physics (ptychography.py:388-391) ----------------------------------------------------------
+    voxel_nm = np.array([psize_cm] * 3) * 1.e7 * ds_level
+    lmbda_nm = 1240. / energy_ev
+    delta_nm = voxel_nm[-1]
+    h = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, probe_size, fresnel_approx=fresnel_approx, sign_convention=sign_convention)
+    probe_pos_int = np.round(probe_pos).astype(int)
+    engine = MultisliceEngine(ctx, this_obj_size, probe_size, probe_pos_int, energy_ev, psize_cm, free_prop_cm=free_prop_cm,
+                              binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
+                              normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
+                              max_batch=minibatch_size)
+
+    # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
+    # (the reference caches them as .npy files in ./arrsize_*; no files are written here)
+    _tables = {}
+
+    def rotation_tables(i_theta):
+        if i_theta not in _tables:
+            _tables[i_theta] = ctx.array(rotation_lookup(this_obj_size, theta_ls[i_theta]).view(np.uint16))
+        return _tables[i_theta]
+
+    # ---- seed (ptychography.py:410-412) ---------------------------------------------------------------
+    seed = comm.bcast_object(int(time.time() / 60), root=0)
+    np.random.seed(seed)
+
+    # ---- object optimiser (ptychography.py:417-453) -----------------------------------------------------
+    if isinstance(optimizer, Optimizer):
+        opt = optimizer
+        opt.name = 'obj'
+    elif optimizer == 'adam':
+        opt = AdamOptimizer('obj', output_folder=output_folder, distribution_mode=distribution_mode,
+                            options_dict={'step_size': learning_rate})
+    elif optimizer == 'gd':
+        opt = GDOptimizer('obj', output_folder=output_folder, distribution_mode=distribution_mode,
+                          options_dict={'step_size': learning_rate, 'dynamic_rate': True, 'first_downrate_iteration': 20})
+    elif optimizer in ('curveball', 'cg', 'momentum', 'scipy'):
+        raise NotImplementedError("optimizer '%s' is outside the accelerated path" % optimizer)
+    else:
+        raise ValueError('Invalid optimizer type. Must be "gd" or "adam" or "cg" or "scipy".')
+    opt.set_index_in_grad_return(0)
+    fused = type(opt) in (AdamOptimizer, GDOptimizer)
+    _not_implemented(not fused and n_ranks > 1, 'user-defined object optimizers with more than one rank')
+    opt_kind = 'adam' if isinstance(opt, AdamOptimizer) else 'gd'
+
+    # ---- object, gradient, moments (ptychography.py:492-576) --------------------------------------------
+    ops = kwargs.pop('ops', None) or HipOps(ctx)
+    state = DataParallelObject(ops, comm, [*this_obj_size, 2], n_moments=2 if opt_kind == 'adam' else 0)
+    if fused:
+        if opt_kind == 'adam':
+            opt.params_whole_array_dict = {'m': state.moments[0], 'v': state.moments[1]}   # shard-sized under DP
+    else:
+        opt.create_container([*this_obj_size, 2], use_checkpoint, ctx)
+    obj = ObjectFunction([*this_obj_size, 2], distribution_mode=distribution_mode, output_folder=output_folder, ds_level=ds_level,
+                         object_type=object_type, device=ctx)
+    init = ObjectFunction.initial_values(this_obj_size, initial_guess, random_guess_means_sigmas, object_type, non_negativity)
+    init = comm.bcast_object(init, root=0) if (initial_guess is None and n_ranks > 1) else init
+    obj.arr = state.obj.view(0, (*this_obj_size, 2))
+    obj.arr.set(init)
+    del init
+    gradient = Gradient(obj)
+    gradient.arr = state.grad.view(0, (*this_obj_size, 2))
+
+    # ---- forward model (ptychography.py:526-546) ---------------------------------------------------------
+    common_vars = dict(unknown_type=unknown_type, normalize_fft=normalize_fft, sign_convention=sign_convention,
+                       rotate_out_of_loop=rotate_out_of_loop, scale_ri_by_k=scale_ri_by_k, is_minus_logged=is_minus_logged,
+                       forward_algorithm=forward_algorithm, stdout_options=stdout_options, poisson_multiplier=poisson_multiplier,
+                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine,
+                       rotation_tables=rotation_tables, two_d_mode=two_d_mode, theta_downsample=theta_downsample,
+                       ds_level=ds_level, probe_size=probe_size, this_obj_size=this_obj_size, n_theta=n_theta,
+                       theta_ls=theta_ls, energy_ev=energy_ev, psize_cm=psize_cm, h=h, free_prop_cm=free_prop_cm,
+                       minibatch_size=minibatch_size, n_probe_modes=n_probe_modes, beamstop=beamstop,
+                       optimize_probe_defocusing=False, optimize_probe_pos_offset=False, optimize_prj_pos_offset=False,
+                       optimize_all_probe_pos=False, optimize_tilt=False, output_folder=output_folder, debug=debug)
+    _not_implemented(rotate_out_of_loop, 'rotate_out_of_loop')
+    fm_args = dict(loss_function_type=loss_function_type, distribution_mode=distribution_mode, device=ctx,
+                   common_vars_dict=common_vars, raw_data_type=raw_data_type, run_bfloat16=run_bfloat16, run_float64=run_float64)
+    if forward_model == 'auto':
+        forward_model = PtychographyModel(**fm_args)
+    else:
+        forward_model = forward_model(**fm_args)
+    print_flush('Forward model: {}.'.format(type(forward_model).__name__), sto_rank, rank, **stdout_options)
+
+    if regularizers is None:
+        regularizers = []
+        if alpha_d not in [0, None]:
+            if reweighted_l1:
+                regularizers.append(ReweightedL1Regularizer(alpha_d, alpha_b, unknown_type=unknown_type))
+            else:
+                regularizers.append(L1Regularizer(alpha_d, alpha_b, unknown_type=unknown_type))
+        if gamma not in [0, None]:
+            regularizers.append(TVRegularizer(gamma, unknown_type=unknown_type))
+    forward_model.add_regularizers(regularizers)
+
+    mask = None
+    if finite_support_mask_path is not None:
+        mask = Mask(this_obj_size, finite_support_mask_path, distribution_mode=distribution_mode, output_folder=output_folder,
+                    ds_level=ds_level, device=ctx)
+        mask_arr = finite_support_mask_path if isinstance(finite_support_mask_path, np.ndarray) else read_tiff(finite_support_mask_path)
+        mask.initialize_array_with_values(mask_arr, device=ctx)
+    flags = constraint_flags(non_negativity, object_type)
+
+    # ---- probe (ptychography.py:607-667) -------------------------------------------------------------------
+    if rank == 0:
+        pk = dict(kwargs)
+        pk.update(lmbda_nm=lmbda_nm, psize_cm=psize_cm, normalize_fft=normalize_fft, n_probe_modes=n_probe_modes)
+        pr0, pi0 = initialize_probe(probe_size, probe_type, pupil_function=pupil_function, probe_initial=probe_initial, **pk)
+        if n_probe_modes == 1:
+            probe_real = np.stack([np.squeeze(pr0)]) if pr0.ndim != 3 else pr0[:1]
+            probe_imag = np.stack([np.squeeze(pi0)]) if pi0.ndim != 3 else pi0[:1]
+        else:
+            _not_implemented(True, 'n_probe_modes > 1')
+    else:
+        probe_real = probe_imag = None
+    probe_real = comm.bcast_object(probe_real, root=0)
+    probe_imag = comm.bcast_object(probe_imag, root=0)
+    probe_dev = ctx.array(np.stack([probe_real, probe_imag], -1), np.float32)       # [modes, Py, Px, 2]
+
+    # ---- optimisable parameters and their optimisers (ptychography.py:673-735) -------------------------------
+    optimizable_params = {'probe_real': probe_dev, 'probe_imag': None, 'probe_defocus_mm': 0.0,
+                          'probe_pos_offset': np.zeros([n_theta, 2]), 'prj_pos_offset': np.zeros([n_theta, 2]),
+                          'probe_pos_correction': np.tile(probe_pos - probe_pos_int, [n_theta, 1, 1]),
+                          'tilt_ls': np.zeros([3, n_theta])}
+    opt_ls = [opt]
+    opt_args_ls = [0]
+    opt_probe = None
+    if optimize_probe:
+        if optimizer_probe is not None:
+            opt_probe = optimizer_probe
+            opt_probe.name = 'probe'
+        else:
+            opt_probe = AdamOptimizer('probe', output_folder=output_folder, options_dict={'step_size': probe_learning_rate},
+                                      forward_model=forward_model)
+        opt_probe.create_param_arrays([n_probe_modes, *probe_size, 2], device=ctx)
+        opt_probe.set_index_in_grad_return(len(opt_args_ls))
+        opt_args_ls = opt_args_ls + [forward_model.get_argument_index('probe_real'), forward_model.get_argument_index('probe_imag')]
+        opt_ls.append(opt_probe)
+        probe_grad_dev = ctx.zeros(probe_dev.shape)
+
+    diff = Differentiator()
+    calculate_loss = forward_model.get_loss_function()
+    diff.create_loss_node(calculate_loss, opt_args_ls)
+
+    if rank == 0:
+        os.makedirs(os.path.join(output_folder, 'convergence'), exist_ok=True)
+    comm.barrier()
+    f_conv = open(os.path.join(output_folder, 'convergence', 'loss_rank_{}.txt'.format(rank)), 'w')
+    f_conv.write('i_epoch,i_batch,loss,time\n')
+    print_flush('Optimizer started.', sto_rank, rank, **stdout_options)
+    if probe_update_limit is None:
+        probe_update_limit = np.inf
+    loss_history = []
+
+    # =========================================================================================================
+    # epoch loop (ptychography.py:783-1295)
+    # =========================================================================================================
+    cont = True
+    i_epoch = 0
+    while cont:
+        t0 = time.time()
+        n_tot_per_batch = minibatch_size * n_ranks
+        np.random.seed(i_epoch)
+        if not two_d_mode:
+            theta_ind_ls = np.arange(n_theta)
+            np.random.shuffle(theta_ind_ls)
+        else:
+            temp = abs(theta_ls - theta_ls[0]) < 1e-5
+            theta_ind_ls = np.array([np.nonzero(temp)[0][0]])
+        ind_list_rand = None
+        for i, i_theta in enumerate(theta_ind_ls):
+            n_pos = len(probe_pos)
+            spots_ls = range(n_pos)
+            if randomize_probe_pos:
+                spots_ls = np.random.choice(spots_ls, len(spots_ls), replace=False)
+            if update_scheme == 'immediate' and n_pos % minibatch_size != 0:
+                spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % minibatch_size],
+                                                                minibatch_size - (n_pos % minibatch_size), replace=False))
+            elif update_scheme == 'per angle' and n_pos % n_tot_per_batch != 0:
+                spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % n_tot_per_batch],
+                                                                n_tot_per_batch - (n_pos % n_tot_per_batch), replace=False))
+            if i == 0:
+                ind_list_rand = np.zeros([len(theta_ind_ls) * len(spots_ls), 2], dtype='int32')
+            temp = np.stack([np.array([i_theta] * len(spots_ls)), spots_ls], axis=1)
+            ind_list_rand[i * len(spots_ls):(i + 1) * len(spots_ls), :] = temp
+        ind_list_rand = split_tasks(ind_list_rand, n_tot_per_batch)
+        n_batch = len(ind_list_rand)
+        i_opt_batch = 0                       # starting_epoch * n_batch + starting_batch (:848) without checkpoints
+        initialize_gradients = True
+
+        for i_batch in range(n_batch):
+            t_elapsed = (time.time() - t_zero) / 60
+            if t_max_min is not None and t_elapsed >= t_max_min:
+                print_flush('Terminating program because maximum time limit is reached.', sto_rank, rank, **stdout_options)
+                sys.exit()
+            print_flush('Epoch {}, batch {} of {} started.'.format(i_epoch, i_batch, n_batch), sto_rank, rank, **stdout_options)
+            t00 = time.time()
+            if len(ind_list_rand[i_batch]) < n_tot_per_batch:
+                n_supp = n_tot_per_batch - len(ind_list_rand[i_batch])
+                ind_list_rand[i_batch] = np.concatenate([ind_list_rand[i_batch], ind_list_rand[0][:n_supp]])
+            this_ind_batch_allranks = ind_list_rand[i_batch]
+            this_i_theta = int(this_ind_batch_allranks[rank * minibatch_size, 0])
+            this_ind_batch = np.sort(this_ind_batch_allranks[rank * minibatch_size:(rank + 1) * minibatch_size, 1])
+            this_pos_batch = probe_pos_int[this_ind_batch]
+            is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != this_i_theta
+            print_flush('  Current rank is processing angle ID {}.'.format(this_i_theta), sto_rank, rank, **stdout_options)
+
+            # ---- gradients (ptychography.py:1017-1066) ----
+            t_grad_0 = time.time()
+            if initialize_gradients:
+                state.zero_grad()
+                if optimize_probe:
+                    probe_grad_dev.zero_()
+            grad_func_args = {}
+            for arg in forward_model.argument_ls:
+                if arg == 'obj':
+                    grad_func_args[arg] = obj.arr
+                elif arg == 'this_i_theta':
+                    grad_func_args[arg] = this_i_theta
+                elif arg == 'this_pos_batch':
+                    grad_func_args[arg] = this_pos_batch
+                elif arg == 'this_ind_batch':
+                    grad_func_args[arg] = this_ind_batch
+                elif arg == 'prj':
+                    grad_func_args[arg] = prj
+                else:
+                    grad_func_args[arg] = optimizable_params[arg]
+            forward_model.update_loss_args(grad_func_args)
+            grads = diff.get_gradients(_accumulate_into=gradient.arr, **grad_func_args)
+            print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
+            if initialize_gradients:
+                initialize_gradients = False
+            if optimize_probe:
+                g = np.ascontiguousarray(np.stack([grads[1], grads[2]], -1), dtype=np.float32)
+                tmp = ctx.array(g)
+                _lib.check(ctx.lib.adm_axpy(ctx.handle, probe_grad_dev.ptr, tmp.ptr, 1.0, tmp.size))
+
+            if update_scheme == 'per angle' and not is_last_batch_of_this_theta:
+                continue
+            initialize_gradients = True
+
+            # ---- exchange + update + constraints + mask (ptychography.py:1113-1158, 1210-1215) ----
+            if optimize_object:
+                if fused:
+                    o = dict(opt.options_dict)
+                    if opt_kind == 'gd':
+                        o['step_size'] = GDOptimizer.scheduled_step(i_opt_batch, o.get('step_size', 0.001), o.get('dynamic_rate', True),
+                                                                    o.get('first_downrate_iteration', 92))
+                    state.exchange_and_update(opt_kind, i_opt_batch, o, flags=flags, mask=mask.mask if mask is not None else None)
+                else:
+                    opt.apply_gradient(obj.arr, gradient, i_opt_batch, flags=flags, mask=mask.mask if mask is not None else None,
+                                       **opt.options_dict)
+
+            # ---- probe (optimizers.py:1022-1032) ----
+            if optimize_probe:
+                if probe_update_delay <= i_batch + i_epoch * n_batch < probe_update_limit:
+                    if n_ranks > 1:
+                        g = comm.torch.from_numpy(probe_grad_dev.get()).to(comm.device)
+                        comm.all_reduce_sum(g)
+                        probe_grad_dev.set(g.cpu().numpy())
+                    opt_probe.apply_gradient(probe_dev, probe_grad_dev, i_opt_batch, **opt_probe.options_dict)
+                else:
+                    print_flush('  Probe is not updated because current batch is out of the specified range ({}, {}).'.format(
+                        probe_update_delay, probe_update_limit), 0, rank, **stdout_options)
+
+            # ---- finishing a batch (ptychography.py:1231-1271) ----
+            current_loss = forward_model.current_loss
+            loss_history.append(current_loss)
+            print_flush('Minibatch/angle done in {} s; loss (rank 0) is {}.'.format(time.time() - t00, current_loss), sto_rank,
+                        rank, **stdout_options)
+            print_flush('Throughput: {} angles/sec'.format(minibatch_size / (time.time() - t00)), sto_rank, rank, **stdout_options)
+            f_conv.write('{},{},{},{}\n'.format(i_epoch, i_batch, current_loss, time.time() - t_zero))
+            f_conv.flush()
+            if optimizer_batch_number_increment == 'angle':
+                if is_last_batch_of_this_theta:
+                    i_opt_batch += 1
+            elif optimizer_batch_number_increment == 'batch':
+                i_opt_batch += 1
+
+        if n_epochs != 'auto' and i_epoch == n_epochs - 1:
+            cont = False
+        print_flush('Epoch {} (rank {}); Delta-t = {} s; current time = {} s,'.format(i_epoch, rank, time.time() - t0,
+                                                                                       time.time() - t_zero), sto_rank, rank, **stdout_options)
+        i_epoch = i_epoch + 1
+
+        # ---- outputs after an epoch (ptychography.py:1290-1294; util.py:1958-2028) ----
+        if rank == 0:
+            arr = obj.arr.get()
+            write_tiff(arr[..., 0], os.path.join(output_folder, 'delta_ds_{}'.format(ds_level)), dtype='float32')
+            write_tiff(arr[..., 1], os.path.join(output_folder, 'beta_ds_{}'.format(ds_level)), dtype='float32')
+            pa = probe_dev.get()
+            pc = pa[..., 0] + 1j * pa[..., 1]
+            write_tiff(np.abs(pc), os.path.join(output_folder, 'probe_mag_ds_{}'.format(ds_level)), dtype='float32')
+            write_tiff(np.angle(pc), os.path.join(output_folder, 'probe_phase_ds_{}'.format(ds_level)), dtype='float32')
+        print_flush('Current iteration finished.', sto_rank, rank, **stdout_options)
+    comm.barrier()
+    f_conv.close()
+    f.close()
+    if return_state:
+        arr = obj.arr.get()
+        pa = probe_dev.get()
+        return {'delta': arr[..., 0], 'beta': arr[..., 1], 'probe_real': pa[..., 0], 'probe_imag': pa[..., 1],
+                'losses': loss_history, 'output_folder': output_folder}
+    return None

@@ -1,0 +1,64 @@
+"""Regulariser descriptors with the reference's constructor signatures (adorym/regularizers.py).
+The values / gradients are evaluated on the GPU by adm_reg_grad (L1 + TV fused in one pass)."""
+
+
+class Regularizer(object):
+    """adorym/regularizers.py:5-15."""
+
+    def __init__(self, unknown_type='delta_beta'):
+        self.unknown_type = unknown_type
+        if unknown_type != 'delta_beta':
+            raise NotImplementedError("unknown_type='real_imag' regularisers are outside the accelerated path")
+
+    def weights(self):
+        """(alpha_d, alpha_b, gamma) contribution of this term."""
+        return 0., 0., 0.
+
+
+class L1Regularizer(Regularizer):
+    """alpha_d * mean|delta| + alpha_b * mean|beta| (adorym/regularizers.py:18-46)."""
+
+    def __init__(self, alpha_d, alpha_b, unknown_type='delta_beta'):
+        super(L1Regularizer, self).__init__(unknown_type)
+        self.alpha_d = alpha_d
+        self.alpha_b = alpha_b
+
+    def weights(self):
+        return float(self.alpha_d or 0.), float(self.alpha_b or 0.), 0.
+
+
+class TVRegularizer(Regularizer):
+    """gamma * (TV(delta) + TV(beta)), periodic anisotropic TV / voxel count
+    (adorym/regularizers.py:86-110 -> adorym/util.py:1427-1440)."""
+
+    def __init__(self, gamma, unknown_type='delta_beta'):
+        super(TVRegularizer, self).__init__(unknown_type)
+        self.gamma = gamma
+
+    def weights(self):
+        return 0., 0., float(self.gamma or 0.)
+
+
+class ReweightedL1Regularizer(Regularizer):
+    """adorym/regularizers.py:49-84 -- SURVEY section 8 row f4 ("next"), not accelerated yet."""
+
+    def __init__(self, alpha_d, alpha_b, unknown_type='delta_beta'):
+        raise NotImplementedError('ReweightedL1Regularizer is not implemented on the HIP path yet')
+
+
+class CorrRegularizer(Regularizer):
+    def __init__(self, gamma, unknown_type='delta_beta'):
+        raise NotImplementedError('CorrRegularizer is outside the accelerated path (unused by every config)')
+
+
+class GradCorrRegularizer(Regularizer):
+    def __init__(self, gamma, unknown_type='delta_beta'):
+        raise NotImplementedError('GradCorrRegularizer is outside the accelerated path (unused by every config)')
+
+
+def combined_weights(reg_list):
+    ad = ab = gm = 0.
+    for r in reg_list:
+        a, b, g = r.weights()
+        ad += a; ab += b; gm += g
+    return ad, ab, gm
