@@ -75,6 +75,12 @@ class TorchComm(object):
         self.size = dist.get_world_size()
         self.device_index = device_index
         self.device = torch.device('cuda', device_index) if backend == 'nccl' else torch.device('cpu')
+        self.stream = None
+        if backend == 'nccl':
+            # a dedicated, explicit stream shared by libadm and torch: collectives are ordered against the
+            # CURRENT torch stream, and the legacy null stream would not order against a non-blocking one
+            self.stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.set_stream(self.stream)
 
     # ---- buffers the collectives touch -------------------------------------------------
     def alloc(self, n, dtype=None):
@@ -84,7 +90,7 @@ class TorchComm(object):
     def stream_handle(self):
         """hipStream_t of torch's current stream, for adm_ctx_create(): libadm kernels and the
         collectives are then ordered on one stream."""
-        return int(self.torch.cuda.current_stream().cuda_stream) if self.backend == 'nccl' else None
+        return int(self.stream.cuda_stream) if self.backend == 'nccl' else None
 
     # ---- collectives ---------------------------------------------------------------------
     def barrier(self):

@@ -72,7 +72,8 @@ class DataParallelObject(object):
         self.lo = comm.rank * self.per
         self.hi = min(self.lo + self.per, self.n)
         self._keep = []
-        if R > 1:
+        self.dist = R > 1 or getattr(comm, 'backend', 'local') != 'local'
+        if self.dist:
             t_obj, t_grad = comm.alloc(self.n_pad), comm.alloc(self.n_pad)
             self.t_obj, self.t_grad = t_obj, t_grad
             self.t_gshard, self.t_xshard = comm.alloc(self.per), comm.alloc(self.per)
@@ -89,7 +90,7 @@ class DataParallelObject(object):
     def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None):
         """optimizer: 'adam' | 'gd'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict."""
         R = self.comm.size
-        if R > 1:
+        if self.dist:
             self.comm.reduce_scatter_sum(self.t_grad, self.t_gshard)
             g, g_base = self.gshard, self.lo
         else:
@@ -103,7 +104,7 @@ class DataParallelObject(object):
                 self.ops.gd(self.obj, g, g_base, self.lo, self.hi, options['step_size'], flags, mask)
             else:
                 raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
-        if R > 1:
+        if self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
 

@@ -68,6 +68,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--minibatch', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed (RCCL) path even with one rank')
     args = ap.parse_args()
 
     import torch
@@ -82,10 +83,11 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
-    comm = C.TorchComm('nccl', device_index=local_rank) if world > 1 else C.LocalComm()
+    use_dist = world > 1 or args.force_dist
+    comm = C.TorchComm('nccl', device_index=local_rank) if use_dist else C.LocalComm()
     rank = comm.rank
-    stream = int(torch.cuda.current_stream().cuda_stream)
-    ctx = A.Context(local_rank, stream=stream if stream else None)
+    # libadm kernels and the RCCL collectives share one explicit stream (see TorchComm)
+    ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
 
     cfg = W.c3_config()
     B = args.minibatch
@@ -193,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         comm.close()
 
 

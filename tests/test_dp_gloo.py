@@ -1,0 +1,117 @@
+"""CPU, world_size = 2 over gloo: the N>1 path of the data-parallel exchange + sharded update
+(adorym_amd/dp.py + adorym_amd/comm.py) against a single-process update with the summed gradient --
+the reference's semantics (`gradient.arr = comm.allreduce(gradient.arr)`, adorym/ptychography.py:1113-1114).
+The element-wise kernels are replaced by a NumPy stand-in (tests may use the oracle); the product uses HipOps."""
+import os
+import socket
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class NumpyOps(object):
+    """Same interface as adorym_amd.dp.HipOps on host buffers (torch CPU tensors / ndarrays)."""
+
+    def wrap(self, tensor, n):
+        return tensor.numpy()
+
+    def alloc(self, n):
+        return np.zeros(n, np.float32)
+
+    def zero(self, buf):
+        buf[...] = 0
+
+    def copy(self, dst, dst_off, src, src_off, n):
+        dst[dst_off:dst_off + n] = src[src_off:src_off + n]
+
+    def adam(self, x, g, g_base, m, v, mv_base, lo, hi, i_batch, step_size, b1, b2, eps, flags, mask):
+        from oracle import adorym_oracle as O
+        xs, ms, vs = O.adam_step(x[lo:hi], g[lo - g_base:hi - g_base], m[lo - mv_base:hi - mv_base], v[lo - mv_base:hi - mv_base],
+                                 i_batch, step_size, b1, b2, eps)
+        if flags & 1:
+            xs = np.clip(xs, 0, None)
+        x[lo:hi] = xs; m[lo - mv_base:hi - mv_base] = ms; v[lo - mv_base:hi - mv_base] = vs
+
+    def gd(self, x, g, g_base, lo, hi, step_size, flags, mask):
+        x[lo:hi] = x[lo:hi] - np.float32(step_size) * g[lo - g_base:hi - g_base]
+
+
+def _worker(rank, world, port, shape, seed, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from adorym_amd.comm import TorchComm
+    from adorym_amd.dp import DataParallelObject
+    comm = TorchComm('gloo')
+    try:
+        st = DataParallelObject(NumpyOps(), comm, shape)
+        n = st.n
+        r = np.random.default_rng(seed)
+        x0 = (r.standard_normal(n) * 1e-3).astype(np.float32)
+        st.obj[:n] = x0
+        for it in range(3):
+            g_all = [np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world)]
+            st.zero_grad()
+            st.grad[:n] += g_all[rank]                       # this rank's minibatch gradient
+            st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+        st.zero_grad()
+        st.grad[:n] += 1.0
+        st.exchange_and_update('gd', 0, {'step_size': 1e-5})
+        out_q.put((rank, np.array(st.obj[:n]), st.lo, st.hi, comm.max_over_ranks(rank), comm.sum_over_ranks(1.0)))
+    finally:
+        comm.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize('shape', [(4, 5, 6, 2), (3, 3, 3, 2)])     # second: n not divisible by 2*world -> padded shards
+def test_reduce_scatter_adam_allgather_world2(shape):
+    import torch.multiprocessing as mp
+    from oracle import adorym_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, 7, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # single-process reference: Adam with the SUM of the per-rank gradients
+    n = int(np.prod(shape))
+    x = (np.random.default_rng(7).standard_normal(n) * 1e-3).astype(np.float32)
+    m = np.zeros_like(x); v = np.zeros_like(x)
+    for it in range(3):
+        g = sum(np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world))
+        x, m, v = O.adam_step(x, g, m, v, it, step_size=1e-4)
+        x = np.clip(x, 0, None)
+    x = x - np.float32(1e-5) * np.float32(world)          # gd step with summed all-ones gradient
+    los = sorted(r[2] for r in res)
+    assert los[0] == 0 and all(r[3] > r[2] for r in res)
+    for rank, obj, lo, hi, mx, sm in res:
+        assert np.allclose(obj, x, rtol=1e-6, atol=1e-9), rank      # every rank holds the identical updated object
+        assert mx == world - 1 and sm == world
+
+
+def test_shard_bounds_cover_and_align():
+    from adorym_amd.comm import shard_bounds
+    for n in (2, 10, 54, 2 * 256 ** 3):
+        for size in (1, 2, 4, 8):
+            segs = [shard_bounds(n, size, r) for r in range(size)]
+            assert segs[0][0] == 0 and segs[-1][1] == n
+            for (a, b), (c, d) in zip(segs[:-1], segs[1:]):
+                assert b == c and a % 2 == 0 and b % 2 == 0
+
+
+def test_rank_slices_of_global_batch_match_reference_rule():
+    """adorym/ptychography.py:905-908: rank r takes positions [r*mb, (r+1)*mb) of the global batch, sorted."""
+    from oracle import adorym_oracle as O
+    b = O.epoch_task_list(0, 3, 10, 4, n_ranks=2)
+    for k in range(len(b)):
+        full = b[k] if len(b[k]) == 8 else np.concatenate([b[k], b[0][:8 - len(b[k])]])
+        for r in range(2):
+            th, ind = O.rank_batch(b, k, r, 4, 2)
+            assert th == full[r * 4, 0] and np.array_equal(ind, np.sort(full[r * 4:(r + 1) * 4, 1]))
