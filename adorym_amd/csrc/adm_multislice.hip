@@ -27,6 +27,9 @@
 
 namespace adm {
 
+#ifdef ADM_ABL_NOBARRIER
+#define __syncthreads() do { } while (0)
+#endif
 #ifdef ADM_SAFE_SYNC
 #define WAVE_SYNC() __syncthreads()
 #else
@@ -39,46 +42,71 @@ namespace adm {
     } while (0)
 #endif
 
+// LDS layout of the P x P field: element (y, x) lives at  y*Q + posx(x),  posx(x) = (x / R2)*PA + (x % R2)*PB.
+// (PA, PB, Q) = (R2, 1, N+1) is the plain padded row-major image; other triples permute the elements
+// inside a row to spread the stride-R2 accesses of the radix passes over the LDS banks (chosen by an
+// exhaustive conflict count over all wave/lane patterns of the kernel, tools/lds_layout_search.py).
+template <int N, int R1, int R2> struct Layout {
+    static constexpr int PA = R2, PB = 1, Q = N + 1;
+};
+#ifndef ADM_PLAIN_LAYOUT
+template <> struct Layout<72, 8, 9> {
+    static constexpr int PA = 2, PB = 9, Q = 113;
+};
+#endif
+
 template <int N, int R1, int R2> struct Geo {
     static constexpr int G = (R1 > R2) ? R1 : R2;      // threads per line
     static constexpr int LPW = 64 / G;                 // lines per wave
     static constexpr int NWAVES = (N + LPW - 1) / LPW;
     static constexpr int NT = NWAVES * 64;
-    static constexpr int PITCH = N + 1;                // complex elements
+    static constexpr int PA = Layout<N, R1, R2>::PA, PB = Layout<N, R1, R2>::PB, Q = Layout<N, R1, R2>::Q;
+    static constexpr int FLD = N * Q;                  // complex elements of one LDS field image
+    // strides (in complex elements) of the two access patterns in the two roles
+    static constexpr int ROW_P1_K = PA, ROW_P1_T = PB;           // element k*R2 + t of a row
+    static constexpr int ROW_P2_K = PB, ROW_P2_T = PA;           // element t*R2 + k of a row
+    static constexpr int COL_P1_K = R2 * Q, COL_P1_T = Q;        // element k*R2 + t of a column
+    static constexpr int COL_P2_K = Q, COL_P2_T = R2 * Q;        // element t*R2 + k of a column
+    static __device__ __forceinline__ int posx(int x) { return (x / R2) * PA + (x % R2) * PB; }
 };
 
-
 // ---- one line transform pass set (wave-local) ------------------------------------------------
-// `fld` points at element 0 of the line, `ES` = element stride along the line (in complex units).
+// `base` points at the line's origin; element index -> address through the (KS, TS) strides above.
 
-// pass 1 forward: a[n1] holds x[n1*R2 + t]; radix-R1, twiddle, store A'[k1] at (k1*R2 + t)
-template <int N, int R1, int R2>
-__device__ __forceinline__ void p1_fwd_store(cf (&a)[R1], const cf (&tw)[R1], cf* fld, int es, int t) {
-    Dft<R1, false>::run(a);
+template <int R, int KS> __device__ __forceinline__ void ld_line(cf (&a)[R], const cf* base) {
+#ifndef ADM_ABL_NOLDS
+#pragma unroll
+    for (int k = 0; k < R; ++k) a[k] = base[k * KS];
+#else
+#pragma unroll
+    for (int k = 0; k < R; ++k) asm volatile("" : "+v"(a[k].x), "+v"(a[k].y));
+#endif
+}
+template <int R, int KS> __device__ __forceinline__ void st_line(const cf (&a)[R], cf* base) {
+#ifndef ADM_ABL_NOLDS
+#pragma unroll
+    for (int k = 0; k < R; ++k) base[k * KS] = a[k];
+#else
+#pragma unroll
+    for (int k = 0; k < R; ++k) asm volatile("" :: "v"(a[k].x), "v"(a[k].y));
+#endif
+}
+// pass 1 forward: a[n1] holds x[n1*R2 + t]; radix-R1 then twiddle W_N^(t*k1)
+#ifdef ADM_ABL_NOMATH
+#define ADM_DFT(R, INV, x) do { } while (0)
+#else
+#define ADM_DFT(R, INV, x) Dft<R, INV>::run(x)
+#endif
+template <int R1> __device__ __forceinline__ void p1_fwd(cf (&a)[R1], const cf (&tw)[R1]) {
+    ADM_DFT(R1, false, a);
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmul(a[k], tw[k]);
-#pragma unroll
-    for (int k = 0; k < R1; ++k) fld[(k * R2 + t) * es] = a[k];
 }
-template <int N, int R1, int R2>
-__device__ __forceinline__ void p1_load(cf (&a)[R1], const cf* fld, int es, int t) {
-#pragma unroll
-    for (int k = 0; k < R1; ++k) a[k] = fld[(k * R2 + t) * es];
-}
-// pass 1 inverse: a[k1] holds A'[k1] (position k1*R2+t); untwiddle, inverse radix-R1 -> x[n1*R2+t]
-template <int N, int R1, int R2>
-__device__ __forceinline__ void p1_inv(cf (&a)[R1], const cf (&tw)[R1]) {
+// pass 1 inverse: untwiddle, inverse radix-R1 -> x[n1*R2 + t]
+template <int R1> __device__ __forceinline__ void p1_inv(cf (&a)[R1], const cf (&tw)[R1]) {
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmulc(a[k], tw[k]);
-    Dft<R1, true>::run(a);
-}
-template <int R2> __device__ __forceinline__ void p2_load(cf (&b)[R2], const cf* fld, int es, int t) {
-#pragma unroll
-    for (int k = 0; k < R2; ++k) b[k] = fld[(t * R2 + k) * es];
-}
-template <int R2> __device__ __forceinline__ void p2_store(const cf (&b)[R2], cf* fld, int es, int t) {
-#pragma unroll
-    for (int k = 0; k < R2; ++k) fld[(t * R2 + k) * es] = b[k];
+    ADM_DFT(R1, true, a);
 }
 
 // position p = k1*R2 + k2 of a scrambled spectrum holds frequency k1 + R1*k2
@@ -86,87 +114,95 @@ template <int R1, int R2> __device__ __forceinline__ int freq_of_pos(int p) { re
 
 template <int N, int R1, int R2> struct Ctx {
     using GE = Geo<N, R1, R2>;
-    cf* fld;          // LDS field [N][PITCH]
-    int line, t;      // line owned in the current role (row for x passes, column for y passes), thread in line
+    cf* fld;          // LDS field image
+    const cf* hl;     // LDS image (same layout) of H / N^2 in scrambled-frequency order
+    int line, t;      // line owned in both roles (row for x passes, column for y passes), thread in line
     bool act1, act2;  // pass-1 role (t < R2) / pass-2 role (t < R1) active
     cf tw[R1];        // W_N^(t*k1)
-    cf hs[R2];        // H[ky = t + R1*k2][kx(line)] / N^2   (pass-2 role)
+    // per-thread base offsets (complex elements) of the four access patterns
+    int row_p1, row_p2, col_p1, col_p2;
 };
 
-// forward x passes starting from registers `a` (row-role, pass-1), ends with the scrambled x spectrum in LDS
+// forward x passes starting from registers `a` (row role, pass 1); ends with the scrambled x spectrum in LDS
 template <int N, int R1, int R2>
 __device__ __forceinline__ void x_fwd(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
-    cf* row = c.fld + c.line * GE::PITCH;
-    if (c.act1) p1_fwd_store<N, R1, R2>(a, c.tw, row, 1, c.t);
+    if (c.act1) {
+        p1_fwd<R1>(a, c.tw);
+        st_line<R1, GE::ROW_P1_K>(a, c.fld + c.row_p1);
+    }
     WAVE_SYNC();
     if (c.act2) {
         cf b[R2];
-        p2_load<R2>(b, row, 1, c.t);
-        Dft<R2, false>::run(b);
-        p2_store<R2>(b, row, 1, c.t);
+        ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
+        ADM_DFT(R2, false, b);
+        st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
 }
-// inverse x passes, ends with the real-space row elements in registers `a`
+// inverse x passes; ends with the real-space row elements in registers `a`
 template <int N, int R1, int R2>
 __device__ __forceinline__ void x_inv(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
-    cf* row = c.fld + c.line * GE::PITCH;
     if (c.act2) {
         cf b[R2];
-        p2_load<R2>(b, row, 1, c.t);
-        Dft<R2, true>::run(b);
-        p2_store<R2>(b, row, 1, c.t);
+        ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
+        ADM_DFT(R2, true, b);
+        st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
     WAVE_SYNC();
     if (c.act1) {
-        p1_load<N, R1, R2>(a, row, 1, c.t);
-        p1_inv<N, R1, R2>(a, c.tw);
+        ld_line<R1, GE::ROW_P1_K>(a, c.fld + c.row_p1);
+        p1_inv<R1>(a, c.tw);
     }
 }
 // forward y pass 1 (column role)
 template <int N, int R1, int R2>
 __device__ __forceinline__ void y_fwd_p1(Ctx<N, R1, R2>& c) {
     using GE = Geo<N, R1, R2>;
-    cf* col = c.fld + c.line;
     if (c.act1) {
         cf a[R1];
-        p1_load<N, R1, R2>(a, col, GE::PITCH, c.t);
-        p1_fwd_store<N, R1, R2>(a, c.tw, col, GE::PITCH, c.t);
+        ld_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
+        p1_fwd<R1>(a, c.tw);
+        st_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
     }
     WAVE_SYNC();
 }
 template <int N, int R1, int R2>
 __device__ __forceinline__ void y_inv_p1(Ctx<N, R1, R2>& c) {
     using GE = Geo<N, R1, R2>;
-    cf* col = c.fld + c.line;
     WAVE_SYNC();
     if (c.act1) {
         cf a[R1];
-        p1_load<N, R1, R2>(a, col, GE::PITCH, c.t);
-        p1_inv<N, R1, R2>(a, c.tw);
-#pragma unroll
-        for (int k = 0; k < R1; ++k) col[(k * R2 + c.t) * GE::PITCH] = a[k];
+        ld_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
+        p1_inv<R1>(a, c.tw);
+        st_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
     }
 }
 
 // psi <- IFFT2( Hmul * FFT2(psi) ), psi in registers `a` (row role) on entry and exit.
-// CONJ: multiply by conj(hs) (adjoint).  `hs` already carries the 1/N^2 of the inverse.
-template <int N, int R1, int R2, bool CONJ>
+// CONJ: multiply by conj(H) (adjoint).  H already carries the 1/N^2 of the inverse.  The thread <-> (ky, kx)
+// map is static, so H is read from an LDS image with the same addressing as the field element it multiplies
+// (HLDS) or, for the one-off detector-plane Fresnel kernel, from registers `hs`.
+template <int N, int R1, int R2, bool CONJ, bool HLDS>
 __device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2]) {
     using GE = Geo<N, R1, R2>;
     x_fwd<N, R1, R2>(c, a);
     __syncthreads();
     y_fwd_p1<N, R1, R2>(c);
     if (c.act2) {
-        cf* col = c.fld + c.line;
         cf b[R2];
-        p2_load<R2>(b, col, GE::PITCH, c.t);
-        Dft<R2, false>::run(b);
+        ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
+        ADM_DFT(R2, false, b);
+        if (HLDS) {
+            const cf* hp = c.hl + c.col_p2;
 #pragma unroll
-        for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hs[k]);
-        Dft<R2, true>::run(b);
-        p2_store<R2>(b, col, GE::PITCH, c.t);
+            for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hp[k * GE::COL_P2_K]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hs[k]);
+        }
+        ADM_DFT(R2, true, b);
+        st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
     y_inv_p1<N, R1, R2>(c);
     __syncthreads();
@@ -175,9 +211,7 @@ __device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const c
 
 // unnormalised 2-D transform of registers `a` up to (and including) the last y pass, result left in
 // registers b[k2] of the pass-2 column role = spectrum at (ky = t + R1*k2, kx = freq_of_pos(line)).
-// INV selects the inverse (conjugate) transform.  Because forward/inverse butterflies are separate
-// template instances, the inverse direction is implemented with the conjugation identity
-// IDFT(x) = conj(DFT(conj(x))) applied by the caller.
+// The inverse direction is obtained by the caller with IDFT(x) = conj(DFT(conj(x))).
 template <int N, int R1, int R2>
 __device__ __forceinline__ void fft2_to_regs(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&b)[R2]) {
     using GE = Geo<N, R1, R2>;
@@ -185,8 +219,8 @@ __device__ __forceinline__ void fft2_to_regs(Ctx<N, R1, R2>& c, cf (&a)[R1], cf 
     __syncthreads();
     y_fwd_p1<N, R1, R2>(c);
     if (c.act2) {
-        p2_load<R2>(b, c.fld + c.line, GE::PITCH, c.t);
-        Dft<R2, false>::run(b);
+        ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
+        ADM_DFT(R2, false, b);
     }
 }
 // the matching unnormalised inverse, from registers b[k2] back to real-space registers a
@@ -194,8 +228,8 @@ template <int N, int R1, int R2>
 __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
     if (c.act2) {
-        Dft<R2, true>::run(b);
-        p2_store<R2>(b, c.fld + c.line, GE::PITCH, c.t);
+        ADM_DFT(R2, true, b);
+        st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
     y_inv_p1<N, R1, R2>(c);
     __syncthreads();
@@ -276,7 +310,8 @@ __device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restri
 template <int N, int R1, int R2, bool BIN1>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
-    __shared__ cf fld[N * GE::PITCH];
+    __shared__ cf fld[GE::FLD];
+    __shared__ cf hl[GE::FLD];
     __shared__ float red[GE::NWAVES];
 
     const int tid = threadIdx.x;
@@ -284,12 +319,18 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const int li = lane / GE::G;
     Ctx<N, R1, R2> c;
     c.fld = fld;
+    c.hl = hl;
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);
     c.act1 = line_ok && (c.t < R2);
     c.act2 = line_ok && (c.t < R1);
     if (!line_ok) c.line = 0;   // keep addresses in range for inactive lanes
+    const int tc2 = c.t % R1;   // clamp for lanes that are inactive in the pass-2 role
+    c.row_p1 = c.line * GE::Q + c.t * GE::ROW_P1_T;
+    c.row_p2 = c.line * GE::Q + tc2 * GE::ROW_P2_T;
+    c.col_p1 = GE::posx(c.line) + c.t * GE::COL_P1_T;
+    c.col_p2 = GE::posx(c.line) + tc2 * GE::COL_P2_T;
     const int b = blockIdx.x;
 
     // ---- static per-thread constants ----
@@ -300,12 +341,18 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     // double): multiplying by fl(1/N^2) would scale every propagation by the same (1+eps) and the
     // bias would grow linearly with the number of slices.
     const double n2 = (double)(N * N);
+    if (c.act2) {
 #pragma unroll
-    for (int k = 0; k < R2; ++k) {
-        int ky = (c.t % R1) + R1 * k;
-        cf h = p.h[ky * N + kx];
-        c.hs[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
+        for (int k = 0; k < R2; ++k) {
+            const int ky = c.t + R1 * k;
+            const cf h = p.h[ky * N + kx];
+            hl[c.col_p2 + k * GE::COL_P2_K] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
+        }
     }
+    __syncthreads();
+    cf hs_unused[R2];
+#pragma unroll
+    for (int k = 0; k < R2; ++k) hs_unused[k] = make_float2(0.f, 0.f);
 
     const int2 ps = p.pos[b];
     const int py = ps.x + p.pad_y0, px = ps.y + p.pad_x0;
@@ -341,7 +388,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
         }
 #ifndef ADM_ABL_NOCONV
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, c.hs);
+        if (step < p.n_steps - 1) convolve<N, R1, R2, false, true>(c, a, hs_unused);
 #endif
     }
 
@@ -351,11 +398,11 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         cf hf[R2];
 #pragma unroll
         for (int k = 0; k < R2; ++k) {
-            int ky = (c.t % R1) + R1 * k;
+            int ky = tc2 + R1 * k;
             cf h = p.hfree[ky * N + kx];
             hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
         }
-        convolve<N, R1, R2, false>(c, a, hf);
+        convolve<N, R1, R2, false, false>(c, a, hf);
     }
     if (p.det_mode == ADM_DET_FARFIELD_) {
         // Psi = scale * F(psi)  (F forward, or inverse via conjugation when det_inverse)
@@ -411,7 +458,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                 cf h = p.hfree[ky * N + kx];
                 hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
             }
-            convolve<N, R1, R2, true>(c, a, hf);
+            convolve<N, R1, R2, true, false>(c, a, hf);
         }
     }
     // block reduction of the loss
@@ -463,7 +510,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             }
         }
 #ifndef ADM_ABL_NOCONV
-        if (step > 0) convolve<N, R1, R2, true>(c, a, c.hs);
+        if (step > 0) convolve<N, R1, R2, true, true>(c, a, hs_unused);
 #endif
     }
     if (p.grad_probe && c.act1) {
