@@ -208,9 +208,9 @@ extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
 
 extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
     if (!plan || batch <= 0) return 0;
-    // [stash | tile gradients | cover lists (Yp*Xp*(1+48) u32) | overflow flag]
+    // [stash | tile gradients | cover lists (Yp*Xp*(1+64) u32) | overflow flag]
     const size_t per = (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x) * sizeof(float2);
-    return 2 * (size_t)batch * per + (size_t)plan->Yp * plan->Xp * 49 * sizeof(unsigned) + 64;
+    return 2 * (size_t)batch * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64;
 }
 
 extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,

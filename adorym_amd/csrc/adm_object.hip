@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void rotate_adj_kernel(const float2* __restric
 // gtile layout per position: [step][k][tid] with pixel (row, col) -> k = col / R2,
 // tid = (row / LPW) * 64 + (row % LPW) * G + col % R2   (the multislice kernel's thread-native order).
 // --------------------------------------------------------------------------------------------
-#define ADM_MAXCOVER 48
+#define ADM_MAXCOVER 64
 
 struct TileGeom {
     int Yp, Xp, pad_y0, pad_x0, P, R1, R2, G, LPW, NT, n_steps, binning, Z;
@@ -316,6 +316,16 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
     hipLaunchKernelGGL(tile_accumulate_kernel, grid, dim3(256), 0, st, gtile, (const unsigned*)cover, (float2*)grad_rot, g, spb);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
+}
+
+extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host) {
+    if (!plan || !workspace || !overflow_host) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: null argument");
+    if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: bad workspace");
+    const size_t per = (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x);
+    char* ws = (char*)workspace;
+    unsigned* cover = (unsigned*)(ws + 2 * (size_t)batch * per * sizeof(float2));
+    int* overflow = (int*)(cover + (size_t)plan->Yp * plan->Xp * (ADM_MAXCOVER + 1));
+    return adm_d2h(plan->ctx, overflow_host, overflow, sizeof(int));
 }
 
 extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,

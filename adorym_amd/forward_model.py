@@ -95,6 +95,9 @@ class PtychographyModel(ForwardModel):
         self._probe_dev = None
         self._grad_probe_dev = None
         self._reg_val = None
+        # >1 when the driver fuses the minibatches of one angle ('per angle' update scheme) into one launch:
+        # the batch then holds `batch_group` reference minibatches whose losses are summed
+        self.batch_group = 1
 
     # ------------------------------------------------------------------ helpers
     def _check_static(self, probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset):
@@ -138,7 +141,11 @@ class PtychographyModel(ForwardModel):
             if self._grad_probe_dev is None or self._grad_probe_dev.shape != probe.shape:
                 self._grad_probe_dev = self.device.empty(probe.shape)
             gp = self._grad_probe_dev.zero_()
-        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred)
+        B = len(np.asarray(this_pos_batch).reshape(-1, 2))
+        mb = B // self.batch_group
+        gs = 2.0 / (mb * eng.probe_size[0] * eng.probe_size[1])     # each reference minibatch is a mean over ITS positions
+        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs)
+        self._last_mb = mb
         if want_grad:
             eng.rotate_adjoint(grad_obj, coords, yr)
         return gp
@@ -155,8 +162,9 @@ class PtychographyModel(ForwardModel):
             if getattr(self, '_scratch_grad', None) is None or self._scratch_grad.size != obj.size:
                 self._scratch_grad = self.device.empty((obj.size,))
             grad_obj = self._scratch_grad
-        check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad, ab, gm, grad_obj.ptr, self._reg_val.ptr))
-        return float(self._reg_val.get()[0])
+        k = float(self.batch_group)     # every fused minibatch adds the regulariser once (forward_model.py:138-139)
+        check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, grad_obj.ptr, self._reg_val.ptr))
+        return float(self._reg_val.get()[0]) / k
 
     # ------------------------------------------------------------------ reference interface
     def predict(self, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
@@ -176,7 +184,7 @@ class PtychographyModel(ForwardModel):
             target = self.get_data(this_i_theta, this_ind_batch, theta_downsample=self.common_vars.get('theta_downsample'),
                                    ds_level=self.common_vars.get('ds_level', 1))
             self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=False)
-            loss = self.engine.loss() + self._regularize(obj, None)
+            loss = self.engine.loss(last=self._last_mb) + self._regularize(obj, None)
             self.current_loss = float(loss)
             return self.current_loss
         calculate_loss.forward_model = self
@@ -197,7 +205,7 @@ class PtychographyModel(ForwardModel):
         gp = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
                        want_probe_grad=want_probe)
         reg = self._regularize(obj, grad_obj)
-        self.current_loss = float(self.engine.loss() + reg)
+        self.current_loss = float(self.engine.loss(last=self._last_mb) + reg)
         out = []
         gph = gp.get() if gp is not None else None
         for i in opt_args_ls:

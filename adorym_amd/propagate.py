@@ -83,6 +83,7 @@ class MultisliceEngine(object):
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
         self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
         self.max_batch = 0
+        self._accumulated = False
         self._ws = self._pos = self._target = self._pred = self._loss = None
         if max_batch:
             self._reserve(max_batch)
@@ -151,12 +152,23 @@ class MultisliceEngine(object):
         """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
         check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._pos.ptr, self._B,
                                                     self._pos_host.ctypes.data, self.grad_rot.ptr))
+        self._accumulated = True
 
-    def loss(self):
-        """mean((pred - target)^2) over the batch (adorym/forward_model.py:91) -- blocks."""
+    def loss(self, last=None):
+        """mean((pred - target)^2) over the batch (adorym/forward_model.py:91) -- blocks.
+        ``last=n``: over the last n positions only (the final minibatch of a fused 'per angle' group)."""
         B = self._B
-        s = self._loss.view(0, (B,)).get().astype(np.float64).sum()
-        return float(s / (B * self.probe_size[0] * self.probe_size[1]))
+        if self._accumulated:
+            ov = C.c_int(0)
+            check(self.ctx.lib.adm_tile_grad_status(self.plan.handle, self._ws.ptr, self._ws.nbytes, B, C.byref(ov)))
+            if ov.value:
+                raise RuntimeError('tile overlap-add overflow: a pixel is covered by more than 64 tiles of this batch; '
+                                   'use a smaller batch')
+            self._accumulated = False
+        sums = self._loss.view(0, (B,)).get().astype(np.float64)
+        if last is not None:
+            sums = sums[B - last:]
+        return float(sums.sum() / (len(sums) * self.probe_size[0] * self.probe_size[1]))
 
     def pred(self):
         return self._pred.view(0, (self._B,) + self.probe_size).get()

@@ -119,6 +119,7 @@ def reconstruct_ptychography(
     t_zero = time.time()
     comm = kwargs.pop('comm', None) or from_env()
     return_state = kwargs.pop('return_state', False)
+    fuse_per_angle = kwargs.pop('fuse_per_angle', True)
     n_ranks, rank = comm.size, comm.rank
     if backend != 'hip':
         warnings.warn("adorym_amd has a single backend ('hip'); backend='%s' is ignored." % backend)
@@ -409,6 +410,7 @@ def reconstruct_ptychography(
         n_batch = len(ind_list_rand)
         i_opt_batch = 0                       # starting_epoch * n_batch + starting_batch (:848) without checkpoints
         initialize_gradients = True
+        pending_ind = []
 
         for i_batch in range(n_batch):
             t_elapsed = (time.time() - t_zero) / 60
@@ -426,6 +428,18 @@ def reconstruct_ptychography(
             this_pos_batch = probe_pos_int[this_ind_batch]
             is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != this_i_theta
             print_flush('  Current rank is processing angle ID {}.'.format(this_i_theta), sto_rank, rank, **stdout_options)
+
+            # 'per angle': the minibatches of one angle see the same object, so they are fused into ONE launch
+            # (identical sums; all CUs busy instead of `minibatch_size` of them).  The reference evaluates them
+            # one by one and only logs the last (ptychography.py:1095-1099 `continue`).
+            if update_scheme == 'per angle' and fuse_per_angle:
+                pending_ind.append(this_ind_batch)
+                if not is_last_batch_of_this_theta:
+                    continue
+                forward_model.batch_group = len(pending_ind)
+                this_ind_batch = np.concatenate(pending_ind)
+                this_pos_batch = probe_pos_int[this_ind_batch]
+                pending_ind = []
 
             # ---- gradients (ptychography.py:1017-1066) ----
             t_grad_0 = time.time()

@@ -136,6 +136,9 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
  * atomics).  pos_host = the same positions on the host (used for the row window). */
 int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                              const int32_t* pos_host, float* grad_rot);
+/* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
+ * (the overlap-add then dropped contributions; use smaller batches). */
+int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);
 
 /* ---- R9  regulariser gradients --------------------------------------------------------
  * L1Regularizer / TVRegularizer (adorym/regularizers.py:30-46, 95-110; adorym/util.py:1427-1440):

@@ -16,6 +16,7 @@ RUNS = {
     'gd_e1': dict(n_epochs=1, optimizer='gd', learning_rate=1e-9),
     'adam_e1_reg': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5),
     'adam_e1_perangle': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, update_scheme='per angle'),
+    'adam_e1_perangle_unfused': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, update_scheme='per angle', fuse_per_angle=False),
     'adam_e1_nonneg': dict(n_epochs=1, optimizer='adam', learning_rate=1e-5, non_negativity=True),
 }
 
@@ -37,6 +38,7 @@ def run(tmp_path, **extra):
 @pytest.mark.parametrize('name', list(RUNS))
 def test_driver_matches_reference(tmp_path, name):
     g, inp, st = run(tmp_path, **RUNS[name])
+    name = name.replace('_unfused', '')
     x = np.stack([st['delta'], st['beta']], -1).astype(np.float64)
     x64 = np.stack([g['delta_%s_64' % name], g['beta_%s_64' % name]], -1).astype(np.float64)
     x32 = np.stack([g['delta_%s_32' % name], g['beta_%s_32' % name]], -1).astype(np.float64)
