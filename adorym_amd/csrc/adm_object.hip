@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     out[0] = (unsigned)cnt;
 }
 
+// One thread owns one padded pixel and TA_STEPS consecutive modulation steps: for every covering tile it issues
+// TA_STEPS independent 8-B loads (stride = one step of that tile) before touching the accumulators, so a wave keeps
+// TA_STEPS x 64 loads in flight instead of one dependent load per iteration.
+#define TA_STEPS 8
 __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
-                                                              float2* __restrict__ grad_rot, TileGeom g, int steps_per_block) {
+                                                              float2* __restrict__ grad_rot, TileGeom g) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= g.Xp || r >= g.nrows) return;
@@ -141,17 +145,35 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     const size_t step_stride = (size_t)g.R1 * g.NT;
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
-    const int st0 = blockIdx.z * steps_per_block;
-    const int st1 = min(st0 + steps_per_block, g.n_steps);
-    for (int st = st0; st < st1; ++st) {
-        float2 acc = make_float2(0.f, 0.f);
+    const int st0 = blockIdx.z * TA_STEPS;
+    const int nst = min(TA_STEPS, g.n_steps - st0);
+    float2 acc[TA_STEPS];
+#pragma unroll
+    for (int i = 0; i < TA_STEPS; ++i) acc[i] = make_float2(0.f, 0.f);
+    if (nst == TA_STEPS) {
         for (int c = 0; c < cnt; ++c) {
-            const float2 v = gtile[(size_t)cv[1 + c] + (size_t)st * step_stride];
-            acc.x += v.x;
-            acc.y += v.y;
+            const float2* src = gtile + (size_t)cv[1 + c] + (size_t)st0 * step_stride;
+            float2 v[TA_STEPS];
+#pragma unroll
+            for (int i = 0; i < TA_STEPS; ++i) v[i] = src[(size_t)i * step_stride];
+#pragma unroll
+            for (int i = 0; i < TA_STEPS; ++i) { acc[i].x += v[i].x; acc[i].y += v[i].y; }
         }
-        const int s_lo = st * g.binning, s_hi = min(s_lo + g.binning, g.Z);
-        for (int sl = s_lo; sl < s_hi; ++sl) out[(size_t)sl * slice_stride] = acc;
+    } else {
+        for (int c = 0; c < cnt; ++c) {
+            const float2* src = gtile + (size_t)cv[1 + c] + (size_t)st0 * step_stride;
+#pragma unroll
+            for (int i = 0; i < TA_STEPS; ++i)
+                if (i < nst) { const float2 v = src[(size_t)i * step_stride]; acc[i].x += v.x; acc[i].y += v.y; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TA_STEPS; ++i) {
+        if (i < nst) {
+            const int st = st0 + i;
+            const int s_lo = st * g.binning, s_hi = min(s_lo + g.binning, g.Z);
+            for (int sl = s_lo; sl < s_hi; ++sl) out[(size_t)sl * slice_stride] = acc[i];
+        }
     }
 }
 
@@ -311,9 +333,8 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
     ADM_HIP(hipGetLastError());
-    const int spb = 16;
-    grid.z = (plan->n_steps + spb - 1) / spb;
-    hipLaunchKernelGGL(tile_accumulate_kernel, grid, dim3(256), 0, st, gtile, (const unsigned*)cover, (float2*)grad_rot, g, spb);
+    grid.z = (plan->n_steps + TA_STEPS - 1) / TA_STEPS;
+    hipLaunchKernelGGL(tile_accumulate_kernel, grid, dim3(256), 0, st, gtile, (const unsigned*)cover, (float2*)grad_rot, g);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }
