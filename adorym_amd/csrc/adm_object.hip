@@ -91,6 +91,52 @@ __global__ __launch_bounds__(256) void rotate_adj_kernel(const float2* __restric
     }
 }
 
+// Rotation adjoint as a GATHER (deterministic, no atomics): the transpose of the bilinear sampling
+// operator is prebuilt per angle as a CSR matrix over object-plane voxels (host: adorym_amd/util.py
+// build_rotation_adjoint_csr, same fp32 coordinate pipeline as make_bilin).  One thread owns one object
+// voxel column (x, z) -- consecutive threads are consecutive z, the fastest object axis, so the
+// read-modify-write of grad_obj is coalesced -- and walks the y planes four at a time.
+__global__ __launch_bounds__(256) void rotate_adj_csr_kernel(const float2* __restrict__ grot, const int* __restrict__ ptr,
+                                                             const int* __restrict__ src, const float* __restrict__ wgt,
+                                                             float2* __restrict__ gobj, RotGeom g, int y_lo, int y_hi, int y_chunk) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= g.X * g.Z) return;
+    const int beg = ptr[t], end = ptr[t + 1];
+    const int ya = y_lo + blockIdx.y * y_chunk;
+    const int yb = min(ya + y_chunk, y_hi);
+    const size_t plane = (size_t)g.X * g.Z;
+    int y = ya;
+    for (; y + 4 <= yb; y += 4) {
+        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        const size_t row = (size_t)(g.pad_y0 + y) * g.Xp;
+        for (int j = beg; j < end; ++j) {
+            const float w = wgt[j];
+            const float2* q = grot + (size_t)src[j] + row;
+            const float2 v0 = q[0], v1 = q[g.Xp], v2 = q[2 * (size_t)g.Xp], v3 = q[3 * (size_t)g.Xp];
+            a0.x += w * v0.x; a0.y += w * v0.y;
+            a1.x += w * v1.x; a1.y += w * v1.y;
+            a2.x += w * v2.x; a2.y += w * v2.y;
+            a3.x += w * v3.x; a3.y += w * v3.y;
+        }
+        float2* o = gobj + (size_t)y * plane + t;
+        float2 c;
+        c = o[0]; c.x += a0.x; c.y += a0.y; o[0] = c;
+        c = o[plane]; c.x += a1.x; c.y += a1.y; o[plane] = c;
+        c = o[2 * plane]; c.x += a2.x; c.y += a2.y; o[2 * plane] = c;
+        c = o[3 * plane]; c.x += a3.x; c.y += a3.y; o[3 * plane] = c;
+    }
+    for (; y < yb; ++y) {
+        float2 a0 = make_float2(0.f, 0.f);
+        const size_t row = (size_t)(g.pad_y0 + y) * g.Xp;
+        for (int j = beg; j < end; ++j) {
+            const float2 v = grot[(size_t)src[j] + row];
+            a0.x += wgt[j] * v.x; a0.y += wgt[j] * v.y;
+        }
+        float2* o = gobj + (size_t)y * plane + t;
+        float2 c = o[0]; c.x += a0.x; c.y += a0.y; o[0] = c;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Overlap-add of the per-position tile gradients written by the multislice kernel (adjoint of the
 // tile gather, adorym/forward_model.py:313-331).  Tiles overlap, so this is a gather per rotated-frame
@@ -302,6 +348,21 @@ extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint1
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
     hipLaunchKernelGGL(rotate_adj_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, coords, grad_obj, g, y_lo,
                        y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
+                                  const float* csr_w, float* grad_obj, int y_lo, int y_hi) {
+    if (!plan || !grad_rot || !csr_ptr || !csr_src || !csr_w || !grad_obj) return fail(ADM_ERR_INVALID, "adm_rotate_adj_csr: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_adj_csr: bad y range");
+    if (y_lo == y_hi) return ADM_OK;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    const int y_chunk = 16;
+    dim3 grid((d.obj_x * d.obj_z + 255) / 256, (y_hi - y_lo + y_chunk - 1) / y_chunk, 1);
+    hipLaunchKernelGGL(rotate_adj_csr_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src, csr_w,
+                       (float2*)grad_obj, g, y_lo, y_hi, y_chunk);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import check
 from .constants import PI
 from .device import Context, DeviceArray, Plan
-from .util import calculate_pad_len
+from .util import calculate_pad_len, rotation_lookup, build_rotation_adjoint_csr
 
 
 def gen_freq_mesh(voxel_nm, shape):
@@ -37,6 +37,32 @@ def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, fresnel_approx=True, sig
         H = np.exp(sign_convention * 1j * 2 * PI * dist_nm / lmbda_nm * np.sqrt(quad_inner))
         H = H * quad_mask
     return H
+
+
+class RotationTable(object):
+    """Per-angle rotation data on the device: the reference's fp16 lookup table (adorym/util.py:492-516) for the
+    forward gather, and -- built lazily from it -- the CSR transpose used by the adjoint gather."""
+
+    def __init__(self, ctx, obj_size, theta, coords_fp16=None):
+        self.ctx = ctx
+        self.obj_size = tuple(int(v) for v in obj_size)
+        self.host = rotation_lookup(self.obj_size, theta) if coords_fp16 is None else np.asarray(coords_fp16, dtype=np.float16)
+        self.coords = ctx.array(np.ascontiguousarray(self.host).view(np.uint16))
+        self._csr = None
+        self._csr_key = None
+
+    @property
+    def ptr(self):
+        return self.coords.ptr
+
+    def csr(self, plan):
+        key = (plan.rot_shape, plan.pads)
+        if self._csr is None or self._csr_key != key:
+            Zp, Yp, Xp, _ = plan.rot_shape
+            p, s, w = build_rotation_adjoint_csr(self.host, self.obj_size, Yp, Xp, plan.pads[1][0])
+            self._csr = (self.ctx.array(p), self.ctx.array(s), self.ctx.array(w))
+            self._csr_key = key
+        return self._csr
 
 
 class MultisliceEngine(object):
@@ -114,9 +140,15 @@ class MultisliceEngine(object):
                                           self.obj_rot.ptr, lo, hi))
 
     def rotate_adjoint(self, grad_obj, coords, y_range=None):
+        """grad_obj += R^T grad_rot.  With a RotationTable the deterministic CSR gather is used; with a bare
+        coordinate array (or None = identity) the scatter kernel with float atomics."""
         lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
-        check(self.ctx.lib.adm_rotate_adj(self.plan.handle, self.grad_rot.ptr, coords.ptr if coords is not None else None,
-                                          grad_obj.ptr, lo, hi))
+        if isinstance(coords, RotationTable):
+            p, s, w = coords.csr(self.plan)
+            check(self.ctx.lib.adm_rotate_adj_csr(self.plan.handle, self.grad_rot.ptr, p.ptr, s.ptr, w.ptr, grad_obj.ptr, lo, hi))
+        else:
+            check(self.ctx.lib.adm_rotate_adj(self.plan.handle, self.grad_rot.ptr, coords.ptr if coords is not None else None,
+                                              grad_obj.ptr, lo, hi))
 
     def set_batch(self, pos_batch, target):
         """Upload the probe positions [B,2] and target magnitudes [B,Py,Px] of the next minibatch

@@ -32,7 +32,7 @@ from .differentiator import Differentiator
 from .dp import DataParallelObject, HipOps, constraint_flags
 from .forward_model import ForwardModel, PtychographyModel
 from .optimizers import Optimizer, AdamOptimizer, GDOptimizer
-from .propagate import MultisliceEngine, get_kernel
+from .propagate import MultisliceEngine, RotationTable, get_kernel
 from .regularizers import L1Regularizer, TVRegularizer, ReweightedL1Regularizer
 from .util import rotation_lookup, split_tasks, initialize_probe
 from ._io import DataFile, write_tiff, read_tiff
@@ -241,7 +241,7 @@ def reconstruct_ptychography(
 
     def rotation_tables(i_theta):
         if i_theta not in _tables:
-            _tables[i_theta] = ctx.array(rotation_lookup(this_obj_size, theta_ls[i_theta]).view(np.uint16))
+            _tables[i_theta] = RotationTable(ctx, this_obj_size, theta_ls[i_theta])
         return _tables[i_theta]
 
     # ---- seed (ptychography.py:410-412) ---------------------------------------------------------------

@@ -85,3 +85,42 @@ def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=
         probe_real = probe_real * pupil_function
         probe_imag = probe_imag * pupil_function
     return probe_real, probe_imag
+
+
+def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0):
+    """
+    Transpose of the bilinear sampling operator of one angle, as CSR over object-plane voxels t = x*Z + z
+    (for adm_rotate_adj_csr).  The coordinate pipeline is w.grid_sample's (adorym/wrappers.py:1137-1141) followed by
+    torch's grid_sampler (border padding, align_corners=False): fp16 table -> float64 normalise -> float32
+    un-normalise -> clamp -> floor / weights, all in float32 like the forward kernel.
+    Returns (ptr int32 [X*Z+1], src int32 [nnz], w float32 [nnz]); src = z'*(Yp*Xp) + pad_x0 + x'.
+    """
+    _, X, Z = [int(v) for v in obj_size]
+    f32 = np.float32
+    c = np.asarray(coords_fp16).astype(np.float64)
+    gz = (-1 + 2. * c[:, 1] / X + 1. / X).astype(f32)       # (sic) divided by arr_shape[0] == X
+    gx = (-1 + 2. * c[:, 0] / Z + 1. / Z).astype(f32)
+    iz = ((gz + f32(1)) * f32(Z) - f32(1)) / f32(2)
+    ix = ((gx + f32(1)) * f32(X) - f32(1)) / f32(2)
+    iz = np.minimum(f32(Z - 1), np.maximum(iz, f32(0)))
+    ix = np.minimum(f32(X - 1), np.maximum(ix, f32(0)))
+    fz, fx = np.floor(iz), np.floor(ix)
+    tz, tx = (iz - fz).astype(f32), (ix - fx).astype(f32)
+    z0, x0 = fz.astype(np.int64), fx.astype(np.int64)
+    vz, vx = (z0 + 1 <= Z - 1), (x0 + 1 <= X - 1)
+    one = f32(1)
+    p = np.arange(X * Z, dtype=np.int64)
+    src_all = (p % Z) * (Yp * Xp) + pad_x0 + (p // Z)
+    tg, sr, ww = [], [], []
+    for (dx, dz, w, valid) in ((0, 0, (one - tx) * (one - tz), None), (0, 1, (one - tx) * tz, vz),
+                               (1, 0, tx * (one - tz), vx), (1, 1, tx * tz, vx & vz)):
+        m = (w != 0) if valid is None else (valid & (w != 0))
+        tg.append(((x0 + dx) * Z + (z0 + dz))[m])
+        sr.append(src_all[m])
+        ww.append(w[m])
+    tg, sr, ww = np.concatenate(tg), np.concatenate(sr), np.concatenate(ww)
+    order = np.lexsort((sr, tg))                      # by target, then by source: fixed summation order
+    tg, sr, ww = tg[order], sr[order], ww[order]
+    ptr = np.zeros(X * Z + 1, dtype=np.int64)
+    np.cumsum(np.bincount(tg, minlength=X * Z), out=ptr[1:])
+    return ptr.astype(np.int32), sr.astype(np.int32), ww.astype(np.float32)

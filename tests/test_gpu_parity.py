@@ -137,6 +137,15 @@ def test_rotation_vs_reference(A, ctx, name):
     d_g = ctx.zeros(obj.shape)
     eng.rotate_adjoint(d_g, d_coords)
     assert np.abs(d_g.get() - g[name + '_adj_64']).max() < 3e-5
+    # the deterministic CSR-gather form of the same operator
+    tab = A.RotationTable(ctx, size, theta)
+    assert np.array_equal(tab.host, g[name + '_coords'])
+    d_g2 = ctx.zeros(obj.shape)
+    eng.rotate_adjoint(d_g2, tab)
+    assert np.abs(d_g2.get() - g[name + '_adj_64']).max() < 3e-5
+    d_g3 = ctx.zeros(obj.shape)
+    eng.rotate_adjoint(d_g3, tab)
+    assert np.array_equal(d_g2.get(), d_g3.get())          # bitwise reproducible
 
 
 # --------------------------------------------------------------------------- F5 optimisers
@@ -220,10 +229,11 @@ def test_full_step_rotation_overlap_padding(A, ctx, free_prop_cm):
     d_obj = ctx.array(obj, np.float32)
     d_coords = ctx.array(coords.view(np.uint16))
     d_probe = ctx.array(c2(probe))
-    for footprint in (True, False):
+    tab = A.RotationTable(ctx, (N, N, S), theta)
+    for footprint, rot in ((True, d_coords), (False, d_coords), (True, tab)):
         d_grad = ctx.zeros(obj.shape)
         d_gp = ctx.zeros((P, P, 2))
-        loss = eng.loss_and_grad(d_obj, d_grad, d_coords, d_probe, pos, target, grad_probe=d_gp, footprint=footprint)
+        loss = eng.loss_and_grad(d_obj, d_grad, rot, d_probe, pos, target, grad_probe=d_gp, footprint=footprint)
         # guess and truth are close here, so the loss is a small difference of large magnitudes:
         # judge against the fp32 restatement of the reference on the same inputs (3x rule)
         assert abs(loss - loss_o) <= 3 * abs(loss32 - loss_o) + 1e-5 * abs(loss_o), (loss, loss_o, loss32)
