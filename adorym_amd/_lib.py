@@ -32,6 +32,9 @@ SIGNATURES = {
     'adm_ctx_sync': (_I, [_VP]),
     'adm_ctx_stream': (_VP, [_VP]),
     'adm_ctx_device': (_I, [_VP]),
+    'adm_ctx_fork': (_I, [_VP]),
+    'adm_ctx_end_fork': (_I, [_VP]),
+    'adm_ctx_join': (_I, [_VP]),
     'adm_malloc': (_I, [_VP, _SZ, C.POINTER(_VP)]),
     'adm_free': (_I, [_VP, _VP]),
     'adm_memset': (_I, [_VP, _VP, _I, _SZ]),

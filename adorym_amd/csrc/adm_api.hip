@@ -42,23 +42,63 @@ extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
         }
         c->owns_stream = true;
     }
+    c->main_stream = c->stream;
+    c->join_pending = false;
+    hipError_t e2 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (e2 != hipSuccess) {
+        delete c;
+        return hip_fail(e2, "aux stream / events");
+    }
     *out = c;
+    return ADM_OK;
+}
+
+extern "C" int adm_ctx_fork(adm_ctx* ctx) {
+    if (!ctx) return fail(ADM_ERR_INVALID, "adm_ctx_fork: null ctx");
+    if (ctx->stream != ctx->main_stream) return fail(ADM_ERR_INVALID, "adm_ctx_fork: already forked");
+    ADM_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
+    ADM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    ctx->stream = ctx->aux_stream;
+    return ADM_OK;
+}
+extern "C" int adm_ctx_end_fork(adm_ctx* ctx) {
+    if (!ctx) return fail(ADM_ERR_INVALID, "adm_ctx_end_fork: null ctx");
+    if (ctx->stream != ctx->aux_stream) return fail(ADM_ERR_INVALID, "adm_ctx_end_fork: not forked");
+    ADM_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    ctx->stream = ctx->main_stream;
+    ctx->join_pending = true;
+    return ADM_OK;
+}
+extern "C" int adm_ctx_join(adm_ctx* ctx) {
+    if (!ctx) return fail(ADM_ERR_INVALID, "adm_ctx_join: null ctx");
+    if (ctx->stream != ctx->main_stream) return fail(ADM_ERR_INVALID, "adm_ctx_join: still forked");
+    if (ctx->join_pending) {
+        ADM_HIP(hipStreamWaitEvent(ctx->main_stream, ctx->ev_join, 0));
+        ctx->join_pending = false;
+    }
     return ADM_OK;
 }
 
 extern "C" int adm_ctx_destroy(adm_ctx* ctx) {
     if (!ctx) return ADM_OK;
-    (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamSynchronize(ctx->main_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->main_stream);
     delete ctx;
     return ADM_OK;
 }
 extern "C" int adm_ctx_sync(adm_ctx* ctx) {
     if (!ctx) return fail(ADM_ERR_INVALID, "adm_ctx_sync: null ctx");
-    ADM_HIP(hipStreamSynchronize(ctx->stream));
+    ADM_HIP(hipStreamSynchronize(ctx->aux_stream));
+    ADM_HIP(hipStreamSynchronize(ctx->main_stream));
     return ADM_OK;
 }
-extern "C" void* adm_ctx_stream(adm_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" void* adm_ctx_stream(adm_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
 extern "C" int adm_ctx_device(adm_ctx* ctx) { return ctx ? ctx->device : -1; }
 
 extern "C" int adm_malloc(adm_ctx* ctx, size_t bytes, void** dptr) {

@@ -11,8 +11,12 @@
 
 struct adm_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;      // stream new work is enqueued on (main, or aux between adm_ctx_fork / adm_ctx_end_fork)
+    hipStream_t main_stream;
+    hipStream_t aux_stream;  // side stream for work that is independent of the multislice chain
+    hipEvent_t ev_fork, ev_join;
     bool owns_stream;
+    bool join_pending;
 };
 
 struct adm_plan {

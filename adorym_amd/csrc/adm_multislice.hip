@@ -311,7 +311,9 @@ template <int N, int R1, int R2, bool BIN1>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
+#ifdef ADM_H_IN_LDS
     __shared__ cf hl[GE::FLD];
+#endif
     __shared__ float red[GE::NWAVES];
 
     const int tid = threadIdx.x;
@@ -319,7 +321,11 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const int li = lane / GE::G;
     Ctx<N, R1, R2> c;
     c.fld = fld;
+#ifdef ADM_H_IN_LDS
     c.hl = hl;
+#else
+    c.hl = nullptr;
+#endif
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);
@@ -341,18 +347,25 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     // double): multiplying by fl(1/N^2) would scale every propagation by the same (1+eps) and the
     // bias would grow linearly with the number of slices.
     const double n2 = (double)(N * N);
+    // The thread <-> (ky, kx) map is static, so each thread keeps its R2 values of H / N^2 in registers for the
+    // whole kernel (ADM_H_IN_LDS: in an LDS image instead -- slower once the register file is not the limit).
+    cf hs[R2];
+#pragma unroll
+    for (int k = 0; k < R2; ++k) {
+        const int ky = tc2 + R1 * k;
+        const cf h = p.h[ky * N + kx];
+        hs[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
+    }
+#ifdef ADM_H_IN_LDS
     if (c.act2) {
 #pragma unroll
-        for (int k = 0; k < R2; ++k) {
-            const int ky = c.t + R1 * k;
-            const cf h = p.h[ky * N + kx];
-            hl[c.col_p2 + k * GE::COL_P2_K] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
-        }
+        for (int k = 0; k < R2; ++k) hl[c.col_p2 + k * GE::COL_P2_K] = hs[k];
     }
     __syncthreads();
-    cf hs_unused[R2];
-#pragma unroll
-    for (int k = 0; k < R2; ++k) hs_unused[k] = make_float2(0.f, 0.f);
+    constexpr bool kHLds = true;
+#else
+    constexpr bool kHLds = false;
+#endif
 
     const int2 ps = p.pos[b];
     const int py = ps.x + p.pad_y0, px = ps.y + p.pad_x0;
@@ -388,7 +401,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
         }
 #ifndef ADM_ABL_NOCONV
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false, true>(c, a, hs_unused);
+        if (step < p.n_steps - 1) convolve<N, R1, R2, false, kHLds>(c, a, hs);
 #endif
     }
 
@@ -510,7 +523,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             }
         }
 #ifndef ADM_ABL_NOCONV
-        if (step > 0) convolve<N, R1, R2, true, true>(c, a, hs_unused);
+        if (step > 0) convolve<N, R1, R2, true, kHLds>(c, a, hs);
 #endif
     }
     if (p.grad_probe && c.act1) {

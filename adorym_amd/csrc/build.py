@@ -33,7 +33,7 @@ def build(force=False, extra=(), out=None, tag=''):
     for s in SRCS:
         o = os.path.join(HERE, s.replace('.hip', tag + '.o'))
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
-               '-Wno-unused-result', '-c', os.path.join(HERE, s), '-o', o] + list(extra)
+               '-Wno-unused-result', '-fno-slp-vectorize', '-c', os.path.join(HERE, s), '-o', o] + list(extra)
         subprocess.check_call(cmd)
         objs.append(o)
     subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)

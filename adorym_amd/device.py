@@ -22,6 +22,17 @@ class Context(object):
     def sync(self):
         check(self.lib.adm_ctx_sync(self.handle))
 
+    def fork(self):
+        """Following calls go to the side stream (after everything enqueued so far) until end_fork()."""
+        check(self.lib.adm_ctx_fork(self.handle))
+
+    def end_fork(self):
+        check(self.lib.adm_ctx_end_fork(self.handle))
+
+    def join(self):
+        """Main stream waits for the side work enqueued between fork() and end_fork()."""
+        check(self.lib.adm_ctx_join(self.handle))
+
     @property
     def stream(self):
         return self.lib.adm_ctx_stream(self.handle)

@@ -110,6 +110,8 @@ class MultisliceEngine(object):
         self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
         self.max_batch = 0
         self._accumulated = False
+        self._all_pos_host = np.ascontiguousarray(probe_pos.astype(np.int32))
+        self._all_pos_dev = ctx.array(self._all_pos_host)
         self._ws = self._pos = self._target = self._pred = self._loss = None
         if max_batch:
             self._reserve(max_batch)
@@ -156,7 +158,20 @@ class MultisliceEngine(object):
         pos = np.ascontiguousarray(np.round(np.asarray(pos_batch)).astype(np.int32).reshape(-1, 2))
         B = len(pos)
         self._reserve(B)
-        self._pos.view(0, (B, 2)).set(pos)
+        # all probe positions live on the device (uploaded once): a minibatch that is a contiguous run of the
+        # scan list needs no host-to-device copy at all
+        run = None
+        if self._all_pos_host is not None and B <= len(self._all_pos_host):
+            cand = np.flatnonzero((self._all_pos_host[:len(self._all_pos_host) - B + 1] == pos[0]).all(axis=1))
+            for c in cand:
+                if np.array_equal(self._all_pos_host[c:c + B], pos):
+                    run = int(c)
+                    break
+        if run is not None:
+            self._cur_pos = self._all_pos_dev.view(2 * run, (B, 2))
+        else:
+            self._cur_pos = self._pos.view(0, (B, 2))
+            self._cur_pos.set(pos)
         self._pos_host = pos
         if isinstance(target, DeviceArray):
             self._cur_target = target
@@ -174,7 +189,7 @@ class MultisliceEngine(object):
         if grad_scale is None:
             grad_scale = 2.0 / (B * Py * Px)          # d mean((pred-target)^2) / d pred
         check(self.ctx.lib.adm_multislice_fwd_adj(
-            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._pos.ptr, B, self._cur_target.ptr,
+            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
             1 if want_grad else 0, grad_probe.ptr if grad_probe is not None else None,
             self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
         if want_grad and accumulate:
@@ -182,7 +197,7 @@ class MultisliceEngine(object):
 
     def accumulate_tiles(self):
         """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
-        check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._pos.ptr, self._B,
+        check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
                                                     self._pos_host.ctypes.data, self.grad_rot.ptr))
         self._accumulated = True
 

@@ -188,7 +188,13 @@ def main():
     def step(k, timed):
         it, ind = plan_batches[k]
         pos = pos_all[ind]
+        # side stream: zero the gradient buffer and add the regulariser gradient (they only read the object) while
+        # the multislice chain, which occupies `minibatch` of the 256 CUs, runs on the main stream
+        ctx.fork()
         state.zero_grad()
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
+                                   state.grad.ptr, None))
+        ctx.end_fork()
         eng.set_batch(pos, targets[(it, int(ind[0]))])
         yr = eng.y_footprint(pos)
         eng.rotate(state.obj, tables[it], yr)
@@ -198,9 +204,8 @@ def main():
         if timed:
             ev_ms[1].record()
         eng.accumulate_tiles()
+        ctx.join()
         eng.rotate_adjoint(state.grad, tables[it], yr)
-        check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
-                                   state.grad.ptr, None))
         state.exchange_and_update('adam', k, opt_options)
         if timed:
             ms_kernel_total[0] += ev_ms[0].elapsed_ms(ev_ms[1])   # blocks on the kernel only; the rest stays queued

@@ -50,6 +50,13 @@ int adm_ctx_destroy(adm_ctx* ctx);
 int adm_ctx_sync(adm_ctx* ctx);                 /* blocks until the stream is idle */
 void* adm_ctx_stream(adm_ctx* ctx);             /* the hipStream_t in use */
 int adm_ctx_device(adm_ctx* ctx);
+/* Side stream for work that does not depend on the multislice chain (e.g. zeroing the gradient buffer and the
+ * regulariser gradient, which only read the object): calls made between adm_ctx_fork and adm_ctx_end_fork are
+ * enqueued on an auxiliary stream that first waits for everything enqueued so far; adm_ctx_join makes the main
+ * stream wait for that side work (call it before the first consumer of its results). */
+int adm_ctx_fork(adm_ctx* ctx);
+int adm_ctx_end_fork(adm_ctx* ctx);
+int adm_ctx_join(adm_ctx* ctx);
 
 /* ---- device memory (replaces w.create_variable / w.zeros / w.to_numpy on device tensors,
  *      adorym/wrappers.py:121-147, 186-205) -------------------------------------------- */
