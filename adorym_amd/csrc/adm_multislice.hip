@@ -275,8 +275,25 @@ __device__ __forceinline__ float exp_fast(float x) {
 // exp(-k1*beta) * (cos, sin)(-sigma*k1*delta)      (adorym/wrappers.py:600-608)
 __device__ __forceinline__ cf modulator(float2 db, float k1, float sigma) {
     const float e = exp_fast(-k1 * db.y);
+    const float phi = -sigma * k1 * db.x;
     float sn, cs;
-    sincos_fast(-sigma * k1 * db.x, sn, cs);
+#ifndef ADM_NO_SMALL_PHASE_PATH
+    // X-ray phase shifts per slice are tiny (k1*delta ~ 1e-2): when every lane of the wave is inside
+    // [-pi/4, pi/4] the range reduction and quadrant selection are skipped (wave-uniform branch, same
+    // polynomials => bit-identical results to the general path).
+    if (__builtin_amdgcn_ballot_w64(fabsf(phi) > 0.78539816f) == 0) {
+        const float r2 = phi * phi;
+        float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+        sp = fmaf(sp, r2, -1.6666654611e-1f);
+        sn = fmaf(sp * r2, phi, phi);
+        float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        cp = fmaf(cp, r2, 4.166664568298827e-2f);
+        cs = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    } else
+#endif
+    {
+        sincos_fast(phi, sn, cs);
+    }
     return make_float2(e * cs, e * sn);
 }
 
