@@ -1,0 +1,128 @@
+"""Edge cases of the C ABI and the host layer on the GPU: error behaviour, ragged / overhanging inputs,
+forward-only and binned paths, determinism of the gradient path, full-field (config-2 shape) run."""
+import ctypes as C
+import numpy as np
+import pytest
+
+import cases
+from oracle import adorym_oracle as O      # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def A():
+    import adorym_amd
+    return adorym_amd
+
+
+@pytest.fixture(scope='module')
+def ctx(A):
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+def c2(z):
+    return np.stack([z.real, z.imag], -1).astype(np.float32)
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64))
+
+
+def test_c_abi_error_codes_and_messages(A, ctx):
+    from adorym_amd import _lib
+    lib = ctx.lib
+    # null / invalid arguments return ADM_ERR_INVALID and leave a message; nothing throws or crashes
+    assert lib.adm_rotate_fwd(None, None, None, None, 0, 1) == _lib.ADM_ERR_INVALID
+    assert b'null' in lib.adm_last_error()
+    eng = A.MultisliceEngine(ctx, (16, 16, 4), (16, 16), np.array([(0, 0)]), 5000., 1e-7)
+    obj = ctx.zeros((16, 16, 4, 2))
+    assert lib.adm_rotate_fwd(eng.plan.handle, obj.ptr, None, eng.obj_rot.ptr, 5, 3) == _lib.ADM_ERR_INVALID      # y_lo > y_hi
+    assert lib.adm_rotate_fwd(eng.plan.handle, obj.ptr, None, eng.obj_rot.ptr, 0, 99) == _lib.ADM_ERR_INVALID     # beyond Y
+    assert lib.adm_rotate_fwd(eng.plan.handle, obj.ptr, None, eng.obj_rot.ptr, 4, 4) == _lib.ADM_OK               # empty range: no-op
+    probe = ctx.zeros((16, 16, 2)); pos = ctx.array(np.zeros((1, 2), np.int32)); tgt = ctx.zeros((1, 16, 16)); loss = ctx.zeros((1,))
+    rc = lib.adm_multislice_fwd_adj(eng.plan.handle, eng.obj_rot.ptr, probe.ptr, pos.ptr, 0, tgt.ptr, 0, None, None, loss.ptr, 1.0, None, 0)
+    assert rc == _lib.ADM_ERR_INVALID and b'batch' in lib.adm_last_error()                                          # empty batch
+    rc = lib.adm_multislice_fwd_adj(eng.plan.handle, eng.obj_rot.ptr, probe.ptr, pos.ptr, 1, tgt.ptr, 1, None, None, loss.ptr, 1.0, None, 0)
+    assert rc == _lib.ADM_ERR_INVALID and b'workspace' in lib.adm_last_error()                                      # gradient without scratch
+    with pytest.raises(ValueError):
+        A.Plan(ctx, (16, 16, 4), (16, 16), ((0, 0), (0, 0)), 1.0, np.ones((16, 16), complex), binning=0)
+    with pytest.raises(ValueError):
+        A.Plan(ctx, (16, 16, 4), (16, 16), ((0, 0), (0, 0)), 1.0, np.ones((16, 16), complex), sign_convention=2)
+    d = ctx.zeros((4,))
+    with pytest.raises(ValueError):
+        d.set(np.zeros(5, np.float32))                                                                              # size mismatch on upload
+
+
+def test_tiles_hanging_over_every_edge_and_duplicates(A, ctx):
+    """Positions far outside on all four sides (zero padding, adorym/util.py:1327-1406) and a duplicated position
+    (the reference pads short spot lists with repeats, ptychography.py:816-819): gradients add up."""
+    r = cases.rng(61)
+    N, P, S = 20, 12, 6
+    obj = np.stack([1e-3 * r.uniform(size=(N, N, S)), 1e-4 * r.uniform(size=(N, N, S))], -1)
+    pos = np.array([(-11, -11), (-11, 19), (19, -11), (19, 19), (4, 4), (4, 4)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    phys = O.Physics((P, P), 5000., 1e-7)
+    target = np.abs(r.standard_normal((len(pos), P, P))) * 5
+    loss_o, _, g_o, _ = O.forward_adjoint_object(obj, None, probe, pos, target, phys, 'float64')
+    eng = A.MultisliceEngine(ctx, (N, N, S), (P, P), pos, 5000., 1e-7)
+    assert eng.pads.tolist() == [[11, 11], [11, 11]]
+    d_grad = ctx.zeros(obj.shape)
+    loss = eng.loss_and_grad(ctx.array(obj, np.float32), d_grad, None, ctx.array(c2(probe)), pos, target)
+    assert abs(loss - loss_o) <= 1e-5 * abs(loss_o)
+    assert rel(d_grad.get(), g_o) < 1e-4
+
+
+def test_gradient_path_is_bitwise_reproducible(A, ctx):
+    """No atomics on the object-gradient path (tile overlap-add and CSR rotation adjoint are gathers)."""
+    r = cases.rng(62)
+    N, P, S = 32, 16, 8
+    obj = np.stack([1e-3 * r.uniform(size=(N, N, S)), 1e-4 * r.uniform(size=(N, N, S))], -1).astype(np.float32)
+    pos = np.array([(y, x) for y in (-4, 4, 12) for x in (-4, 4, 12, 20)])
+    probe = ctx.array(c2((0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))))
+    target = np.abs(r.standard_normal((len(pos), P, P))).astype(np.float32) * 4
+    eng = A.MultisliceEngine(ctx, (N, N, S), (P, P), pos, 5000., 1e-7)
+    tab = A.RotationTable(ctx, (N, N, S), np.float32(0.9))
+    d_obj = ctx.array(obj)
+    outs = []
+    for _ in range(3):
+        g = ctx.zeros(obj.shape)
+        eng.loss_and_grad(d_obj, g, tab, probe, pos, target)
+        outs.append(g.get())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_fullfield_config2_shape_driver_vs_oracle(A, ctx, tmp_path):
+    """Config 2 of BASELINE.json: 64^3 full-field multislice tomography, one 64x64 'position' at (0,0), near field
+    (free_prop_cm=0), plane probe, minibatch 1, L1 regulariser, finite-support mask, Adam -- the shape of the
+    reference's only pytest (tests/test_multislice_tomography_64.py:20-65), on 6 angles."""
+    N, n_theta = 64, 6
+    truth = np.stack([2e-5 * cases.smooth_field((N, N, N), 71), 2e-7 * cases.smooth_field((N, N, N), 72)], -1)
+    theta_ls = np.linspace(0, 2 * np.pi, n_theta, dtype='float32')
+    phys = O.Physics((N, N), 800., 0.67e-7, free_prop_cm=0)
+    probe = np.ones((N, N), complex)
+    prj = np.zeros((n_theta, 1, N, N))
+    for i, th in enumerate(theta_ls):
+        rot = O.rotate_fwd(truth, O.rotation_coords((N, N, N), th), 'float64')
+        prj[i, 0] = np.abs(O.multislice_forward(rot[None], probe, phys, 'float64'))[0]
+    r = cases.rng(73)
+    guess = [r.normal(8.7e-7, 1e-7, (N, N, N)), r.normal(5.1e-8, 1e-8, (N, N, N))]
+    yy, xx, zz = np.meshgrid(*[np.arange(N)] * 3, indexing='ij')
+    mask = (((xx - 31.5) ** 2 + (zz - 31.5) ** 2) < 28 ** 2).astype(np.float32)
+    kw = dict(n_epochs=1, minibatch_size=1, optimizer='adam', learning_rate=1e-7, alpha_d=1.e-9 * 64 ** 3, alpha_b=1.e-10 * 64 ** 3,
+              gamma=0)
+    st = A.reconstruct_ptychography(fname=prj.astype(np.float32), obj_size=(N, N, N), probe_pos=[(0, 0)], theta_st=0, theta_end=2 * np.pi,
+                                    n_theta=n_theta, energy_ev=800., psize_cm=0.67e-7, free_prop_cm=0, probe_type='plane',
+                                    initial_guess=guess, finite_support_mask_path=mask, save_path=str(tmp_path), output_folder='ff',
+                                    store_checkpoint=False, use_checkpoint=False, return_state=True, **kw)
+    ref, losses, _ = O.reconstruct(prj.astype(np.float32).astype(np.float64), guess, probe, np.array([(0., 0.)]), theta_ls, phys,
+                                   mask=mask, dtype='float64', return_trace=True, n_epochs=1, minibatch_size=1, optimizer='adam',
+                                   learning_rate=1e-7, alpha_d=kw['alpha_d'], alpha_b=kw['alpha_b'], gamma=None)
+    x = np.stack([st['delta'], st['beta']], -1)
+    assert np.allclose(st['losses'], losses, rtol=1e-4)
+    assert np.sqrt(np.mean((x - ref) ** 2)) < 1e-5                     # BASELINE's absolute bar
+    d = np.abs(x - ref)
+    assert (d > 3e-8).mean() < 2e-3, (d > 3e-8).mean()                 # lr = 1e-7 steps: all but sign-flip voxels agree
+    assert np.all(x[mask == 0] == 0)                                   # finite-support mask applied
