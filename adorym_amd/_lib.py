@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get('ADM_LIB_PATH') or os.path.join(_HERE, 'libadm.so')   
 
 ADM_OK, ADM_ERR_INVALID, ADM_ERR_HIP, ADM_ERR_UNSUPPORTED, ADM_ERR_NOMEM = 0, -1, -2, -3, -4
 DET_NONE, DET_FARFIELD, DET_FRESNEL = 0, 1, 2
+LOSS_LSQ, LOSS_POISSON = 0, 1
 FLAG_NONNEG, FLAG_ZERO_CH0, FLAG_ZERO_CH1 = 1, 2, 4
 
 
@@ -18,7 +19,8 @@ class PlanDesc(C.Structure):
                 ('binning', C.c_int32), ('n_modes', C.c_int32), ('sign_convention', C.c_int32),
                 ('det_mode', C.c_int32), ('normalize_fft', C.c_int32), ('k1', C.c_float),
                 ('h_re', C.POINTER(C.c_float)), ('h_im', C.POINTER(C.c_float)),
-                ('hfree_re', C.POINTER(C.c_float)), ('hfree_im', C.POINTER(C.c_float))]
+                ('hfree_re', C.POINTER(C.c_float)), ('hfree_im', C.POINTER(C.c_float)),
+                ('loss_type', C.c_int32), ('poisson_multiplier', C.c_float)]
 
 
 _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
@@ -58,6 +60,9 @@ SIGNATURES = {
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
+    'adm_momentum_step': (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _D, _D, _I, _VP]),
+    'adm_rwl1_update': (_I, [_VP, _VP, _VP, _VP]),
+    'adm_reg_grad_weighted': (_I, [_VP, _VP, _VP, _F, _F, _VP, _VP]),
     'adm_axpy': (_I, [_VP, _VP, _VP, _F, _SZ]),
 }
 

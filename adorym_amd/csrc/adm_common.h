@@ -54,6 +54,8 @@ struct MsParams {
     float det_scale;               // far-field scale: 1, 1/N^2, or 1/N (ortho)
     float k1, sigma;
     float grad_scale;
+    int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
+    float poisson_mult;
 };
 int ms_threads_for(int n);
 int ms_r2_for(int n);

@@ -238,6 +238,21 @@ __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], 
 
 __device__ __forceinline__ cf conjf2(cf a) { return make_float2(a.x, -a.y); }
 
+// Per-pixel loss term and the factor g with dL/dPsi = g * Psi (adorym/forward_model.py:88-103):
+//   LSQ      term = (|Psi| - t)^2,                         g = grad_scale * (|Psi| - t) / |Psi|     (0 at |Psi| = 0)
+//   Poisson  term = |Psi|^2 pm - t pm log(|Psi|^2 pm),     g = grad_scale * pm * (1 - t / |Psi|^2)
+// grad_scale = 2 / (minibatch * Py * Px) in both cases.
+__device__ __forceinline__ float loss_term(float mag, float t, const MsParams& p, float& g) {
+    if (p.loss_type == 0) {
+        const float diff = mag - t;
+        g = (mag > 0.f) ? p.grad_scale * diff / mag : 0.f;
+        return diff * diff;
+    }
+    const float inten = mag * mag;
+    g = p.grad_scale * p.poisson_mult * (1.f - t / inten);
+    return inten * p.poisson_mult - t * p.poisson_mult * logf(inten * p.poisson_mult);
+}
+
 // Branch-free single-precision sin/cos: 3-term Cody-Waite reduction by pi/2 (exact product steps via
 // fma, good for |x| < ~1e5) + Cephes minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ocml's sincosf
 // is equally accurate but costs several hundred instructions and dozens of branches per call, which
@@ -355,6 +370,12 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     c.col_p1 = GE::posx(c.line) + c.t * GE::COL_P1_T;
     c.col_p2 = GE::posx(c.line) + tc2 * GE::COL_P2_T;
     const int b = blockIdx.x;
+#ifdef ADM_SETPRIO
+    // experiment: static wave priorities to break the lockstep of the waves that share a SIMD
+    if (ADM_SETPRIO == 1) { if (wave >= 4 && wave < 8) __builtin_amdgcn_s_setprio(1); else if (wave >= 8) __builtin_amdgcn_s_setprio(2); }
+    if (ADM_SETPRIO == 2) { if (wave >= 6) __builtin_amdgcn_s_setprio(1); }
+    if (ADM_SETPRIO == 3) { if (wave < 4) __builtin_amdgcn_s_setprio(2); else if (wave < 8) __builtin_amdgcn_s_setprio(1); }
+#endif
 
     // ---- static per-thread constants ----
 #pragma unroll
@@ -451,10 +472,9 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                 const size_t di = ((size_t)b * N + my) * N + mx;
                 cf psi = cscale(bb[k], p.det_scale);           // (conjugated when det_inverse; |.| unaffected)
                 float mag = sqrtf(psi.x * psi.x + psi.y * psi.y);
-                float diff = mag - p.target[di];
-                lsum += diff * diff;
+                float g;
+                lsum += loss_term(mag, p.target[di], p, g);
                 if (p.pred) p.pred[di] = mag;
-                float g = (mag > 0.f) ? p.grad_scale * diff / mag : 0.f;
                 // adjoint of (scale * F): scale * F^H; with bb conjugated both ways the same code serves
                 bb[k] = cscale(psi, g * p.det_scale);
             }
@@ -473,10 +493,9 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             for (int k = 0; k < R1; ++k) {
                 const size_t di = ((size_t)b * N + c.line) * N + k * R2 + c.t;
                 float mag = sqrtf(a[k].x * a[k].x + a[k].y * a[k].y);
-                float diff = mag - p.target[di];
-                lsum += diff * diff;
+                float g;
+                lsum += loss_term(mag, p.target[di], p, g);
                 if (p.pred) p.pred[di] = mag;
-                float g = (mag > 0.f) ? p.grad_scale * diff / mag : 0.f;
                 a[k] = cscale(a[k], g);
             }
         }

@@ -310,6 +310,69 @@ __global__ __launch_bounds__(256) void gd_kernel(float* __restrict__ x, const fl
         x[i] = constrain(x[i] - step * g[i], i, flags, mask);
 }
 
+__global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ v,
+                                                       size_t lo, size_t hi, float step, float gamma, int flags,
+                                                       const float* __restrict__ mask) {
+#pragma clang fp contract(off)
+    for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
+        const float vv = gamma * v[i] + step * g[i];
+        v[i] = vv;
+        x[i] = constrain(x[i] - vv, i, flags, mask);
+    }
+}
+
+// reweighted L1: block partials of (max, sum) -> final scalars -> weights
+__global__ __launch_bounds__(256) void rwl1_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ part) {
+    float mx = -3.4e38f;
+    double sm = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        mx = fmaxf(mx, v);
+        sm += (double)v;
+    }
+    __shared__ float smx[256];
+    __shared__ double ssm[256];
+    smx[threadIdx.x] = mx; ssm[threadIdx.x] = sm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]); ssm[threadIdx.x] += ssm[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = smx[0]; part[2 * blockIdx.x + 1] = (float)(ssm[0] / (double)n); }
+}
+__global__ void rwl1_final_kernel(float* part, int nblocks) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float mx = -3.4e38f; double mean = 0.0;
+        for (int b = 0; b < nblocks; ++b) { mx = fmaxf(mx, part[2 * b]); mean += (double)part[2 * b + 1]; }
+        part[2 * nblocks] = mx; part[2 * nblocks + 1] = (float)mean;
+    }
+}
+__global__ __launch_bounds__(256) void rwl1_weight_kernel(const float* __restrict__ x, float* __restrict__ w, size_t n,
+                                                          const float* __restrict__ scal) {
+    const float mx = scal[0], off = 1e-4f * scal[1];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        w[i] = mx / (fabsf(x[i]) + off);
+}
+__global__ __launch_bounds__(256) void reg_grad_weighted_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float* __restrict__ g, size_t n, float a_d, float a_b,
+                                                                float invV, float* reg_value) {
+    float val = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float al = (i & 1) ? a_b : a_d;
+        const float v = x[i], wi = w[i];
+        g[i] += al * wi * sgn(v) * invV;
+        val += al * wi * fabsf(v) * invV;
+    }
+    if (reg_value) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reg_value, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         y[i] += a * x[i];
@@ -442,6 +505,41 @@ extern "C" int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, si
     if (!ctx || !x || !g) return fail(ADM_ERR_INVALID, "adm_gd_step: null argument");
     if (hi <= lo) return ADM_OK;
     hipLaunchKernelGGL(gd_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, lo, hi, (float)step_size, flags, mask);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_momentum_step(adm_ctx* ctx, float* x, const float* g, float* v, size_t lo, size_t hi, double step_size,
+                                 double gamma, int flags, const float* mask) {
+    if (!ctx || !x || !g || !v) return fail(ADM_ERR_INVALID, "adm_momentum_step: null argument");
+    if (hi <= lo) return ADM_OK;
+    hipLaunchKernelGGL(momentum_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, v, lo, hi, (float)step_size,
+                       (float)gamma, flags, mask);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rwl1_update(adm_plan* plan, const float* obj, float* weight, float* scratch) {
+    if (!plan || !obj || !weight || !scratch) return fail(ADM_ERR_INVALID, "adm_rwl1_update: null argument");
+    const adm_plan_desc& d = plan->d;
+    const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
+    int nb = stream_grid(n);
+    if (nb > 1024) nb = 1024;
+    hipStream_t st = plan->ctx->stream;
+    hipLaunchKernelGGL(rwl1_partial_kernel, dim3(nb), dim3(256), 0, st, obj, n, scratch);
+    hipLaunchKernelGGL(rwl1_final_kernel, dim3(1), dim3(64), 0, st, scratch, nb);
+    hipLaunchKernelGGL(rwl1_weight_kernel, dim3(stream_grid(n)), dim3(256), 0, st, obj, weight, n, (const float*)(scratch + 2 * nb));
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_reg_grad_weighted(adm_plan* plan, const float* obj, const float* weight, float alpha_d, float alpha_b,
+                                     float* grad_obj, float* reg_value) {
+    if (!plan || !obj || !weight || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad_weighted: null argument");
+    const adm_plan_desc& d = plan->d;
+    const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
+    hipLaunchKernelGGL(reg_grad_weighted_kernel, dim3(stream_grid(n)), dim3(256), 0, plan->ctx->stream, obj, weight, grad_obj, n,
+                       alpha_d, alpha_b, 1.0f / (float)(n / 2), reg_value);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -42,6 +42,10 @@ class HipOps(object):
                                          lo, hi, int(i_batch), float(step_size), float(b1), float(b2), float(eps), int(flags),
                                          mask.ptr if mask is not None else None))
 
+    def momentum(self, x, g, g_base, v, v_base, lo, hi, step_size, gamma, flags, mask):
+        check(self.ctx.lib.adm_momentum_step(self.ctx.handle, x.ptr, g.ptr - 4 * g_base, v.ptr - 4 * v_base, lo, hi, float(step_size),
+                                             float(gamma), int(flags), mask.ptr if mask is not None else None))
+
     def gd(self, x, g, g_base, lo, hi, step_size, flags, mask):
         check(self.ctx.lib.adm_gd_step(self.ctx.handle, x.ptr, g.ptr - 4 * g_base, lo, hi, float(step_size), int(flags),
                                        mask.ptr if mask is not None else None))
@@ -88,7 +92,7 @@ class DataParallelObject(object):
 
     # gradient exchange + update ------------------------------------------------------------
     def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None):
-        """optimizer: 'adam' | 'gd'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict."""
+        """optimizer: 'adam' | 'gd' | 'momentum'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict."""
         R = self.comm.size
         if self.dist:
             self.comm.reduce_scatter_sum(self.t_grad, self.t_gshard)
@@ -102,6 +106,9 @@ class DataParallelObject(object):
                               options.get('eps', 1e-7), flags, mask)
             elif optimizer == 'gd':
                 self.ops.gd(self.obj, g, g_base, self.lo, self.hi, options['step_size'], flags, mask)
+            elif optimizer == 'momentum':
+                self.ops.momentum(self.obj, g, g_base, self.moments[0], self.lo, self.lo, self.hi, options.get('step_size', 0.001),
+                                  options.get('gamma', 0.9), flags, mask)
             else:
                 raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
         if self.dist:

@@ -22,9 +22,8 @@ class ForwardModel(object):
                  raw_data_type='magnitude', simulation_mode=False):
         if distribution_mode is not None:
             raise NotImplementedError("distribution_mode '%s' is outside the accelerated path (DP only)" % distribution_mode)
-        if loss_function_type != 'lsq':
-            raise NotImplementedError("loss_function_type '%s' is not implemented on the HIP path yet (SURVEY 8 f4)"
-                                      % loss_function_type)
+        if loss_function_type not in ('lsq', 'poisson'):
+            raise ValueError("loss_function_type must be 'lsq' or 'poisson'")
         if raw_data_type not in ('magnitude', 'intensity'):
             raise ValueError("raw_data_type must be 'magnitude' or 'intensity'")
         self.loss_function_type = loss_function_type
@@ -65,8 +64,12 @@ class ForwardModel(object):
         if ds_level not in (1, None):
             raise NotImplementedError('multiscale (ds_level > 1) is outside the accelerated path')
         t = np.abs(np.asarray(self.prj[int(this_i_theta) * theta_downsample, np.asarray(this_ind_batch)]))
-        if self.raw_data_type == 'intensity':
-            t = np.sqrt(t)
+        if self.loss_function_type == 'lsq':
+            if self.raw_data_type == 'intensity':
+                t = np.sqrt(t)
+        else:   # Poisson compares intensities (forward_model.py:94-102): |prj|^2 for magnitude data, |prj| for intensity data
+            if self.raw_data_type == 'magnitude':
+                t = t ** 2
         return np.ascontiguousarray(t, dtype=np.float32)
 
     def predict(self, *args, **kwargs):
@@ -152,8 +155,10 @@ class PtychographyModel(ForwardModel):
 
     def _regularize(self, obj, grad_obj):
         """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value."""
+        from .regularizers import ReweightedL1Regularizer
         ad, ab, gm = combined_weights(self.reg_list)
-        if ad == 0 and ab == 0 and gm == 0:
+        rw = [r for r in self.reg_list if isinstance(r, ReweightedL1Regularizer)]
+        if ad == 0 and ab == 0 and gm == 0 and not rw:
             return 0.0
         if self._reg_val is None:
             self._reg_val = self.device.zeros((1,))
@@ -163,7 +168,13 @@ class PtychographyModel(ForwardModel):
                 self._scratch_grad = self.device.empty((obj.size,))
             grad_obj = self._scratch_grad
         k = float(self.batch_group)     # every fused minibatch adds the regulariser once (forward_model.py:138-139)
-        check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, grad_obj.ptr, self._reg_val.ptr))
+        if ad != 0 or ab != 0 or gm != 0:
+            check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, grad_obj.ptr, self._reg_val.ptr))
+        for r in rw:
+            if r.weight_l1 is None:
+                raise RuntimeError('ReweightedL1Regularizer: update_l1_weight() has not been called')
+            check(self.device.lib.adm_reg_grad_weighted(self.engine.plan.handle, obj.ptr, r.weight_l1.ptr, float(r.alpha_d or 0.) * k,
+                                                        float(r.alpha_b or 0.) * k, grad_obj.ptr, self._reg_val.ptr))
         return float(self._reg_val.get()[0]) / k
 
     # ------------------------------------------------------------------ reference interface

@@ -107,6 +107,23 @@ class GDOptimizer(Optimizer):
         return x
 
 
+class MomentumOptimizer(Optimizer):
+    """adorym/optimizers.py:366-411: v = gamma*v + step*g; x = x - v."""
+
+    def __init__(self, name, output_folder='.', distribution_mode=None, options_dict=None, forward_model=None):
+        super(MomentumOptimizer, self).__init__(name, output_folder=output_folder, params_list=['v'],
+                                                distribution_mode=distribution_mode, options_dict=options_dict,
+                                                forward_model=forward_model)
+
+    def apply_gradient(self, x, gradient, i_batch, step_size=0.001, gamma=0.9, flags=0, mask=None, **kwargs):
+        g = self.convert_gradient(gradient)
+        v = self.params_whole_array_dict['v']
+        ctx = x.ctx
+        check(ctx.lib.adm_momentum_step(ctx.handle, x.ptr, g.ptr, v.ptr, 0, x.size, float(step_size), float(gamma), int(flags),
+                                        mask.ptr if mask is not None else None))
+        return x
+
+
 def _unsupported(name):
     class _U(Optimizer):
         def __init__(self, *a, **k):
@@ -115,7 +132,6 @@ def _unsupported(name):
     return _U
 
 
-MomentumOptimizer = _unsupported('MomentumOptimizer')
 CurveballOptimizer = _unsupported('CurveballOptimizer')
 CGOptimizer = _unsupported('CGOptimizer')
 ScipyOptimizer = _unsupported('ScipyOptimizer')

@@ -78,7 +78,7 @@ class MultisliceEngine(object):
 
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
-                 n_probe_modes=1, max_batch=None):
+                 n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1.):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -104,7 +104,10 @@ class MultisliceEngine(object):
                                 sign_convention=sign_convention)
         self.plan = Plan(ctx, self.obj_size, self.probe_size, pads, self.k1, kernel, binning=binning,
                          n_modes=n_probe_modes, sign_convention=sign_convention, det_mode=det,
-                         normalize_fft=normalize_fft, h_free=h_free)
+                         normalize_fft=normalize_fft, h_free=h_free,
+                         loss_type={'lsq': _lib.LOSS_LSQ, 'poisson': _lib.LOSS_POISSON}[loss_function_type],
+                         poisson_multiplier=poisson_multiplier)
+        self.loss_function_type = loss_function_type
         self.pads = pads
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
         self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
@@ -202,7 +205,7 @@ class MultisliceEngine(object):
         self._accumulated = True
 
     def loss(self, last=None):
-        """mean((pred - target)^2) over the batch (adorym/forward_model.py:91) -- blocks.
+        """mean of the per-pixel loss terms over the batch (adorym/forward_model.py:88-103) -- blocks.
         ``last=n``: over the last n positions only (the final minibatch of a fused 'per angle' group)."""
         B = self._B
         if self._accumulated:

@@ -31,7 +31,7 @@ from .device import Context
 from .differentiator import Differentiator
 from .dp import DataParallelObject, HipOps, constraint_flags
 from .forward_model import ForwardModel, PtychographyModel
-from .optimizers import Optimizer, AdamOptimizer, GDOptimizer
+from .optimizers import Optimizer, AdamOptimizer, GDOptimizer, MomentumOptimizer
 from .propagate import MultisliceEngine, RotationTable, get_kernel
 from .regularizers import L1Regularizer, TVRegularizer, ReweightedL1Regularizer
 from .util import rotation_lookup, split_tasks, initialize_probe
@@ -135,7 +135,6 @@ def reconstruct_ptychography(
     _not_implemented(use_epie, 'ePIE')
     _not_implemented(is_minus_logged, 'is_minus_logged')
     _not_implemented(beamstop is not None, 'beamstop')
-    _not_implemented(loss_function_type != 'lsq', "loss_function_type='%s'" % loss_function_type)
     _not_implemented(not common_probe_pos, 'common_probe_pos=False')
     _not_implemented(not shared_probe_among_angles, 'shared_probe_among_angles=False')
     _not_implemented(rescale_probe_intensity or probe_extra_defocus_cm is not None, 'probe rescaling / extra defocus')
@@ -233,7 +232,7 @@ def reconstruct_ptychography(
     engine = MultisliceEngine(ctx, this_obj_size, probe_size, probe_pos_int, energy_ev, psize_cm, free_prop_cm=free_prop_cm,
                               binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
                               normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
-                              max_batch=minibatch_size)
+                              max_batch=minibatch_size, loss_function_type=loss_function_type, poisson_multiplier=poisson_multiplier)
 
     # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
     # (the reference caches them as .npy files in ./arrsize_*; no files are written here)
@@ -258,21 +257,26 @@ def reconstruct_ptychography(
     elif optimizer == 'gd':
         opt = GDOptimizer('obj', output_folder=output_folder, distribution_mode=distribution_mode,
                           options_dict={'step_size': learning_rate, 'dynamic_rate': True, 'first_downrate_iteration': 20})
-    elif optimizer in ('curveball', 'cg', 'momentum', 'scipy'):
+    elif optimizer == 'momentum':
+        opt = MomentumOptimizer('obj', output_folder=output_folder, distribution_mode=distribution_mode,
+                                options_dict={'step_size': learning_rate})
+    elif optimizer in ('curveball', 'cg', 'scipy'):
         raise NotImplementedError("optimizer '%s' is outside the accelerated path" % optimizer)
     else:
         raise ValueError('Invalid optimizer type. Must be "gd" or "adam" or "cg" or "scipy".')
     opt.set_index_in_grad_return(0)
-    fused = type(opt) in (AdamOptimizer, GDOptimizer)
+    fused = type(opt) in (AdamOptimizer, GDOptimizer, MomentumOptimizer)
     _not_implemented(not fused and n_ranks > 1, 'user-defined object optimizers with more than one rank')
-    opt_kind = 'adam' if isinstance(opt, AdamOptimizer) else 'gd'
+    opt_kind = 'adam' if isinstance(opt, AdamOptimizer) else ('momentum' if isinstance(opt, MomentumOptimizer) else 'gd')
 
     # ---- object, gradient, moments (ptychography.py:492-576) --------------------------------------------
     ops = kwargs.pop('ops', None) or HipOps(ctx)
-    state = DataParallelObject(ops, comm, [*this_obj_size, 2], n_moments=2 if opt_kind == 'adam' else 0)
+    state = DataParallelObject(ops, comm, [*this_obj_size, 2], n_moments={'adam': 2, 'momentum': 1, 'gd': 0}[opt_kind])
     if fused:
         if opt_kind == 'adam':
             opt.params_whole_array_dict = {'m': state.moments[0], 'v': state.moments[1]}   # shard-sized under DP
+        elif opt_kind == 'momentum':
+            opt.params_whole_array_dict = {'v': state.moments[0]}
     else:
         opt.create_container([*this_obj_size, 2], use_checkpoint, ctx)
     obj = ObjectFunction([*this_obj_size, 2], distribution_mode=distribution_mode, output_folder=output_folder, ds_level=ds_level,
@@ -315,6 +319,12 @@ def reconstruct_ptychography(
         if gamma not in [0, None]:
             regularizers.append(TVRegularizer(gamma, unknown_type=unknown_type))
     forward_model.add_regularizers(regularizers)
+    reg_rwl1 = None
+    for r_ in regularizers:
+        if isinstance(r_, ReweightedL1Regularizer):
+            reg_rwl1 = r_
+            rwl1_weight = ctx.empty((*this_obj_size, 2))
+            rwl1_scratch = ctx.empty((2 * 1024 + 2,))
 
     mask = None
     if finite_support_mask_path is not None:
@@ -440,6 +450,12 @@ def reconstruct_ptychography(
                 this_ind_batch = np.concatenate(pending_ind)
                 this_pos_batch = probe_pos_int[this_ind_batch]
                 pending_ind = []
+
+            # ---- reweighted-L1 weights, refreshed every 10 minibatches (ptychography.py:995-1000) ----
+            if reg_rwl1 is not None:
+                if i_batch % 10 == 0:
+                    _lib.check(ctx.lib.adm_rwl1_update(engine.plan.handle, obj.arr.ptr, rwl1_weight.ptr, rwl1_scratch.ptr))
+                reg_rwl1.update_l1_weight(rwl1_weight)
 
             # ---- gradients (ptychography.py:1017-1066) ----
             t_grad_0 = time.time()

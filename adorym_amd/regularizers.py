@@ -40,10 +40,17 @@ class TVRegularizer(Regularizer):
 
 
 class ReweightedL1Regularizer(Regularizer):
-    """adorym/regularizers.py:49-84 -- SURVEY section 8 row f4 ("next"), not accelerated yet."""
+    """alpha_d*mean(w_d|delta|) + alpha_b*mean(w_b|beta|) with weights refreshed by the driver
+    (adorym/regularizers.py:49-84, adorym/ptychography.py:995-1000).  ``weight_l1`` is a device array [Y,X,Z,2]."""
 
     def __init__(self, alpha_d, alpha_b, unknown_type='delta_beta'):
-        raise NotImplementedError('ReweightedL1Regularizer is not implemented on the HIP path yet')
+        super(ReweightedL1Regularizer, self).__init__(unknown_type)
+        self.alpha_d = alpha_d
+        self.alpha_b = alpha_b
+        self.weight_l1 = None
+
+    def update_l1_weight(self, weight_l1):
+        self.weight_l1 = weight_l1
 
 
 class CorrRegularizer(Regularizer):
@@ -59,6 +66,8 @@ class GradCorrRegularizer(Regularizer):
 def combined_weights(reg_list):
     ad = ab = gm = 0.
     for r in reg_list:
+        if isinstance(r, ReweightedL1Regularizer):
+            continue
         a, b, g = r.weights()
         ad += a; ab += b; gm += g
     return ad, ab, gm

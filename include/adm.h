@@ -75,6 +75,7 @@ int adm_event_elapsed_ms(adm_ctx* ctx, void* ev_start, void* ev_stop, float* ms)
 
 /* ---- plan: static geometry + physics of one reconstruction ------------------------- */
 typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;
+typedef enum { ADM_LOSS_LSQ = 0, ADM_LOSS_POISSON = 1 } adm_loss_type;
 
 typedef struct {
     int32_t obj_y, obj_x, obj_z;      /* object [Y, X, Z, 2] (delta, beta interleaved, z fastest)    */
@@ -91,6 +92,8 @@ typedef struct {
     const float* h_im;                /*   unshifted, = get_kernel() cast to fp32 (propagate.py:62-81, 202-204) */
     const float* hfree_re;            /* host, detector-plane Fresnel kernel for ADM_DET_FRESNEL      */
     const float* hfree_im;            /*   (adorym/propagate.py:537-553), else NULL                   */
+    int32_t loss_type;                /* adm_loss_type: LSQ on magnitudes, or Poisson (adorym/forward_model.py:88-103) */
+    float   poisson_multiplier;       /* forward_model.py:94-102; ignored for LSQ                     */
 } adm_plan_desc;
 
 int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out);
@@ -130,13 +133,14 @@ int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr
  * probe     device [n_modes][Py][Px][2] (real, imag interleaved)
  * pos       device int32 [batch][2] = (y, x) top-left corner of each tile in OBJECT coordinates
  *           (may be negative / overhang: the pads cover it)
- * target    device [batch][Py][Px] target magnitude abs(prj) (sqrt(abs(prj)) for intensity data),
- *           in the reference's fftshift-ed detector layout
+ * target    device [batch][Py][Px], in the reference's fftshift-ed detector layout.  LSQ: target magnitude abs(prj)
+ *           (sqrt(abs(prj)) for intensity data).  Poisson: abs(prj)^2 for magnitude data, abs(prj) for intensity data.
  * want_grad 0 = forward / loss only (predict); 1 = also run the adjoint sweep, leaving one tile gradient per
  *           position in `workspace` for adm_tile_grad_accumulate
  * grad_probe device [n_modes][Py][Px][2], accumulated into; may be NULL
  * pred      device [batch][Py][Px] predicted magnitude (reference layout); may be NULL
- * loss_sum  device [batch] : per-position sum over pixels of (pred-target)^2 (overwritten)
+ * loss_sum  device [batch] : per-position sum over pixels of (pred-target)^2, or of the Poisson terms
+ *           pred^2*pm - target*pm*log(pred^2*pm) (overwritten)
  * grad_scale multiplies d loss/d pred: 2/(batch*Py*Px) for the reference's mean()
  * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when want_grad==0) */
 int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
@@ -176,6 +180,15 @@ int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, si
 /* GDOptimizer.apply_gradient (adorym/optimizers.py:440-464); step_size already scheduled by the host */
 int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, double step_size, int flags,
                 const float* mask);
+/* MomentumOptimizer.apply_gradient (adorym/optimizers.py:376-411): v = gamma*v + step*g; x = x - v; + constraints */
+int adm_momentum_step(adm_ctx* ctx, float* x, const float* g, float* v, size_t lo, size_t hi, double step_size, double gamma,
+                      int flags, const float* mask);
+/* Reweighted L1 (adorym/regularizers.py:49-84).  adm_rwl1_update: weight = max(obj) / (|obj| + 1e-4*mean(obj)) over both
+ * channels jointly (adorym/ptychography.py:995-1000); scratch = device float[2*1024+2].  adm_reg_grad_weighted:
+ * grad_obj += alpha_c * weight * sign(obj) / V, reg_value += alpha_d*mean(w_d|delta|) + alpha_b*mean(w_b|beta|). */
+int adm_rwl1_update(adm_plan* plan, const float* obj, float* weight, float* scratch);
+int adm_reg_grad_weighted(adm_plan* plan, const float* obj, const float* weight, float alpha_d, float alpha_b, float* grad_obj,
+                          float* reg_value);
 /* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
 int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);
 

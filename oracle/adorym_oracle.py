@@ -500,6 +500,32 @@ def adam_step(x, g, m, v, i_batch, step_size=0.001, b1=0.9, b2=0.999, eps=1e-7):
     return (x - d).astype(x.dtype), m.astype(x.dtype), v.astype(x.dtype)
 
 
+def momentum_step(x, g, v, step_size=0.001, gamma=0.9):
+    """MomentumOptimizer.apply_gradient (optimizers.py:376-411): v = gamma*v + step*g; x = x - v."""
+    dt = x.dtype.type
+    v = dt(gamma) * v + dt(step_size) * g
+    return (x - v).astype(x.dtype), v.astype(x.dtype)
+
+
+def reweighted_l1_weight(obj):
+    """ptychography.py:995-1000 (DP branch): max(obj) / (|obj| + 1e-4 * mean(obj)), over both channels jointly."""
+    return obj.max() / (np.abs(obj) + 1e-4 * obj.mean())
+
+
+def reweighted_l1_value_grad(obj, weight, alpha_d, alpha_b):
+    """ReweightedL1Regularizer.get_value (regularizers.py:64-71), weights are constants (no_grad)."""
+    V = obj[..., 0].size
+    val = 0.
+    g = np.zeros_like(obj)
+    if alpha_d not in (None, 0):
+        val += alpha_d * np.mean(weight[..., 0] * np.abs(obj[..., 0]))
+        g[..., 0] = alpha_d * weight[..., 0] * np.sign(obj[..., 0]) / V
+    if alpha_b not in (None, 0):
+        val += alpha_b * np.mean(weight[..., 1] * np.abs(obj[..., 1]))
+        g[..., 1] = alpha_b * weight[..., 1] * np.sign(obj[..., 1]) / V
+    return val, g
+
+
 def gd_step_size(i_batch, step_size, dynamic_rate=True, first_downrate_iteration=92):
     """GDOptimizer.apply_gradient schedule (optimizers.py:452-460)."""
     if dynamic_rate:

@@ -364,8 +364,66 @@ def gen_f8():
     save('F8_tasks', **out)
 
 
+# ----------------------------------------------------------------------------- F9 (next-row f4 variants)
+def gen_f9():
+    """Poisson loss (forward_model.py:94-102), Momentum optimizer (optimizers.py:366-411), reweighted L1
+    (regularizers.py:49-84 + weight update ptychography.py:995-1000)."""
+    out = {}
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = np.load(os.path.join(HERE, 'F23_' + name + '.npz'))['meas']
+    for rdt in ('magnitude', 'intensity'):
+        for pm in (1.0, 50.0):
+            for fp64 in (True, False):
+                t, prs, pis, fields, pred = ref_case(c, c['guess'], fp64)
+                fm = adorym.ForwardModel(loss_function_type='poisson', raw_data_type=rdt)
+                fm.poisson_multiplier = pm
+                m_t = torch.tensor(meas if rdt == 'magnitude' else meas ** 2, dtype=pred.dtype)
+                loss = fm.get_mismatch_loss(pred, m_t)
+                g = torch.autograd.grad(loss, [t] + prs + pis)
+                tag = '%s_pm%d_%s' % (rdt, int(pm), '64' if fp64 else '32')
+                out['poisson_loss_' + tag] = np.array(loss.item())
+                out['poisson_grad_tiles_' + tag] = g[0].numpy()
+                out['poisson_grad_probe_real_' + tag] = g[1].numpy()
+                out['poisson_grad_probe_imag_' + tag] = g[2].numpy()
+    gs.run_fp64 = False
+    # momentum
+    r = cases.rng(9)
+    shape = (5, 4, 3, 2)
+    x0 = r.standard_normal(shape) * 1e-3
+    gseq = r.standard_normal((3,) + shape)
+    out['mom_x0'] = x0; out['mom_gseq'] = gseq
+    for fp64 in (True, False):
+        gs.run_fp64 = fp64
+        dt = torch.float64 if fp64 else torch.float32
+        opt = adorym.MomentumOptimizer('obj', options_dict={})
+        opt.create_container(list(shape), False, None)
+        x = torch.tensor(x0, dtype=dt)
+        xs = []
+        for k in range(3):
+            x = opt.apply_gradient(x, torch.tensor(gseq[k], dtype=dt), k, step_size=1e-3, gamma=0.9)
+            xs.append(x.numpy().copy())
+        out['mom_x_' + ('64' if fp64 else '32')] = np.stack(xs)
+        out['mom_v_' + ('64' if fp64 else '32')] = opt.params_whole_array_dict['v'].numpy().copy()
+    # reweighted L1
+    gs.run_fp64 = True
+    obj = np.abs(r.standard_normal((6, 6, 6, 2))) * 1e-3 + 1e-5
+    o = torch.tensor(obj, dtype=torch.float64, requires_grad=True)
+    with torch.no_grad():
+        wgt = w.max(o) / (w.abs(o) + 1e-4 * w.mean(o))
+    reg = adorym.ReweightedL1Regularizer(alpha_d=0.8, alpha_b=0.3)
+    reg.update_l1_weight(wgt)
+    val = reg.get_value(o)
+    out['rwl1_obj'] = obj
+    out['rwl1_weight'] = wgt.numpy()
+    out['rwl1_val'] = np.array(val.item())
+    out['rwl1_grad'] = torch.autograd.grad(val, [o])[0].numpy()
+    gs.run_fp64 = False
+    save('F9_variants', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8']
+    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -373,3 +431,4 @@ if __name__ == '__main__':
     if 'f7' in which: gen_f7()
     if 'f8' in which: gen_f8()
     if 'f6' in which: gen_f6()
+    if 'f9' in which: gen_f9()

@@ -78,6 +78,18 @@ def test_probe_optimisation_runs_and_reduces_loss(tmp_path):
 
 def test_unsupported_options_raise(tmp_path):
     for bad in (dict(distribution_mode='shared_file'), dict(unknown_type='real_imag'), dict(optimizer='cg'),
-                dict(optimize_all_probe_pos=True), dict(loss_function_type='poisson'), dict(cpu_only=True)):
+                dict(optimize_all_probe_pos=True), dict(n_probe_modes=3), dict(cpu_only=True)):
         with pytest.raises(NotImplementedError):
             run(tmp_path, n_epochs=1, **bad)
+
+
+def test_driver_variants_run(tmp_path):
+    """Poisson loss, Momentum optimiser and reweighted L1 through the driver (each pinned at kernel level against the
+    reference in test_gpu_parity.py): finite results and a decreasing loss."""
+    for extra in (dict(loss_function_type='poisson', optimizer='adam', learning_rate=1e-6),
+                  dict(optimizer='momentum', learning_rate=1e-10),
+                  dict(optimizer='adam', learning_rate=1e-6, alpha_d=1e-4, alpha_b=1e-5, reweighted_l1=True)):
+        g, inp, st = run(tmp_path, n_epochs=2, **extra)
+        assert np.all(np.isfinite(st['delta'])) and np.all(np.isfinite(st['beta']))
+        l = np.array(st['losses'])
+        assert np.all(np.isfinite(l)) and l[len(l) // 2:].mean() < l[:len(l) // 2].mean(), extra

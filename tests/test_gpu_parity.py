@@ -306,3 +306,60 @@ def test_c3_shape_energy_conservation(A, ctx):
     assert np.all(np.isfinite(gg)) and np.abs(gg).max() > 0
     # beta-gradient identity for target = 0 : dL/dbeta_s summed over a tile = -2*k1*mean-energy ... (sign check)
     assert gg[..., 1].sum() < 0
+
+
+# --------------------------------------------------------------------------- F9: Poisson, Momentum, reweighted L1
+@pytest.mark.parametrize('rdt', ['magnitude', 'intensity'])
+@pytest.mark.parametrize('pm', [1.0, 50.0])
+def test_poisson_loss_vs_reference(A, ctx, rdt, pm):
+    g = load('F9_variants')
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = load('F23_' + name)['meas']
+    P, S, B = c['P'], c['S'], cases.TILE_B
+    obj = c['guess'].reshape(B * P, P, S, 2)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, loss_function_type='poisson',
+                             poisson_multiplier=pm)
+    d_grad = ctx.zeros(obj.shape)
+    d_gp = ctx.zeros((P, P, 2))
+    target = meas ** 2            # Poisson target is the measured INTENSITY for both raw data types
+    eng.set_batch(pos, target)
+    eng.rotate(ctx.array(obj, np.float32), None)
+    eng.multislice(ctx.array(c2(c['probes'][0])), grad_probe=d_gp)
+    eng.rotate_adjoint(d_grad, None)
+    tag = '%s_pm%d_' % (rdt, int(pm))
+    assert abs(eng.loss() - g['poisson_loss_' + tag + '64']) <= 2e-5 * abs(g['poisson_loss_' + tag + '64'])
+    e = rel(d_grad.get().reshape(B, P, P, S, 2), g['poisson_grad_tiles_' + tag + '64'])
+    e_ref = rel(g['poisson_grad_tiles_' + tag + '32'], g['poisson_grad_tiles_' + tag + '64'])
+    assert e < 1e-4 and e <= 3 * e_ref + 1e-5, (e, e_ref)
+    gp64 = np.stack([g['poisson_grad_probe_real_' + tag + '64'], g['poisson_grad_probe_imag_' + tag + '64']], -1)
+    assert rel(d_gp.get(), gp64) < 1e-4
+
+
+def test_momentum_vs_reference(A, ctx):
+    g = load('F9_variants')
+    opt = A.MomentumOptimizer('obj', options_dict={})
+    opt.create_container(g['mom_x0'].shape, False, ctx)
+    x = ctx.array(g['mom_x0'], np.float32)
+    for k in range(3):
+        x = opt.apply_gradient(x, ctx.array(g['mom_gseq'][k], np.float32), k, step_size=1e-3, gamma=0.9)
+        assert rel(x.get(), g['mom_x_32'][k]) < 2e-6
+    assert rel(opt.params_whole_array_dict['v'].get(), g['mom_v_32']) < 2e-6
+
+
+def test_reweighted_l1_vs_reference(A, ctx):
+    from adorym_amd._lib import check
+    g = load('F9_variants')
+    obj = g['rwl1_obj']
+    eng = A.MultisliceEngine(ctx, obj.shape[:3], (12, 12), np.array([(0, 0)]), 5000., 1e-7)
+    d_obj = ctx.array(obj, np.float32)
+    d_w = ctx.empty(obj.shape)
+    d_s = ctx.empty((2 * 1024 + 2,))
+    check(ctx.lib.adm_rwl1_update(eng.plan.handle, d_obj.ptr, d_w.ptr, d_s.ptr))
+    assert rel(d_w.get(), g['rwl1_weight']) < 2e-6
+    d_g = ctx.zeros(obj.shape)
+    d_v = ctx.zeros((1,))
+    check(ctx.lib.adm_reg_grad_weighted(eng.plan.handle, d_obj.ptr, d_w.ptr, 0.8, 0.3, d_g.ptr, d_v.ptr))
+    assert rel(d_g.get(), g['rwl1_grad']) < 2e-6
+    assert abs(d_v.get()[0] - g['rwl1_val']) <= 1e-5 * abs(g['rwl1_val'])

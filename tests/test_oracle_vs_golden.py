@@ -232,3 +232,39 @@ def test_f6_end_to_end_fp32_within_3x_reference():
     e_us = np.linalg.norm(obj - x64)
     assert np.sqrt(np.mean((obj - x64) ** 2)) < 1e-5
     assert e_us <= 3 * e_ref + 1e-12, (e_us, e_ref)
+
+
+# ------------------------------------------------------------------ F9 (variants: Poisson, Momentum, reweighted L1)
+@pytest.mark.parametrize('rdt', ['magnitude', 'intensity'])
+@pytest.mark.parametrize('pm', [1.0, 50.0])
+def test_f9_poisson_loss_and_gradient(rdt, pm):
+    g = load('F9_variants')
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = load('F23_' + name)['meas']
+    data = meas if rdt == 'magnitude' else meas ** 2
+    loss, pred, gt, gp = O.forward_adjoint_tiles(c['guess'], c['probes'], data, _phys(c), 'float64', loss_function_type='poisson',
+                                                 raw_data_type=rdt, poisson_multiplier=pm)
+    tag = '%s_pm%d_64' % (rdt, int(pm))
+    assert abs(loss - g['poisson_loss_' + tag]) <= 1e-12 * abs(g['poisson_loss_' + tag])
+    assert rel(gt, g['poisson_grad_tiles_' + tag]) < 1e-11
+    assert rel(gp[0].real, g['poisson_grad_probe_real_' + tag]) < 1e-11
+    assert rel(gp[0].imag, g['poisson_grad_probe_imag_' + tag]) < 1e-11
+
+
+def test_f9_momentum():
+    g = load('F9_variants')
+    for tag, dt, tol in (('64', np.float64, 1e-13), ('32', np.float32, 2e-6)):
+        x = g['mom_x0'].astype(dt); v = np.zeros_like(x)
+        for k in range(3):
+            x, v = O.momentum_step(x, g['mom_gseq'][k].astype(dt), v, 1e-3, 0.9)
+            assert rel(x, g['mom_x_' + tag][k]) < tol
+        assert rel(v, g['mom_v_' + tag]) < tol
+
+
+def test_f9_reweighted_l1():
+    g = load('F9_variants')
+    wgt = O.reweighted_l1_weight(g['rwl1_obj'])
+    assert rel(wgt, g['rwl1_weight']) < 1e-13
+    val, grad = O.reweighted_l1_value_grad(g['rwl1_obj'], wgt, 0.8, 0.3)
+    assert abs(val - g['rwl1_val']) < 1e-13 * abs(g['rwl1_val']) and rel(grad, g['rwl1_grad']) < 1e-12
