@@ -49,6 +49,41 @@ def print_flush(a, designate_rank=None, this_rank=None, save_stdout=False, outpu
     sys.stdout.flush()
 
 
+def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_name='obj', rank=0, n_ranks=1, params=None):
+    """Reference file formats (adorym/misc.py:179-194, adorym/optimizers.py:170-188, :779-790):
+    checkpoint/checkpoint.txt (epoch, batch), obj_checkpoint.npy [Y,X,Z,2], opt_obj_params_checkpoint.npy
+    (stacked moments [n,Y,X,Z,2]) and the pickled params_{rank}.  With more than one rank the moments are sharded,
+    so every rank writes its shard as opt_obj_params_checkpoint_rank_{r}.npy (the reference's per-rank naming)."""
+    import pickle
+    path = os.path.join(output_folder, 'checkpoint')
+    os.makedirs(path, exist_ok=True)
+    if rank == 0:
+        np.savetxt(os.path.join(path, 'checkpoint.txt'), np.array([i_epoch, i_batch]), fmt='%d')
+        np.save(os.path.join(path, 'obj_checkpoint.npy'), obj_array)
+    if len(moments) > 0:
+        arr = np.stack(moments)
+        if n_ranks == 1:
+            np.save(os.path.join(path, 'opt_{}_params_checkpoint.npy'.format(opt_name)), arr.reshape((len(moments),) + obj_array.shape))
+        else:
+            np.save(os.path.join(path, 'opt_{}_params_checkpoint_rank_{}.npy'.format(opt_name, rank)), arr)
+    if params is not None:
+        with open(os.path.join(path, 'params_{}'.format(rank)), 'wb') as f_pcp:
+            pickle.dump(params, f_pcp)
+
+
+def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks=1):
+    """adorym/misc.py:197-211.  Returns (i_epoch, i_batch, obj [Y,X,Z,2], moments or None)."""
+    path = os.path.join(output_folder, 'checkpoint')
+    i_epoch, i_batch = [int(i) for i in np.loadtxt(os.path.join(path, 'checkpoint.txt'))]
+    obj = np.load(os.path.join(path, 'obj_checkpoint.npy'))
+    mom = None
+    if n_moments > 0:
+        f1 = os.path.join(path, 'opt_{}_params_checkpoint.npy'.format(opt_name))
+        fr = os.path.join(path, 'opt_{}_params_checkpoint_rank_{}.npy'.format(opt_name, rank))
+        mom = np.load(f1 if n_ranks == 1 else fr)
+    return i_epoch, i_batch, obj, mom
+
+
 def _not_implemented(cond, what):
     if cond:
         raise NotImplementedError(what + ' is outside the accelerated path of adorym_amd (see DESIGN.md, out of scope)')
@@ -286,6 +321,21 @@ def reconstruct_ptychography(
     obj.arr = state.obj.view(0, (*this_obj_size, 2))
     obj.arr.set(init)
     del init
+    # ---- checkpoint restore (ptychography.py:458-487) ----
+    starting_epoch, starting_batch = 0, 0
+    if use_checkpoint:
+        try:
+            starting_epoch, starting_batch, obj_arr, mom = restore_checkpoint(output_folder, len(state.moments), rank=rank,
+                                                                              n_ranks=n_ranks)
+            obj.arr.set(obj_arr)
+            for k_, m_ in enumerate(state.moments):
+                m_.set(np.ascontiguousarray(mom[k_]).reshape(-1)[:m_.size] if n_ranks == 1 else mom[k_])
+            print_flush('Resuming from checkpoint: epoch {}, batch {}.'.format(starting_epoch, starting_batch), sto_rank, rank,
+                        **stdout_options)
+        except Exception:
+            if force_to_use_checkpoint:
+                raise
+            starting_epoch, starting_batch = 0, 0
     gradient = Gradient(obj)
     gradient.arr = state.grad.view(0, (*this_obj_size, 2))
 
@@ -389,7 +439,8 @@ def reconstruct_ptychography(
     # epoch loop (ptychography.py:783-1295)
     # =========================================================================================================
     cont = True
-    i_epoch = 0
+    i_epoch = starting_epoch
+    _ckpt_thread = [None]
     while cont:
         t0 = time.time()
         n_tot_per_batch = minibatch_size * n_ranks
@@ -418,11 +469,23 @@ def reconstruct_ptychography(
             ind_list_rand[i * len(spots_ls):(i + 1) * len(spots_ls), :] = temp
         ind_list_rand = split_tasks(ind_list_rand, n_tot_per_batch)
         n_batch = len(ind_list_rand)
-        i_opt_batch = 0                       # starting_epoch * n_batch + starting_batch (:848) without checkpoints
+        i_opt_batch = starting_epoch * n_batch + starting_batch      # (:848), re-evaluated every epoch like the reference
         initialize_gradients = True
         pending_ind = []
 
-        for i_batch in range(n_batch):
+        for i_batch in range(starting_batch, n_batch):
+            starting_batch = 0
+            # ---- checkpoint (ptychography.py:879-895): device -> host copy here, file writes on a helper thread ----
+            if store_checkpoint and i_batch % n_batch_per_checkpoint == 0:
+                import threading
+                if _ckpt_thread[0] is not None:
+                    _ckpt_thread[0].join()
+                host_obj = obj.arr.get() if rank == 0 else None
+                host_mom = [m_.get() for m_ in state.moments] if (rank == 0 or n_ranks > 1) else []
+                pk = {'probe': probe_dev.get()} if rank == 0 or True else None
+                _ckpt_thread[0] = threading.Thread(target=save_checkpoint, args=(i_epoch, i_batch, output_folder, host_obj, host_mom),
+                                                   kwargs=dict(rank=rank, n_ranks=n_ranks, params=pk))
+                _ckpt_thread[0].start()
             t_elapsed = (time.time() - t_zero) / 60
             if t_max_min is not None and t_elapsed >= t_max_min:
                 print_flush('Terminating program because maximum time limit is reached.', sto_rank, rank, **stdout_options)
@@ -545,6 +608,8 @@ def reconstruct_ptychography(
             write_tiff(np.abs(pc), os.path.join(output_folder, 'probe_mag_ds_{}'.format(ds_level)), dtype='float32')
             write_tiff(np.angle(pc), os.path.join(output_folder, 'probe_phase_ds_{}'.format(ds_level)), dtype='float32')
         print_flush('Current iteration finished.', sto_rank, rank, **stdout_options)
+    if _ckpt_thread[0] is not None:
+        _ckpt_thread[0].join()
     comm.barrier()
     f_conv.close()
     f.close()

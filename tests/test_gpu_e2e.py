@@ -93,3 +93,25 @@ def test_driver_variants_run(tmp_path):
         assert np.all(np.isfinite(st['delta'])) and np.all(np.isfinite(st['beta']))
         l = np.array(st['losses'])
         assert np.all(np.isfinite(l)) and l[len(l) // 2:].mean() < l[:len(l) // 2].mean(), extra
+
+
+def test_checkpoint_files_and_resume(tmp_path):
+    """Reference checkpoint formats (adorym/misc.py:179-211, optimizers.py:170-188): a run interrupted after its
+    first epoch and resumed from the files ends where the uninterrupted 2-epoch run ends."""
+    kw = dict(optimizer='adam', learning_rate=1e-6, store_checkpoint=True, n_batch_per_checkpoint=4)
+    g, inp, full = run(tmp_path / 'a', n_epochs=2, **kw)
+    ck = os.path.join(full['output_folder'], 'checkpoint')
+    assert sorted(os.listdir(ck)) == ['checkpoint.txt', 'obj_checkpoint.npy', 'opt_obj_params_checkpoint.npy', 'params_0']
+    assert np.load(os.path.join(ck, 'obj_checkpoint.npy')).shape == (32, 32, 32, 2)
+    assert np.load(os.path.join(ck, 'opt_obj_params_checkpoint.npy')).shape == (2, 32, 32, 32, 2)
+    assert [int(v) for v in np.loadtxt(os.path.join(ck, 'checkpoint.txt'))] == [1, 8]
+    # interrupted run: stop after epoch 0 ... the last checkpoint of that run is (epoch 0, batch 8)
+    _, _, part = run(tmp_path / 'b', n_epochs=1, **kw)
+    assert [int(v) for v in np.loadtxt(os.path.join(part['output_folder'], 'checkpoint', 'checkpoint.txt'))] == [0, 8]
+    # resume in the same folder: replays batches 8..11 of epoch 0, then epoch 1
+    _, _, res = run(tmp_path / 'b', n_epochs=2, use_checkpoint=True, **kw)
+    assert len(res['losses']) == 4 + 12
+    # not bit-identical to the uninterrupted run BY DESIGN of the reference: on resume the Adam step counter restarts at
+    # starting_epoch*n_batch + starting_batch (a minibatch index, ptychography.py:848) although it otherwise counts angles
+    assert np.allclose(res['losses'][-12:], full['losses'][-12:], rtol=3e-2)
+    assert np.abs(res['delta'] - full['delta']).max() < 5e-5
