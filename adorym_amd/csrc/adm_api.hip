@@ -200,7 +200,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
         return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: non-square probes are not implemented yet");
     if (ms_threads_for(d.probe_x) == 0)
         return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size not in the compiled set {12,16,32,64,72}");
-    if (d.n_modes != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: n_probe_modes > 1 is not implemented yet");
+    if (d.n_modes < 1 || d.n_modes > 64) return fail(ADM_ERR_INVALID, "adm_plan_create: n_modes must be in [1, 64]");
     if (d.pad_y0 + d.obj_y + d.pad_y1 < d.probe_y || d.pad_x0 + d.obj_x + d.pad_x1 < d.probe_x)
         return fail(ADM_ERR_INVALID, "adm_plan_create: padded object smaller than the probe");
     ADM_HIP(hipSetDevice(ctx->device));
@@ -249,10 +249,23 @@ extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
 
 extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
     if (!plan || batch <= 0) return 0;
-    // [stash | tile gradients | cover lists (Yp*Xp*(1+64) u32) | overflow flag]
-    const size_t per = (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x) * sizeof(float2);
-    return 2 * (size_t)batch * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64;
+    // [stash: B*M*per | tile gradients: B*per | cover lists (Yp*Xp*(1+64) u32) + overflow flag | detector fields: B*M*G*NT]
+    const size_t per = adm::ms_ws_per_pos(plan) * sizeof(float2);
+    const int N = plan->d.probe_x;
+    const int G = ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N);
+    const size_t det = plan->d.n_modes > 1 ? (size_t)batch * plan->d.n_modes * G * ms_threads_for(N) * sizeof(float2) : 0;
+    return (size_t)batch * (plan->d.n_modes + 1) * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64 + det;
 }
+
+namespace adm {
+size_t ms_ws_per_pos(const adm_plan* plan) {
+    return (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x);
+}
+// byte offsets of the workspace sections
+size_t ws_off_gtile(const adm_plan* plan, int batch) { return (size_t)batch * plan->d.n_modes * ms_ws_per_pos(plan) * sizeof(float2); }
+size_t ws_off_cover(const adm_plan* plan, int batch) { return ws_off_gtile(plan, batch) + (size_t)batch * ms_ws_per_pos(plan) * sizeof(float2); }
+size_t ws_off_det(const adm_plan* plan, int batch) { return ws_off_cover(plan, batch) + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64; }
+}  // namespace adm
 
 extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
                                       const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
@@ -276,7 +289,11 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
     p.pred = pred;
     p.loss_sum = loss_sum;
     p.stash = (float2*)workspace;
-    p.gtile = (float2*)workspace + (size_t)batch * plan->n_steps * ms_r1_for(d.probe_x) * ms_threads_for(d.probe_x);
+    p.gtile = workspace ? (float2*)((char*)workspace + ws_off_gtile(plan, batch)) : nullptr;
+    p.det = workspace ? (float2*)((char*)workspace + ws_off_det(plan, batch)) : nullptr;
+    p.n_modes = d.n_modes;
+    if (d.n_modes > 1 && (!workspace || workspace_bytes < adm_plan_workspace_bytes(plan, batch)))
+        return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: several probe modes need the workspace even for want_grad = 0");
     p.h = plan->h_dev;
     p.hfree = plan->hfree_dev;
     p.twid = plan->twid_dev;

@@ -54,11 +54,17 @@ struct MsParams {
     float det_scale;               // far-field scale: 1, 1/N^2, or 1/N (ortho)
     float k1, sigma;
     float grad_scale;
+    int n_modes;               // incoherent probe modes
+    float2* det;               // [B][n_modes][G][NT] detector-plane fields of the modes (n_modes > 1 only)
     int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
     float poisson_mult;
 };
 int ms_threads_for(int n);
 int ms_r2_for(int n);
+size_t ms_ws_per_pos(const adm_plan* plan);   // float2 elements of one position's stash of ONE mode
+size_t ws_off_gtile(const adm_plan* plan, int batch);
+size_t ws_off_cover(const adm_plan* plan, int batch);
+size_t ws_off_det(const adm_plan* plan, int batch);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 }  // namespace adm

@@ -312,6 +312,51 @@ __device__ __forceinline__ cf modulator(float2 db, float k1, float sigma) {
     return make_float2(e * cs, e * sn);
 }
 
+// ---- building blocks of the kernel body -------------------------------------------------------------------------
+__device__ __forceinline__ float loss_term_nz(float mag, float t, const MsParams& p, float& g) {
+    // multi-mode variant: pred = sqrt(sum_m |Psi_m|^2); like the reference there is no guard at pred = 0
+    if (p.loss_type == 0) {
+        const float diff = mag - t;
+        g = p.grad_scale * diff / mag;
+        return diff * diff;
+    }
+    const float inten = mag * mag;
+    g = p.grad_scale * p.poisson_mult * (1.f - t / inten);
+    return inten * p.poisson_mult - t * p.poisson_mult * logf(inten * p.poisson_mult);
+}
+
+template <int N, int R1, int R2>
+__device__ __forceinline__ void load_probe(const Ctx<N, R1, R2>& c, cf (&a)[R1], const float2* __restrict__ probe) {
+#pragma unroll
+    for (int k = 0; k < R1; ++k) a[k] = c.act1 ? probe[c.line * N + k * R2 + c.t] : make_float2(0.f, 0.f);
+}
+
+template <int N, int R1, int R2>
+__device__ __forceinline__ void add_probe_grad(const Ctx<N, R1, R2>& c, const cf (&a)[R1], float2* grad_probe) {
+    if (grad_probe && c.act1) {
+#pragma unroll
+        for (int k = 0; k < R1; ++k) {
+            float* gp = reinterpret_cast<float*>(grad_probe + c.line * N + k * R2 + c.t);
+            atomicAdd(gp, a[k].x);
+            atomicAdd(gp + 1, a[k].y);
+        }
+    }
+}
+
+template <int N, int R1, int R2>
+__device__ __forceinline__ void block_loss(float lsum, float* red, float* out, int tid, int wave, int lane) {
+    using GE = Geo<N, R1, R2>;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < GE::NWAVES; ++w) s += red[w];
+        *out = s;
+    }
+}
+
 // sum of the (delta, beta) pairs of the slices of one modulation step for this thread's R1 pixels.
 // BIN1 (binning == 1): pure loads, so the caller can issue them one step ahead and let the
 // propagation hide their latency.
@@ -340,6 +385,137 @@ __device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restri
 }
 
 template <int N, int R1, int R2, bool BIN1>
+__device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, float2* stash,
+                                          const float2* tile_base, size_t slice_stride, bool do_grad) {
+    using GE = Geo<N, R1, R2>;
+#ifdef ADM_H_IN_LDS
+    constexpr bool kHLds = true;
+#else
+    constexpr bool kHLds = false;
+#endif
+    float2 db[R1];
+    if (c.act1) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, 0, p.binning, p.Z);
+    for (int step = 0; step < p.n_steps; ++step) {
+        if (c.act1) {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+#ifndef ADM_ABL_NOMOD
+                a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
+#else
+                a[k] = cmul(a[k], db[k]);
+#endif
+#ifndef ADM_ABL_NOSTASH
+                if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
+#endif
+            }
+            // next step's tile slice is requested before the propagation so its latency is hidden
+            if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
+        }
+#ifndef ADM_ABL_NOCONV
+        if (step < p.n_steps - 1) convolve<N, R1, R2, false, kHLds>(c, a, hs);
+#endif
+    }
+}
+
+// ACC: add to the tile gradient already stored by a previous probe mode instead of overwriting it
+template <int N, int R1, int R2, bool BIN1, bool ACC>
+__device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, const float2* stash,
+                                          float2* gtile, const float2* tile_base, size_t slice_stride) {
+    using GE = Geo<N, R1, R2>;
+#ifdef ADM_H_IN_LDS
+    constexpr bool kHLds = true;
+#else
+    constexpr bool kHLds = false;
+#endif
+    const float sk1 = p.sigma * p.k1;
+    float2 db[R1];
+    cf psi[R1];
+    if (c.act1) {
+        load_db<R1, R2, BIN1>(db, tile_base, slice_stride, p.n_steps - 1, p.binning, p.Z);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((p.n_steps - 1) * R1 + k) * GE::NT];
+    }
+    for (int step = p.n_steps - 1; step >= 0; --step) {
+        if (c.act1) {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                // z = conj(G) * psi'
+                const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
+                const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
+                float gd = sk1 * zi;
+                float gb = -p.k1 * zr;
+                // tile gradient of this modulation step, thread-native layout (coalesced 8-B/lane store);
+                // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
+                float2* gq = gtile + (size_t)(step * R1 + k) * GE::NT;
+                if (ACC) { const float2 o = *gq; gd += o.x; gb += o.y; }
+                *gq = make_float2(gd, gb);
+#ifndef ADM_ABL_NOMOD
+                a[k] = cmulc(a[k], modulator(db[k], p.k1, p.sigma));
+#else
+                a[k] = cmulc(a[k], db[k]);
+#endif
+            }
+            if (step > 0) {
+                load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
+#ifndef ADM_ABL_NOSTASH
+#pragma unroll
+                for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((step - 1) * R1 + k) * GE::NT];
+#else
+#pragma unroll
+                for (int k = 0; k < R1; ++k) psi[k] = a[k];
+#endif
+            }
+        }
+#ifndef ADM_ABL_NOCONV
+        if (step > 0) convolve<N, R1, R2, true, kHLds>(c, a, hs);
+#endif
+    }
+}
+
+template <int N, int R1, int R2>
+__device__ __forceinline__ void load_hfree(cf (&hf)[R2], const MsParams& p, int kx, int tc2) {
+    const double n2 = (double)(N * N);
+#pragma unroll
+    for (int k = 0; k < R2; ++k) {
+        const cf h = p.hfree[(tc2 + R1 * k) * N + kx];
+        hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
+    }
+}
+
+// exit wave `a` -> detector plane.  Far field: unnormalised spectrum left in bb (pass-2 column role);
+// near field / Fresnel: the detector field stays in `a` (real space).
+template <int N, int R1, int R2>
+__device__ __forceinline__ void detector_forward(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2) {
+    if (p.det_mode == ADM_DET_FRESNEL_) {
+        cf hf[R2];
+        load_hfree<N, R1, R2>(hf, p, kx, tc2);
+        convolve<N, R1, R2, false, false>(c, a, hf);
+    } else if (p.det_mode == ADM_DET_FARFIELD_) {
+        // Psi = scale * F(psi)  (F forward, or inverse via conjugation when det_inverse)
+        if (p.det_inverse) {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) a[k] = conjf2(a[k]);
+        }
+        fft2_to_regs<N, R1, R2>(c, a, bb);
+    }
+}
+// dL/d(detector field) (in bb for the far field, in `a` otherwise) -> dL/d(exit wave) in `a`
+template <int N, int R1, int R2>
+__device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2) {
+    if (p.det_mode == ADM_DET_FARFIELD_) {
+        ifft2_from_regs<N, R1, R2>(c, bb, a);
+        if (p.det_inverse) {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) a[k] = conjf2(a[k]);
+        }
+    } else if (p.det_mode == ADM_DET_FRESNEL_) {
+        cf hf[R2];
+        load_hfree<N, R1, R2>(hf, p, kx, tc2);
+        convolve<N, R1, R2, true, false>(c, a, hf);
+    }
+}
+
+template <int N, int R1, int R2, bool BIN1, bool MULTI>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
@@ -411,171 +587,134 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const size_t slice_stride = (size_t)p.Yp * p.Xp;
     const size_t tile_off = (size_t)(py + c.line) * p.Xp + px + c.t;   // + n1*R2 + slice*slice_stride
     const bool do_grad = (p.want_grad != 0);
-    float2* stash = p.stash + (size_t)b * p.n_steps * R1 * GE::NT + tid;
+    float2* stash = p.stash + (size_t)b * p.n_modes * p.n_steps * R1 * GE::NT + tid;
     float2* gtile = p.gtile + (size_t)b * p.n_steps * R1 * GE::NT + tid;
 
     cf a[R1];
-#pragma unroll
-    for (int k = 0; k < R1; ++k) a[k] = c.act1 ? p.probe[c.line * N + k * R2 + c.t] : make_float2(0.f, 0.f);
-
-    // ================= forward sweep =================
     const float2* tile_base = p.obj_rot + tile_off;
-    float2 db[R1];
-    if (c.act1) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, 0, p.binning, p.Z);
-    for (int step = 0; step < p.n_steps; ++step) {
-        if (c.act1) {
-#pragma unroll
-            for (int k = 0; k < R1; ++k) {
-#ifndef ADM_ABL_NOMOD
-                a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
-#else
-                a[k] = cmul(a[k], db[k]);
-#endif
-#ifndef ADM_ABL_NOSTASH
-                if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
-#endif
-            }
-            // next step's tile slice is requested before the propagation so its latency is hidden
-            if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
-        }
-#ifndef ADM_ABL_NOCONV
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false, kHLds>(c, a, hs);
-#endif
-    }
-
-    // ================= detector plane: loss and dL/dpsi_exit =================
+    cf bb[R2];
     float lsum = 0.f;
-    if (p.det_mode == ADM_DET_FRESNEL_) {
-        cf hf[R2];
+    if (!MULTI) {
+        // ================= single probe mode: everything stays in registers =================
+        load_probe<N, R1, R2>(c, a, p.probe);
+        fwd_sweep<N, R1, R2, BIN1>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
+        detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
+        if (p.det_mode == ADM_DET_FARFIELD_) {
+            if (c.act2) {
+                const int mx = (kx + N / 2) % N;
 #pragma unroll
-        for (int k = 0; k < R2; ++k) {
-            int ky = tc2 + R1 * k;
-            cf h = p.hfree[ky * N + kx];
-            hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
-        }
-        convolve<N, R1, R2, false, false>(c, a, hf);
-    }
-    if (p.det_mode == ADM_DET_FARFIELD_) {
-        // Psi = scale * F(psi)  (F forward, or inverse via conjugation when det_inverse)
-        cf bb[R2];
-        if (p.det_inverse) {
-#pragma unroll
-            for (int k = 0; k < R1; ++k) a[k] = conjf2(a[k]);
-        }
-        fft2_to_regs<N, R1, R2>(c, a, bb);
-        if (c.act2) {
-            const int mx = (kx + N / 2) % N;
-#pragma unroll
-            for (int k = 0; k < R2; ++k) {
-                const int ky = c.t + R1 * k;
-                const int my = (ky + N / 2) % N;
-                const size_t di = ((size_t)b * N + my) * N + mx;
-                cf psi = cscale(bb[k], p.det_scale);           // (conjugated when det_inverse; |.| unaffected)
-                float mag = sqrtf(psi.x * psi.x + psi.y * psi.y);
-                float g;
-                lsum += loss_term(mag, p.target[di], p, g);
-                if (p.pred) p.pred[di] = mag;
-                // adjoint of (scale * F): scale * F^H; with bb conjugated both ways the same code serves
-                bb[k] = cscale(psi, g * p.det_scale);
+                for (int k = 0; k < R2; ++k) {
+                    const int my = (c.t + R1 * k + N / 2) % N;
+                    const size_t di = ((size_t)b * N + my) * N + mx;
+                    const cf psi = cscale(bb[k], p.det_scale);      // (conjugated when det_inverse; |.| unaffected)
+                    const float mag = sqrtf(psi.x * psi.x + psi.y * psi.y);
+                    float g;
+                    lsum += loss_term(mag, p.target[di], p, g);
+                    if (p.pred) p.pred[di] = mag;
+                    bb[k] = cscale(psi, g * p.det_scale);            // adjoint of (scale * F) is scale * F^H
+                }
             }
-        }
-        if (do_grad) {
-            ifft2_from_regs<N, R1, R2>(c, bb, a);
-            if (p.det_inverse) {
-#pragma unroll
-                for (int k = 0; k < R1; ++k) a[k] = conjf2(a[k]);
-            }
-        }
-    } else {
-        // near field / Fresnel: the detector field is `a` in real space
-        if (c.act1) {
+        } else if (c.act1) {
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
                 const size_t di = ((size_t)b * N + c.line) * N + k * R2 + c.t;
-                float mag = sqrtf(a[k].x * a[k].x + a[k].y * a[k].y);
+                const float mag = sqrtf(a[k].x * a[k].x + a[k].y * a[k].y);
                 float g;
                 lsum += loss_term(mag, p.target[di], p, g);
                 if (p.pred) p.pred[di] = mag;
                 a[k] = cscale(a[k], g);
             }
         }
-        if (do_grad && p.det_mode == ADM_DET_FRESNEL_) {
-            cf hf[R2];
+        block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
+        if (!do_grad) return;
+        detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
+        rev_sweep<N, R1, R2, BIN1, false>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+        add_probe_grad<N, R1, R2>(c, a, p.grad_probe);
+    } else {
+        // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
+        // pred = sqrt(sum_m |Psi_m|^2): the detector-plane fields of all modes are parked in HBM (thread-native
+        // order), the intensity is summed in registers, then every mode is back-propagated with the common factor g.
+        const int M = p.n_modes;
+        const size_t per = (size_t)p.n_steps * R1 * GE::NT;
+        const bool far = (p.det_mode == ADM_DET_FARFIELD_);
+        float inten[GE::G];
 #pragma unroll
-            for (int k = 0; k < R2; ++k) {
-                int ky = (c.t % R1) + R1 * k;
-                cf h = p.hfree[ky * N + kx];
-                hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
+        for (int k = 0; k < GE::G; ++k) inten[k] = 0.f;
+        for (int m = 0; m < M; ++m) {
+            load_probe<N, R1, R2>(c, a, p.probe + (size_t)m * N * N);
+            fwd_sweep<N, R1, R2, BIN1>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
+            detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
+            float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
+            if (far) {
+                if (c.act2) {
+#pragma unroll
+                    for (int k = 0; k < R2; ++k) {
+                        const cf psi = cscale(bb[k], p.det_scale);
+                        inten[k] += psi.x * psi.x + psi.y * psi.y;
+                        dq[(size_t)k * GE::NT] = psi;
+                    }
+                }
+            } else if (c.act1) {
+#pragma unroll
+                for (int k = 0; k < R1; ++k) {
+                    inten[k] += a[k].x * a[k].x + a[k].y * a[k].y;
+                    dq[(size_t)k * GE::NT] = a[k];
+                }
             }
-            convolve<N, R1, R2, true, false>(c, a, hf);
         }
-    }
-    // block reduction of the loss
+        // loss and the common factor g (same for every mode): dL/dPsi_m = g * Psi_m
+        float gf[GE::G];
+        if (far) {
+            if (c.act2) {
+                const int mx = (kx + N / 2) % N;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
-    if (lane == 0) red[wave] = lsum;
-    __syncthreads();
-    if (tid == 0) {
-        float s = 0.f;
-        for (int w = 0; w < GE::NWAVES; ++w) s += red[w];
-        p.loss_sum[b] = s;
-    }
-    if (!do_grad) return;
-
-    // ================= reverse sweep =================
-    const float sk1 = p.sigma * p.k1;
-    cf psi[R1];
-    if (c.act1) {
-        load_db<R1, R2, BIN1>(db, tile_base, slice_stride, p.n_steps - 1, p.binning, p.Z);
-#pragma unroll
-        for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((p.n_steps - 1) * R1 + k) * GE::NT];
-    }
-    for (int step = p.n_steps - 1; step >= 0; --step) {
-        if (c.act1) {
+                for (int k = 0; k < R2; ++k) {
+                    const int my = (c.t + R1 * k + N / 2) % N;
+                    const size_t di = ((size_t)b * N + my) * N + mx;
+                    const float mag = sqrtf(inten[k]);
+                    lsum += loss_term_nz(mag, p.target[di], p, gf[k]);
+                    if (p.pred) p.pred[di] = mag;
+                }
+            }
+        } else if (c.act1) {
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                // z = conj(G) * psi'
-                const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
-                const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
-                const float gd = sk1 * zi;
-                const float gb = -p.k1 * zr;
-                // tile gradient of this modulation step, thread-native layout (coalesced 8-B/lane store);
-                // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
-                gtile[(size_t)(step * R1 + k) * GE::NT] = make_float2(gd, gb);
-#ifndef ADM_ABL_NOMOD
-                a[k] = cmulc(a[k], modulator(db[k], p.k1, p.sigma));
-#else
-                a[k] = cmulc(a[k], db[k]);
-#endif
-            }
-            if (step > 0) {
-                load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
-#pragma unroll
-#ifndef ADM_ABL_NOSTASH
-                for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((step - 1) * R1 + k) * GE::NT];
-#else
-                for (int k = 0; k < R1; ++k) psi[k] = a[k];
-#endif
+                const size_t di = ((size_t)b * N + c.line) * N + k * R2 + c.t;
+                const float mag = sqrtf(inten[k]);
+                lsum += loss_term_nz(mag, p.target[di], p, gf[k]);
+                if (p.pred) p.pred[di] = mag;
             }
         }
-#ifndef ADM_ABL_NOCONV
-        if (step > 0) convolve<N, R1, R2, true, kHLds>(c, a, hs);
-#endif
-    }
-    if (p.grad_probe && c.act1) {
+        block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
+        if (!do_grad) return;
+        for (int m = 0; m < M; ++m) {
+            const float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
+            if (far) {
+                if (c.act2) {
 #pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            float* gp = reinterpret_cast<float*>(p.grad_probe + c.line * N + k * R2 + c.t);
-            atomicAdd(gp, a[k].x);
-            atomicAdd(gp + 1, a[k].y);
+                    for (int k = 0; k < R2; ++k) bb[k] = cscale(dq[(size_t)k * GE::NT], gf[k] * p.det_scale);
+                }
+            } else if (c.act1) {
+#pragma unroll
+                for (int k = 0; k < R1; ++k) a[k] = cscale(dq[(size_t)k * GE::NT], gf[k]);
+            }
+            detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
+            if (m == 0) rev_sweep<N, R1, R2, BIN1, false>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+            else rev_sweep<N, R1, R2, BIN1, true>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
+            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)m * N * N : nullptr);
         }
     }
 }
 
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
-    if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true>), dim3(batch), dim3(GE::NT), 0, st, p);
-    else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false>), dim3(batch), dim3(GE::NT), 0, st, p);
+    if (p.n_modes > 1) {
+        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true>), dim3(batch), dim3(GE::NT), 0, st, p);
+        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, true>), dim3(batch), dim3(GE::NT), 0, st, p);
+    } else {
+        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false>), dim3(batch), dim3(GE::NT), 0, st, p);
+        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, false>), dim3(batch), dim3(GE::NT), 0, st, p);
+    }
     return hipGetLastError();
 }
 

@@ -449,8 +449,8 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
     const size_t per = (size_t)plan->n_steps * g.R1 * g.NT;
     if ((size_t)batch * per >= 0xFFFFFFFFull) return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate: batch too large for 32-bit tile offsets");
     char* ws = (char*)workspace;
-    const float2* gtile = (const float2*)(ws + (size_t)batch * per * sizeof(float2));
-    unsigned* cover = (unsigned*)(ws + 2 * (size_t)batch * per * sizeof(float2));
+    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
+    unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)g.Yp * g.Xp * (ADM_MAXCOVER + 1));
     hipStream_t st = plan->ctx->stream;
     ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
@@ -466,9 +466,8 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
 extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host) {
     if (!plan || !workspace || !overflow_host) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: null argument");
     if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: bad workspace");
-    const size_t per = (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x);
     char* ws = (char*)workspace;
-    unsigned* cover = (unsigned*)(ws + 2 * (size_t)batch * per * sizeof(float2));
+    unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)plan->Yp * plan->Xp * (ADM_MAXCOVER + 1));
     return adm_d2h(plan->ctx, overflow_host, overflow, sizeof(int));
 }

@@ -109,6 +109,7 @@ class MultisliceEngine(object):
                          poisson_multiplier=poisson_multiplier)
         self.loss_function_type = loss_function_type
         self.pads = pads
+        self.n_probe_modes = int(n_probe_modes)
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
         self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
         self.max_batch = 0

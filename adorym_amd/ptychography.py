@@ -392,8 +392,18 @@ def reconstruct_ptychography(
         if n_probe_modes == 1:
             probe_real = np.stack([np.squeeze(pr0)]) if pr0.ndim != 3 else pr0[:1]
             probe_imag = np.stack([np.squeeze(pi0)]) if pi0.ndim != 3 else pi0[:1]
+        elif pr0.ndim == 3 and len(pr0) > 1:
+            probe_real, probe_imag = pr0[:n_probe_modes], pi0[:n_probe_modes]
+            if len(probe_real) != n_probe_modes:
+                raise RuntimeError('Length of supplied supplied probe does not match number of probe modes.')
         else:
-            _not_implemented(True, 'n_probe_modes > 1')
+            # a single supplied / generated probe is spread over the modes with 20 % Gaussian jitter (ptychography.py:641-659)
+            pr0, pi0 = np.squeeze(pr0), np.squeeze(pi0)
+            probe_real, probe_imag = [], []
+            for i_mode in range(n_probe_modes):
+                probe_real.append(np.random.normal(pr0, abs(pr0) * 0.2))
+                probe_imag.append(np.random.normal(pi0, abs(pi0) * 0.2))
+            probe_real, probe_imag = np.stack(probe_real), np.stack(probe_imag)
     else:
         probe_real = probe_imag = None
     probe_real = comm.bcast_object(probe_real, root=0)

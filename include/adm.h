@@ -142,7 +142,7 @@ int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr
  * loss_sum  device [batch] : per-position sum over pixels of (pred-target)^2, or of the Poisson terms
  *           pred^2*pm - target*pm*log(pred^2*pm) (overwritten)
  * grad_scale multiplies d loss/d pred: 2/(batch*Py*Px) for the reference's mean()
- * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when want_grad==0) */
+ * workspace device scratch of adm_plan_workspace_bytes(plan, batch) bytes (unused when want_grad==0 and n_modes==1) */
 int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
                            const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                            float grad_scale, void* workspace, size_t workspace_bytes);

@@ -78,7 +78,7 @@ def test_probe_optimisation_runs_and_reduces_loss(tmp_path):
 
 def test_unsupported_options_raise(tmp_path):
     for bad in (dict(distribution_mode='shared_file'), dict(unknown_type='real_imag'), dict(optimizer='cg'),
-                dict(optimize_all_probe_pos=True), dict(n_probe_modes=3), dict(cpu_only=True)):
+                dict(optimize_all_probe_pos=True), dict(optimize_probe_defocusing=True), dict(cpu_only=True)):
         with pytest.raises(NotImplementedError):
             run(tmp_path, n_epochs=1, **bad)
 
@@ -88,6 +88,7 @@ def test_driver_variants_run(tmp_path):
     reference in test_gpu_parity.py): finite results and a decreasing loss."""
     for extra in (dict(loss_function_type='poisson', optimizer='adam', learning_rate=1e-6),
                   dict(optimizer='momentum', learning_rate=1e-10),
+                  dict(optimizer='adam', learning_rate=1e-6, n_probe_modes=3, optimize_probe=True, probe_learning_rate=1e-4),
                   dict(optimizer='adam', learning_rate=1e-6, alpha_d=1e-4, alpha_b=1e-5, reweighted_l1=True)):
         g, inp, st = run(tmp_path, n_epochs=2, **extra)
         assert np.all(np.isfinite(st['delta'])) and np.all(np.isfinite(st['beta']))

@@ -108,8 +108,6 @@ def test_unsupported_configs_raise(A, ctx):
     with pytest.raises(NotImplementedError):
         A.MultisliceEngine(ctx, (20, 20, 4), (20, 20), pos, 5000., 1e-7)            # size not compiled
     with pytest.raises(NotImplementedError):
-        A.MultisliceEngine(ctx, (16, 16, 4), (16, 16), pos, 5000., 1e-7, n_probe_modes=3)
-    with pytest.raises(NotImplementedError):
         A.MultisliceEngine(ctx, (16, 12, 4), (16, 12), pos, 5000., 1e-7)            # non-square
 
 
@@ -363,3 +361,44 @@ def test_reweighted_l1_vs_reference(A, ctx):
     check(ctx.lib.adm_reg_grad_weighted(eng.plan.handle, d_obj.ptr, d_w.ptr, 0.8, 0.3, d_g.ptr, d_v.ptr))
     assert rel(d_g.get(), g['rwl1_grad']) < 2e-6
     assert abs(d_v.get()[0] - g['rwl1_val']) <= 1e-5 * abs(g['rwl1_val'])
+
+
+# --------------------------------------------------------------------------- incoherent probe modes (next row f2)
+@pytest.mark.parametrize('free_prop_cm', ['inf', 0])
+def test_probe_modes_vs_reference_and_oracle(A, ctx, free_prop_cm):
+    """pred = sqrt(sum_m |Psi_m|^2) (adorym/forward_model.py:354-375): far field against the reference golden
+    (3 modes), near field against the pinned oracle."""
+    name = 'p12_s9_far_modes3'
+    c = cases.tile_case_inputs(name)
+    g = load('F23_' + name)
+    P, S, B, M = c['P'], c['S'], cases.TILE_B, c['n_modes']
+    obj = c['guess'].reshape(B * P, P, S, 2)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    if free_prop_cm == 'inf':
+        meas, loss_ref, pred_ref = g['meas'], float(g['loss_64']), g['pred_64']
+        gt_ref, e_ref = g['grad_tiles_64'], rel(g['grad_tiles_32'], g['grad_tiles_64'])
+        gp_ref = np.stack([g['grad_probe_real_64'], g['grad_probe_imag_64']], -1)
+    else:
+        phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=0)
+        meas = np.abs(O.predict(c['truth'], c['probes'], phys, 'float64')[0])
+        loss_ref, pred_ref, gt_ref, gp = O.forward_adjoint_tiles(c['guess'], c['probes'], meas, phys, 'float64')
+        _, _, gt32, _ = O.forward_adjoint_tiles(c['guess'].astype(np.float32), c['probes'], meas, phys, 'float32')
+        e_ref = rel(gt32, gt_ref)
+        gp_ref = np.stack([gp.real, gp.imag], -1)
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=free_prop_cm,
+                             n_probe_modes=M)
+    d_grad = ctx.zeros(obj.shape)
+    d_probe = ctx.array(np.stack([c2(pm) for pm in c['probes']]))
+    d_gp = ctx.zeros((M, P, P, 2))
+    eng.set_batch(pos, meas)
+    eng.rotate(ctx.array(obj, np.float32), None)
+    eng.multislice(d_probe, grad_probe=d_gp, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    assert rel(eng.pred(), pred_ref) < 2e-6
+    assert abs(eng.loss() - loss_ref) <= 1e-5 * abs(loss_ref)
+    e = rel(d_grad.get().reshape(B, P, P, S, 2), gt_ref)
+    assert e < 1e-4 and e <= 3 * e_ref + 1e-5, (e, e_ref)
+    assert rel(d_gp.get(), gp_ref) < 1e-4
+    # forward-only (predict) path with modes
+    eng.multislice(d_probe, want_grad=False, want_pred=True)
+    assert rel(eng.pred(), pred_ref) < 2e-6
