@@ -199,7 +199,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     if (d.probe_y != d.probe_x)
         return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: non-square probes are not implemented yet");
     if (ms_threads_for(d.probe_x) == 0)
-        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size not in the compiled set {12,16,32,64,72}");
+        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size not in the compiled set {8,12,16,18,24,27,32,36,64,72}");
     if (d.n_modes < 1 || d.n_modes > 64) return fail(ADM_ERR_INVALID, "adm_plan_create: n_modes must be in [1, 64]");
     if (d.pad_y0 + d.obj_y + d.pad_y1 < d.probe_y || d.pad_x0 + d.obj_x + d.pad_x1 < d.probe_x)
         return fail(ADM_ERR_INVALID, "adm_plan_create: padded object smaller than the probe");

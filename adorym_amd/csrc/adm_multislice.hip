@@ -718,44 +718,39 @@ template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int
     return hipGetLastError();
 }
 
+// compiled probe sizes N = R1 * R2 (radices from {2, 3, 4, 8, 9}; at most 16 waves per workgroup)
+#define ADM_FOR_EACH_SIZE(X) X(8, 2, 4) X(12, 3, 4) X(16, 4, 4) X(18, 2, 9) X(24, 3, 8) X(27, 3, 9) X(32, 4, 8) X(36, 4, 9) X(64, 8, 8) X(72, 8, 9)
+
 int ms_threads_for(int n) {
     switch (n) {
-        case 12: return Geo<12, 3, 4>::NT;
-        case 16: return Geo<16, 4, 4>::NT;
-        case 32: return Geo<32, 4, 8>::NT;
-        case 64: return Geo<64, 8, 8>::NT;
-        case 72: return Geo<72, 8, 9>::NT;
+#define X(N_, A_, B_) case N_: return Geo<N_, A_, B_>::NT;
+        ADM_FOR_EACH_SIZE(X)
+#undef X
         default: return 0;
     }
 }
 int ms_r2_for(int n) {
     switch (n) {
-        case 12: return 4;
-        case 16: return 4;
-        case 32: return 8;
-        case 64: return 8;
-        case 72: return 9;
+#define X(N_, A_, B_) case N_: return B_;
+        ADM_FOR_EACH_SIZE(X)
+#undef X
         default: return 0;
     }
 }
 int ms_r1_for(int n) {
     switch (n) {
-        case 12: return 3;
-        case 16: return 4;
-        case 32: return 4;
-        case 64: return 8;
-        case 72: return 8;
+#define X(N_, A_, B_) case N_: return A_;
+        ADM_FOR_EACH_SIZE(X)
+#undef X
         default: return 0;
     }
 }
 
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st) {
     switch (n) {
-        case 12: return launch<12, 3, 4>(p, batch, st);
-        case 16: return launch<16, 4, 4>(p, batch, st);
-        case 32: return launch<32, 4, 8>(p, batch, st);
-        case 64: return launch<64, 8, 8>(p, batch, st);
-        case 72: return launch<72, 8, 9>(p, batch, st);
+#define X(N_, A_, B_) case N_: return launch<N_, A_, B_>(p, batch, st);
+        ADM_FOR_EACH_SIZE(X)
+#undef X
         default: return hipErrorInvalidValue;
     }
 }

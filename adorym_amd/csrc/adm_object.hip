@@ -422,7 +422,9 @@ extern "C" int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const i
     if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_adj_csr: bad y range");
     if (y_lo == y_hi) return ADM_OK;
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
-    const int y_chunk = 16;
+    // small y chunks: the few blocks that own border voxels (long lists of clamped samples) are split over many
+    // workgroups instead of forming a tail
+    const int y_chunk = 4;
     dim3 grid((d.obj_x * d.obj_z + 255) / 256, (y_hi - y_lo + y_chunk - 1) / y_chunk, 1);
     hipLaunchKernelGGL(rotate_adj_csr_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src, csr_w,
                        (float2*)grad_obj, g, y_lo, y_hi, y_chunk);

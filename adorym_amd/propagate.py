@@ -209,13 +209,13 @@ class MultisliceEngine(object):
         """mean of the per-pixel loss terms over the batch (adorym/forward_model.py:88-103) -- blocks.
         ``last=n``: over the last n positions only (the final minibatch of a fused 'per angle' group)."""
         B = self._B
-        if self._accumulated:
+        if self._accumulated and B > 64:      # a pixel cannot be covered by more than B <= 64 tiles
             ov = C.c_int(0)
             check(self.ctx.lib.adm_tile_grad_status(self.plan.handle, self._ws.ptr, self._ws.nbytes, B, C.byref(ov)))
             if ov.value:
                 raise RuntimeError('tile overlap-add overflow: a pixel is covered by more than 64 tiles of this batch; '
                                    'use a smaller batch')
-            self._accumulated = False
+        self._accumulated = False
         sums = self._loss.view(0, (B,)).get().astype(np.float64)
         if last is not None:
             sums = sums[B - last:]

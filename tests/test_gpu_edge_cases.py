@@ -126,3 +126,59 @@ def test_fullfield_config2_shape_driver_vs_oracle(A, ctx, tmp_path):
     d = np.abs(x - ref)
     assert (d > 3e-8).mean() < 2e-3, (d > 3e-8).mean()                 # lr = 1e-7 steps: all but sign-flip voxels agree
     assert np.all(x[mask == 0] == 0)                                   # finite-support mask applied
+
+
+@pytest.mark.parametrize('P', [8, 12, 16, 18, 24, 27, 32, 36, 64, 72])
+def test_every_compiled_probe_size_vs_oracle(A, ctx, P):
+    """All FFT factorisations N = R1*R2 shipped in libadm (radices 2, 3, 4, 8, 9), forward and gradient."""
+    r = cases.rng(80 + P)
+    S, B = 5, 2
+    obj = np.stack([2e-3 * r.uniform(size=(B * P, P, S)), 2e-4 * r.uniform(size=(B * P, P, S))], -1)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    phys = O.Physics((P, P), 5000., 1e-7)
+    truth = np.stack([2e-3 * r.uniform(size=(B * P, P, S)), 2e-4 * r.uniform(size=(B * P, P, S))], -1)   # independent of the guess
+    target = np.abs(O.multislice_forward(O.extract_tiles(truth, pos, (P, P))[0], probe, phys, 'float64'))
+    loss_o, pred_o, g_o, gp_o = O.forward_adjoint_object(obj, None, probe, pos, target, phys, 'float64')
+    _, _, g32, _ = O.forward_adjoint_object(obj.astype(np.float32), None, probe, pos, target, phys, 'float32')
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, 5000., 1e-7)
+    d_grad = ctx.zeros(obj.shape)
+    d_gp = ctx.zeros((P, P, 2))
+    eng.set_batch(pos, target)
+    eng.rotate(ctx.array(obj, np.float32), None)
+    eng.multislice(ctx.array(c2(probe)), grad_probe=d_gp, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    assert rel(eng.pred(), pred_o) < 2e-6
+    assert abs(eng.loss() - loss_o) <= 2e-5 * abs(loss_o)
+    e, e32 = rel(d_grad.get(), g_o), rel(g32, g_o)
+    assert e < 1e-4 and e <= 3 * e32 + 1e-5, (P, e, e32)
+    assert rel(d_gp.get(), c2(gp_o[0])) < 1e-4
+
+
+def test_two_d_mode_config1_shape_driver_vs_oracle(A, ctx, tmp_path):
+    """Config 1 of BASELINE.json in miniature: 2-D single-slice ptychography (obj_size[-1] == 1 => two_d_mode, no
+    rotation), several probe modes, intensity data, overlapping raster scan, minibatch > 1."""
+    r = cases.rng(91)
+    Y, X, P, M = 60, 52, 16, 3
+    truth = np.stack([2e-2 * cases.smooth_field((Y, X, 1), 92), 2e-3 * cases.smooth_field((Y, X, 1), 93)], -1)
+    guess = [np.full((Y, X, 1), 1e-2), np.full((Y, X, 1), 1e-3)]
+    pos = np.array([(y, x) for y in range(-4, 50, 8) for x in range(-4, 42, 8)], dtype=float)
+    base = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    probes = np.stack([base * (0.6 ** m) * np.exp(1j * m * 0.3 * r.uniform(-1, 1, (P, P))) for m in range(M)])
+    phys = O.Physics((P, P), 8000., 1e-6)
+    tiles, _ = O.extract_tiles(truth, pos, (P, P))
+    inten = O.predict(tiles, probes, phys, 'float64')[0] ** 2                 # raw_data_type='intensity'
+    prj = inten[None].astype(np.float32)
+    st = A.reconstruct_ptychography(fname=prj, obj_size=(Y, X, 1), probe_pos=pos, energy_ev=8000., psize_cm=1e-6, free_prop_cm='inf',
+                                    raw_data_type='intensity', n_probe_modes=M, probe_type='supplied',
+                                    probe_initial=[np.abs(probes), np.angle(probes)], initial_guess=guess, minibatch_size=7,
+                                    n_epochs=2, optimizer='adam', learning_rate=1e-4, gamma=0, alpha_d=0, alpha_b=0,
+                                    save_path=str(tmp_path), output_folder='twod', store_checkpoint=False, use_checkpoint=False,
+                                    return_state=True)
+    ref, losses, _ = O.reconstruct(np.sqrt(prj.astype(np.float64)) ** 2, guess, probes, pos, np.zeros(1, 'float32'), phys, n_epochs=2,
+                                   minibatch_size=7, optimizer='adam', learning_rate=1e-4, dtype='float64', two_d_mode=True,
+                                   raw_data_type='intensity', return_trace=True)
+    x = np.stack([st['delta'], st['beta']], -1)
+    assert len(st['losses']) == len(losses) and np.allclose(st['losses'], losses, rtol=2e-4)
+    upd = np.linalg.norm(ref - np.stack(guess, -1))
+    assert np.linalg.norm(x - ref) < 5e-3 * upd, np.linalg.norm(x - ref) / upd
