@@ -53,7 +53,7 @@ SIGNATURES = {
     'adm_plan_workspace_bytes': (_SZ, [_VP, _I]),
     'adm_rotate_fwd': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
-    'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I]),
+    'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_tile_grad_accumulate': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),

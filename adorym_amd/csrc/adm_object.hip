@@ -96,44 +96,63 @@ __global__ __launch_bounds__(256) void rotate_adj_kernel(const float2* __restric
 // build_rotation_adjoint_csr, same fp32 coordinate pipeline as make_bilin).  One thread owns one object
 // voxel column (x, z) -- consecutive threads are consecutive z, the fastest object axis, so the
 // read-modify-write of grad_obj is coalesced -- and walks the y planes four at a time.
+// A block owns a 16 x 16 patch of object-plane voxels and four y planes.  ALONG_X = false: lanes run along z (the
+// fastest object axis): gobj accesses are coalesced, and so are the gathers from grad_rot when |sin(theta)| is large
+// (a step in z is then a step in x').  ALONG_X = true (|cos| > |sin|): lanes run along x so that the gathered
+// rotated-frame voxels are consecutive in x' (the fastest axis of [Z][Yp][Xp]); the patch is then transposed through
+// LDS so that the read-modify-write of gobj is still issued along z.
+template <bool ALONG_X>
 __global__ __launch_bounds__(256) void rotate_adj_csr_kernel(const float2* __restrict__ grot, const int* __restrict__ ptr,
                                                              const int* __restrict__ src, const float* __restrict__ wgt,
-                                                             float2* __restrict__ gobj, RotGeom g, int y_lo, int y_hi, int y_chunk) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= g.X * g.Z) return;
-    const int beg = ptr[t], end = ptr[t + 1];
-    const int ya = y_lo + blockIdx.y * y_chunk;
-    const int yb = min(ya + y_chunk, y_hi);
+                                                             float2* __restrict__ gobj, RotGeom g, int y_lo, int y_hi) {
+    __shared__ float2 tile[4][16][17];
+    const int lx = ALONG_X ? (threadIdx.x & 15) : (threadIdx.x >> 4);
+    const int lz = ALONG_X ? (threadIdx.x >> 4) : (threadIdx.x & 15);
+    const int x = blockIdx.x * 16 + lx, z = blockIdx.y * 16 + lz;
+    const bool ok = (x < g.X) && (z < g.Z);
+    const int t = ok ? x * g.Z + z : 0;
+    const int beg = ok ? ptr[t] : 0, end = ok ? ptr[t + 1] : 0;
+    const int y0 = y_lo + blockIdx.z * 4;
+    const int ny = min(4, y_hi - y0);
     const size_t plane = (size_t)g.X * g.Z;
-    int y = ya;
-    for (; y + 4 <= yb; y += 4) {
-        float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        const size_t row = (size_t)(g.pad_y0 + y) * g.Xp;
+    float2 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = make_float2(0.f, 0.f);
+    const size_t row = (size_t)(g.pad_y0 + y0) * g.Xp;
+    if (ny == 4) {
         for (int j = beg; j < end; ++j) {
             const float w = wgt[j];
             const float2* q = grot + (size_t)src[j] + row;
             const float2 v0 = q[0], v1 = q[g.Xp], v2 = q[2 * (size_t)g.Xp], v3 = q[3 * (size_t)g.Xp];
-            a0.x += w * v0.x; a0.y += w * v0.y;
-            a1.x += w * v1.x; a1.y += w * v1.y;
-            a2.x += w * v2.x; a2.y += w * v2.y;
-            a3.x += w * v3.x; a3.y += w * v3.y;
+            a[0].x += w * v0.x; a[0].y += w * v0.y;
+            a[1].x += w * v1.x; a[1].y += w * v1.y;
+            a[2].x += w * v2.x; a[2].y += w * v2.y;
+            a[3].x += w * v3.x; a[3].y += w * v3.y;
         }
-        float2* o = gobj + (size_t)y * plane + t;
-        float2 c;
-        c = o[0]; c.x += a0.x; c.y += a0.y; o[0] = c;
-        c = o[plane]; c.x += a1.x; c.y += a1.y; o[plane] = c;
-        c = o[2 * plane]; c.x += a2.x; c.y += a2.y; o[2 * plane] = c;
-        c = o[3 * plane]; c.x += a3.x; c.y += a3.y; o[3 * plane] = c;
-    }
-    for (; y < yb; ++y) {
-        float2 a0 = make_float2(0.f, 0.f);
-        const size_t row = (size_t)(g.pad_y0 + y) * g.Xp;
+    } else {
         for (int j = beg; j < end; ++j) {
-            const float2 v = grot[(size_t)src[j] + row];
-            a0.x += wgt[j] * v.x; a0.y += wgt[j] * v.y;
+            const float w = wgt[j];
+            const float2* q = grot + (size_t)src[j] + row;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < ny) { const float2 v = q[(size_t)i * g.Xp]; a[i].x += w * v.x; a[i].y += w * v.y; }
         }
-        float2* o = gobj + (size_t)y * plane + t;
-        float2 c = o[0]; c.x += a0.x; c.y += a0.y; o[0] = c;
+    }
+    int wx = lx, wz = lz;
+    if (ALONG_X) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[i][lx][lz] = a[i];
+        __syncthreads();
+        wx = threadIdx.x >> 4; wz = threadIdx.x & 15;          // now lanes run along z
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = tile[i][wx][wz];
+    }
+    const int ox = blockIdx.x * 16 + wx, oz = blockIdx.y * 16 + wz;
+    if (ox < g.X && oz < g.Z) {
+        float2* o = gobj + (size_t)y0 * plane + (size_t)ox * g.Z + oz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < ny) { float2 c = o[(size_t)i * plane]; c.x += a[i].x; c.y += a[i].y; o[(size_t)i * plane] = c; }
     }
 }
 
@@ -416,18 +435,19 @@ extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint1
 }
 
 extern "C" int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
-                                  const float* csr_w, float* grad_obj, int y_lo, int y_hi) {
+                                  const float* csr_w, float* grad_obj, int y_lo, int y_hi, int lanes_along_x) {
     if (!plan || !grad_rot || !csr_ptr || !csr_src || !csr_w || !grad_obj) return fail(ADM_ERR_INVALID, "adm_rotate_adj_csr: null argument");
     const adm_plan_desc& d = plan->d;
     if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_adj_csr: bad y range");
     if (y_lo == y_hi) return ADM_OK;
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
-    // small y chunks: the few blocks that own border voxels (long lists of clamped samples) are split over many
-    // workgroups instead of forming a tail
-    const int y_chunk = 4;
-    dim3 grid((d.obj_x * d.obj_z + 255) / 256, (y_hi - y_lo + y_chunk - 1) / y_chunk, 1);
-    hipLaunchKernelGGL(rotate_adj_csr_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src, csr_w,
-                       (float2*)grad_obj, g, y_lo, y_hi, y_chunk);
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + 3) / 4);
+    if (lanes_along_x)
+        hipLaunchKernelGGL(rotate_adj_csr_kernel<true>, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src,
+                           csr_w, (float2*)grad_obj, g, y_lo, y_hi);
+    else
+        hipLaunchKernelGGL(rotate_adj_csr_kernel<false>, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src,
+                           csr_w, (float2*)grad_obj, g, y_lo, y_hi);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -50,6 +50,8 @@ class RotationTable(object):
         self.coords = ctx.array(np.ascontiguousarray(self.host).view(np.uint16))
         self._csr = None
         self._csr_key = None
+        th = float(theta)
+        self.lanes_along_x = abs(np.cos(th)) > abs(np.sin(th))
 
     @property
     def ptr(self):
@@ -151,7 +153,8 @@ class MultisliceEngine(object):
         lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
         if isinstance(coords, RotationTable):
             p, s, w = coords.csr(self.plan)
-            check(self.ctx.lib.adm_rotate_adj_csr(self.plan.handle, self.grad_rot.ptr, p.ptr, s.ptr, w.ptr, grad_obj.ptr, lo, hi))
+            check(self.ctx.lib.adm_rotate_adj_csr(self.plan.handle, self.grad_rot.ptr, p.ptr, s.ptr, w.ptr, grad_obj.ptr, lo, hi,
+                                                  1 if coords.lanes_along_x else 0))
         else:
             check(self.ctx.lib.adm_rotate_adj(self.plan.handle, self.grad_rot.ptr, coords.ptr if coords is not None else None,
                                               grad_obj.ptr, lo, hi))

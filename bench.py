@@ -190,14 +190,14 @@ def main():
         pos = pos_all[ind]
         # side stream: zero the gradient buffer and add the regulariser gradient (they only read the object) while
         # the multislice chain, which occupies `minibatch` of the 256 CUs, runs on the main stream
+        eng.set_batch(pos, targets[(it, int(ind[0]))])
+        yr = eng.y_footprint(pos)
+        eng.rotate(state.obj, tables[it], yr)
         ctx.fork()
         state.zero_grad()
         check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
                                    state.grad.ptr, None))
         ctx.end_fork()
-        eng.set_batch(pos, targets[(it, int(ind[0]))])
-        yr = eng.y_footprint(pos)
-        eng.rotate(state.obj, tables[it], yr)
         if timed:
             ev_ms[0].record()
         eng.multislice(probe, accumulate=False)

@@ -118,9 +118,11 @@ int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords
  * matrix of one angle in CSR form over object-plane voxels t = x*Z + z:
  *   csr_ptr [X*Z+1], csr_src [nnz] = z'*(Yp*Xp) + pad_x0 + x' (float2 offset of the rotated-frame voxel inside
  *   grad_rot, without the y row), csr_w [nnz] bilinear weights.   grad_obj[y][t] += sum_j w_j * grad_rot[src_j + row(y)].
- * The host builds the CSR once per angle from the same fp16 lookup table (adorym_amd/util.py). */
+ * The host builds the CSR once per angle from the same fp16 lookup table (adorym_amd/util.py).
+ * lanes_along_x: performance hint only (same result): 1 when |cos(theta)| > |sin(theta)| so that neighbouring lanes
+ * gather neighbouring x' of grad_rot. */
 int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
-                       const float* csr_w, float* grad_obj, int y_lo, int y_hi);
+                       const float* csr_w, float* grad_obj, int y_lo, int y_hi, int lanes_along_x);
 
 /* ---- R3,R5-R8,R10  multislice forward + loss + adjoint ------------------------------
  * Replaces, for one minibatch of `batch` probe positions of one rotation angle:
