@@ -20,7 +20,7 @@ class PlanDesc(C.Structure):
                 ('det_mode', C.c_int32), ('normalize_fft', C.c_int32), ('k1', C.c_float),
                 ('h_re', C.POINTER(C.c_float)), ('h_im', C.POINTER(C.c_float)),
                 ('hfree_re', C.POINTER(C.c_float)), ('hfree_im', C.POINTER(C.c_float)),
-                ('loss_type', C.c_int32), ('poisson_multiplier', C.c_float)]
+                ('loss_type', C.c_int32), ('poisson_multiplier', C.c_float), ('unknown_type', C.c_int32)]
 
 
 _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double

@@ -25,7 +25,7 @@ class ObjectFunction(LargeArray):
 
     @staticmethod
     def initial_values(shape, initial_guess=None, random_guess_means_sigmas=(8.7e-7, 5.1e-8, 1e-7, 1e-8),
-                       object_type='normal', non_negativity=False):
+                       object_type='normal', non_negativity=False, unknown_type='delta_beta'):
         """initialize_object_for_dp (adorym/util.py:71-125), delta_beta branch.  Uses the legacy global
         NumPy RNG like the reference (the caller seeds it)."""
         if initial_guess is None:
@@ -34,6 +34,14 @@ class ObjectFunction(LargeArray):
         else:
             delta = np.array(initial_guess[0], dtype=np.float64)
             beta = np.array(initial_guess[1], dtype=np.float64)
+        if unknown_type == 'real_imag':
+            # the guess is (magnitude, phase) and is converted to (real, imag) (adorym/util.py:106-122)
+            if object_type == 'phase_only':
+                delta[...] = 1
+            elif object_type == 'absorption_only':
+                beta[...] = 0
+            cplx = delta * np.exp(1j * beta)
+            return np.stack([cplx.real, cplx.imag], -1).astype(np.float32)
         if object_type == 'phase_only':
             beta[...] = 0
         elif object_type == 'absorption_only':

@@ -193,6 +193,8 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     if (d.sign_convention != 1 && d.sign_convention != -1) return fail(ADM_ERR_INVALID, "adm_plan_create: sign_convention must be +-1");
     if (d.det_mode < 0 || d.det_mode > 2) return fail(ADM_ERR_INVALID, "adm_plan_create: bad det_mode");
     if (d.loss_type != ADM_LOSS_LSQ && d.loss_type != ADM_LOSS_POISSON) return fail(ADM_ERR_INVALID, "adm_plan_create: bad loss_type");
+    if (d.unknown_type != 0 && d.unknown_type != 1) return fail(ADM_ERR_INVALID, "adm_plan_create: bad unknown_type");
+    if (d.unknown_type == 1 && d.binning != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: binning > 1 with unknown_type real_imag is not implemented");
     if (!d.h_re || !d.h_im) return fail(ADM_ERR_INVALID, "adm_plan_create: transfer function missing");
     if (d.det_mode == ADM_DET_FRESNEL && (!d.hfree_re || !d.hfree_im))
         return fail(ADM_ERR_INVALID, "adm_plan_create: det_mode fresnel needs hfree");
@@ -314,6 +316,7 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
     p.grad_scale = grad_scale;
     p.loss_type = d.loss_type;
     p.poisson_mult = d.poisson_multiplier;
+    p.real_imag = d.unknown_type;
     ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     return ADM_OK;
 }

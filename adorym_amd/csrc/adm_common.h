@@ -58,6 +58,7 @@ struct MsParams {
     float2* det;               // [B][n_modes][G][NT] detector-plane fields of the modes (n_modes > 1 only)
     int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
     float poisson_mult;
+    int real_imag;             // unknown_type == 'real_imag'
 };
 int ms_threads_for(int n);
 int ms_r2_for(int n);

@@ -384,7 +384,7 @@ __device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restri
     }
 }
 
-template <int N, int R1, int R2, bool BIN1>
+template <int N, int R1, int R2, bool BIN1, bool RI>
 __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, float2* stash,
                                           const float2* tile_base, size_t slice_stride, bool do_grad) {
     using GE = Geo<N, R1, R2>;
@@ -399,14 +399,20 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
         if (c.act1) {
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
+                if (RI) {
+                    // the slice IS the complex transmission; its gradient needs the PRE-modulation field
+                    if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
+                    a[k] = cmul(a[k], db[k]);
+                } else {
 #ifndef ADM_ABL_NOMOD
-                a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
+                    a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
 #else
-                a[k] = cmul(a[k], db[k]);
+                    a[k] = cmul(a[k], db[k]);
 #endif
 #ifndef ADM_ABL_NOSTASH
-                if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
+                    if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
 #endif
+                }
             }
             // next step's tile slice is requested before the propagation so its latency is hidden
             if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
@@ -418,7 +424,7 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
 }
 
 // ACC: add to the tile gradient already stored by a previous probe mode instead of overwriting it
-template <int N, int R1, int R2, bool BIN1, bool ACC>
+template <int N, int R1, int R2, bool BIN1, bool ACC, bool RI>
 __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, const float2* stash,
                                           float2* gtile, const float2* tile_base, size_t slice_stride) {
     using GE = Geo<N, R1, R2>;
@@ -439,18 +445,23 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
         if (c.act1) {
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                // z = conj(G) * psi'
+                // z = conj(G) * psi'  (delta_beta: psi' is the post-modulation field; real_imag: the stash holds the
+                // pre-modulation field and (d/dre, d/dim) = G * conj(psi) = (Re z, -Im z))
                 const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
                 const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
-                float gd = sk1 * zi;
-                float gb = -p.k1 * zr;
+                float gd = RI ? zr : sk1 * zi;
+                float gb = RI ? -zi : -p.k1 * zr;
                 // tile gradient of this modulation step, thread-native layout (coalesced 8-B/lane store);
                 // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
+#ifdef ADM_GTILE_PIXEL
+                float2* gq = gtile + (size_t)step * N * N + k * R2;      // pixel-major [step][row][col]; gtile -> (row, t)
+#else
                 float2* gq = gtile + (size_t)(step * R1 + k) * GE::NT;
+#endif
                 if (ACC) { const float2 o = *gq; gd += o.x; gb += o.y; }
                 *gq = make_float2(gd, gb);
 #ifndef ADM_ABL_NOMOD
-                a[k] = cmulc(a[k], modulator(db[k], p.k1, p.sigma));
+                a[k] = cmulc(a[k], RI ? db[k] : modulator(db[k], p.k1, p.sigma));
 #else
                 a[k] = cmulc(a[k], db[k]);
 #endif
@@ -515,7 +526,7 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
     }
 }
 
-template <int N, int R1, int R2, bool BIN1, bool MULTI>
+template <int N, int R1, int R2, bool BIN1, bool MULTI, bool RI>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
@@ -588,7 +599,11 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const size_t tile_off = (size_t)(py + c.line) * p.Xp + px + c.t;   // + n1*R2 + slice*slice_stride
     const bool do_grad = (p.want_grad != 0);
     float2* stash = p.stash + (size_t)b * p.n_modes * p.n_steps * R1 * GE::NT + tid;
+#ifdef ADM_GTILE_PIXEL
+    float2* gtile = p.gtile + (size_t)b * p.n_steps * N * N + c.line * N + c.t;
+#else
     float2* gtile = p.gtile + (size_t)b * p.n_steps * R1 * GE::NT + tid;
+#endif
 
     cf a[R1];
     const float2* tile_base = p.obj_rot + tile_off;
@@ -597,7 +612,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     if (!MULTI) {
         // ================= single probe mode: everything stays in registers =================
         load_probe<N, R1, R2>(c, a, p.probe);
-        fwd_sweep<N, R1, R2, BIN1>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
+        fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
         detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
         if (p.det_mode == ADM_DET_FARFIELD_) {
             if (c.act2) {
@@ -628,7 +643,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
-        rev_sweep<N, R1, R2, BIN1, false>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+        rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
         add_probe_grad<N, R1, R2>(c, a, p.grad_probe);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
@@ -642,7 +657,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         for (int k = 0; k < GE::G; ++k) inten[k] = 0.f;
         for (int m = 0; m < M; ++m) {
             load_probe<N, R1, R2>(c, a, p.probe + (size_t)m * N * N);
-            fwd_sweep<N, R1, R2, BIN1>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
+            fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
             detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
             float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
             if (far) {
@@ -699,8 +714,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                 for (int k = 0; k < R1; ++k) a[k] = cscale(dq[(size_t)k * GE::NT], gf[k]);
             }
             detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
-            if (m == 0) rev_sweep<N, R1, R2, BIN1, false>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
-            else rev_sweep<N, R1, R2, BIN1, true>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
+            if (m == 0) rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+            else rev_sweep<N, R1, R2, BIN1, true, RI>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
             add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)m * N * N : nullptr);
         }
     }
@@ -708,12 +723,16 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
-    if (p.n_modes > 1) {
-        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true>), dim3(batch), dim3(GE::NT), 0, st, p);
-        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, true>), dim3(batch), dim3(GE::NT), 0, st, p);
+    const dim3 g(batch), t(GE::NT);
+    if (p.real_imag) {          // binning == 1 is enforced at plan creation
+        if (p.n_modes > 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true, true>), g, t, 0, st, p);
+        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, true>), g, t, 0, st, p);
+    } else if (p.n_modes > 1) {
+        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true, false>), g, t, 0, st, p);
+        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, true, false>), g, t, 0, st, p);
     } else {
-        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false>), dim3(batch), dim3(GE::NT), 0, st, p);
-        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, false>), dim3(batch), dim3(GE::NT), 0, st, p);
+        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, false>), g, t, 0, st, p);
+        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, false, false>), g, t, 0, st, p);
     }
     return hipGetLastError();
 }

@@ -180,14 +180,22 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     const int y = g.row0 + r;
     unsigned* out = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
     int cnt = 0;
+#ifdef ADM_GTILE_PIXEL
+    const unsigned per_pos = (unsigned)g.n_steps * g.P * g.P;
+#else
     const unsigned per_pos = (unsigned)g.n_steps * g.R1 * g.NT;
+#endif
     for (int b = 0; b < B; ++b) {
         const int2 p = pos[b];
         const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
         if (row >= 0 && row < g.P && col >= 0 && col < g.P) {
             if (cnt < ADM_MAXCOVER) {
                 const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
+#ifdef ADM_GTILE_PIXEL
+                out[1 + cnt] = (unsigned)b * per_pos + (unsigned)(row * g.P + col);
+#else
                 out[1 + cnt] = (unsigned)b * per_pos + (unsigned)((col / g.R2) * g.NT + tid);
+#endif
             }
             ++cnt;
         }
@@ -207,7 +215,11 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     if (x >= g.Xp || r >= g.nrows) return;
     const unsigned* cv = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
     const int cnt = (int)cv[0];
+#ifdef ADM_GTILE_PIXEL
+    const size_t step_stride = (size_t)g.P * g.P;
+#else
     const size_t step_stride = (size_t)g.R1 * g.NT;
+#endif
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
     const int st0 = blockIdx.z * TA_STEPS;

@@ -141,7 +141,7 @@ class Plan(object):
     """adm_plan: object/probe geometry, padding, physics constants and transfer functions."""
 
     def __init__(self, ctx, obj_size, probe_size, pads, k1, h, binning=1, n_modes=1, sign_convention=1,
-                 det_mode=_lib.DET_FARFIELD, normalize_fft=False, h_free=None, loss_type=_lib.LOSS_LSQ, poisson_multiplier=1.0):
+                 det_mode=_lib.DET_FARFIELD, normalize_fft=False, h_free=None, loss_type=_lib.LOSS_LSQ, poisson_multiplier=1.0, unknown_type='delta_beta'):
         self.ctx = ctx
         d = _lib.PlanDesc()
         d.obj_y, d.obj_x, d.obj_z = [int(v) for v in obj_size]
@@ -150,6 +150,7 @@ class Plan(object):
         d.binning, d.n_modes, d.sign_convention = int(binning), int(n_modes), int(sign_convention)
         d.det_mode, d.normalize_fft, d.k1 = int(det_mode), int(bool(normalize_fft)), float(k1)
         d.loss_type, d.poisson_multiplier = int(loss_type), float(poisson_multiplier)
+        d.unknown_type = {'delta_beta': 0, 'real_imag': 1}[unknown_type]
         h = np.asarray(h)
         # h_real / h_imag are cast separately to fp32, as in adorym/propagate.py:202-204
         self._h = (np.ascontiguousarray(h.real, dtype=np.float32), np.ascontiguousarray(h.imag, dtype=np.float32))

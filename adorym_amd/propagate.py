@@ -80,7 +80,7 @@ class MultisliceEngine(object):
 
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
-                 n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1.):
+                 n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta'):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -108,11 +108,18 @@ class MultisliceEngine(object):
                          n_modes=n_probe_modes, sign_convention=sign_convention, det_mode=det,
                          normalize_fft=normalize_fft, h_free=h_free,
                          loss_type={'lsq': _lib.LOSS_LSQ, 'poisson': _lib.LOSS_POISSON}[loss_function_type],
-                         poisson_multiplier=poisson_multiplier)
+                         poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
+        self.unknown_type = unknown_type
         self.loss_function_type = loss_function_type
         self.pads = pads
         self.n_probe_modes = int(n_probe_modes)
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
+        if unknown_type == 'real_imag':
+            # pad_object pads a real_imag object with 1 + 0i (adorym/util.py:1338-1350): vacuum transmission
+            fill = np.zeros(self.plan.rot_shape, np.float32)
+            fill[..., 0] = 1.0
+            self.obj_rot.set(fill)
+            del fill
         self.grad_rot = ctx.zeros(self.plan.rot_shape)      # rows of the current batch are overwritten each call
         self.max_batch = 0
         self._accumulated = False

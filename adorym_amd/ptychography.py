@@ -164,7 +164,15 @@ def reconstruct_ptychography(
     _not_implemented(distribution_mode is not None, "distribution_mode='%s'" % distribution_mode)
     _not_implemented(cpu_only, 'cpu_only=True (there is no CPU fallback)')
     _not_implemented(run_bfloat16 or run_float64, 'run_bfloat16 / run_float64')
-    _not_implemented(unknown_type != 'delta_beta', "unknown_type='%s'" % unknown_type)
+    if unknown_type not in ('delta_beta', 'real_imag'):
+        raise ValueError("unknown_type must be 'delta_beta' or 'real_imag'")
+    if unknown_type == 'real_imag':
+        # accelerated subset for complex-transmission unknowns: no regularisers / masks / object-type constraints yet
+        _not_implemented(regularizers not in (None, []) or alpha_d not in (0, None) or alpha_b not in (0, None) or gamma not in (0, None),
+                         "regularisers with unknown_type='real_imag' (pass gamma=0, alpha_d=0, alpha_b=0)")
+        _not_implemented(finite_support_mask_path is not None, "finite support mask with unknown_type='real_imag'")
+        _not_implemented(object_type != 'normal', "object_type='%s' with unknown_type='real_imag'" % object_type)
+        _not_implemented(binning != 1, "binning > 1 with unknown_type='real_imag'")
     _not_implemented(multiscale_level != 1, 'multiscale_level > 1')
     _not_implemented(pure_projection or forward_algorithm != 'fresnel', 'pure_projection / CTF forward algorithm')
     _not_implemented(use_epie, 'ePIE')
@@ -267,7 +275,8 @@ def reconstruct_ptychography(
     engine = MultisliceEngine(ctx, this_obj_size, probe_size, probe_pos_int, energy_ev, psize_cm, free_prop_cm=free_prop_cm,
                               binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
                               normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
-                              max_batch=minibatch_size, loss_function_type=loss_function_type, poisson_multiplier=poisson_multiplier)
+                              max_batch=minibatch_size, loss_function_type=loss_function_type, poisson_multiplier=poisson_multiplier,
+                              unknown_type=unknown_type)
 
     # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
     # (the reference caches them as .npy files in ./arrsize_*; no files are written here)
@@ -316,7 +325,8 @@ def reconstruct_ptychography(
         opt.create_container([*this_obj_size, 2], use_checkpoint, ctx)
     obj = ObjectFunction([*this_obj_size, 2], distribution_mode=distribution_mode, output_folder=output_folder, ds_level=ds_level,
                          object_type=object_type, device=ctx)
-    init = ObjectFunction.initial_values(this_obj_size, initial_guess, random_guess_means_sigmas, object_type, non_negativity)
+    init = ObjectFunction.initial_values(this_obj_size, initial_guess, random_guess_means_sigmas, object_type, non_negativity,
+                                         unknown_type=unknown_type)
     init = comm.bcast_object(init, root=0) if (initial_guess is None and n_ranks > 1) else init
     obj.arr = state.obj.view(0, (*this_obj_size, 2))
     obj.arr.set(init)
@@ -382,7 +392,7 @@ def reconstruct_ptychography(
                     ds_level=ds_level, device=ctx)
         mask_arr = finite_support_mask_path if isinstance(finite_support_mask_path, np.ndarray) else read_tiff(finite_support_mask_path)
         mask.initialize_array_with_values(mask_arr, device=ctx)
-    flags = constraint_flags(non_negativity, object_type)
+    flags = constraint_flags(non_negativity and unknown_type == 'delta_beta', object_type)   # (ptychography.py:1138)
 
     # ---- probe (ptychography.py:607-667) -------------------------------------------------------------------
     if rank == 0:
@@ -611,8 +621,12 @@ def reconstruct_ptychography(
         # ---- outputs after an epoch (ptychography.py:1290-1294; util.py:1958-2028) ----
         if rank == 0:
             arr = obj.arr.get()
-            write_tiff(arr[..., 0], os.path.join(output_folder, 'delta_ds_{}'.format(ds_level)), dtype='float32')
-            write_tiff(arr[..., 1], os.path.join(output_folder, 'beta_ds_{}'.format(ds_level)), dtype='float32')
+            if unknown_type == 'delta_beta':
+                write_tiff(arr[..., 0], os.path.join(output_folder, 'delta_ds_{}'.format(ds_level)), dtype='float32')
+                write_tiff(arr[..., 1], os.path.join(output_folder, 'beta_ds_{}'.format(ds_level)), dtype='float32')
+            else:   # util.py:1990-2005
+                write_tiff(np.sqrt(arr[..., 0] ** 2 + arr[..., 1] ** 2), os.path.join(output_folder, 'obj_mag_ds_{}'.format(ds_level)), dtype='float32')
+                write_tiff(np.arctan2(arr[..., 1], arr[..., 0]), os.path.join(output_folder, 'obj_phase_ds_{}'.format(ds_level)), dtype='float32')
             pa = probe_dev.get()
             pc = pa[..., 0] + 1j * pa[..., 1]
             write_tiff(np.abs(pc), os.path.join(output_folder, 'probe_mag_ds_{}'.format(ds_level)), dtype='float32')

@@ -94,6 +94,9 @@ typedef struct {
     const float* hfree_im;            /*   (adorym/propagate.py:537-553), else NULL                   */
     int32_t loss_type;                /* adm_loss_type: LSQ on magnitudes, or Poisson (adorym/forward_model.py:88-103) */
     float   poisson_multiplier;       /* forward_model.py:94-102; ignored for LSQ                     */
+    int32_t unknown_type;             /* 0 'delta_beta': slices hold (delta, beta), c = exp(-k1 beta) e^{-i sigma k1 delta};  */
+                                      /* 1 'real_imag': slices hold c = re + i im directly (adorym/propagate.py:236-249);     */
+                                      /*   the caller pre-fills the pads of obj_rot with (1, 0) (adorym/util.py:1338-1350)    */
 } adm_plan_desc;
 
 int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out);

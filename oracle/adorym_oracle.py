@@ -197,12 +197,16 @@ def calculate_pad_len(this_obj_size, probe_pos, probe_size):
     return pad_arr
 
 
-def extract_tiles(obj_rot, pos_batch, probe_size):
-    """pad_object (util.py:1327-1351, delta_beta: zero pad) + the tile stack of
+def extract_tiles(obj_rot, pos_batch, probe_size, unknown_type='delta_beta'):
+    """pad_object (util.py:1327-1351; delta_beta: zero pad, real_imag: pad with 1 + 0i) + the tile stack of
     forward_model.py:313-331.  Returns tiles [B, Py, Px, S, 2] and pad_arr."""
     pos = np.round(np.asarray(pos_batch)).astype(int)            # forward_model.py:248
     pad = calculate_pad_len(obj_rot.shape[:3], pos, probe_size)
     o = np.pad(obj_rot, [tuple(pad[0]), tuple(pad[1]), (0, 0), (0, 0)], mode='constant')
+    if unknown_type == 'real_imag':
+        inside = np.zeros(o.shape[:2], bool)
+        inside[pad[0, 0]:o.shape[0] - pad[0, 1], pad[1, 0]:o.shape[1] - pad[1, 1]] = True
+        o[~inside, :, 0] = 1
     tiles = np.stack([o[p[0] + pad[0, 0]: p[0] + pad[0, 0] + probe_size[0],
                         p[1] + pad[1, 0]: p[1] + pad[1, 0] + probe_size[1]] for p in pos])
     return tiles, pad
@@ -228,7 +232,7 @@ class Physics(object):
 
     def __init__(self, probe_size, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None,
-                 scale_ri_by_k=True):
+                 scale_ri_by_k=True, unknown_type='delta_beta'):
         self.probe_size = tuple(int(p) for p in probe_size)
         self.energy_ev = float(energy_ev)
         self.psize_cm = float(psize_cm)
@@ -236,6 +240,7 @@ class Physics(object):
         self.lmbda_nm = 1240. / energy_ev                            # propagate.py:148
         self.delta_nm = self.voxel_nm[-1]
         self.binning = int(binning)
+        self.unknown_type = unknown_type      # 'delta_beta' | 'real_imag' (propagate.py:236-249)
         self.sigma = int(sign_convention)
         self.normalize_fft = bool(normalize_fft)
         self.free_prop_cm = free_prop_cm
@@ -308,8 +313,12 @@ def _slice_sums(tiles, i_step, binning):
 
 
 def _modulator(delta_s, beta_s, phys, dtype):
-    """w.exp_complex(-k1*beta, -sigma*k1*delta) (propagate.py:241, wrappers.py:600-608)."""
+    """delta_beta: w.exp_complex(-k1*beta, -sigma*k1*delta) (propagate.py:241, wrappers.py:600-608);
+    real_imag: the slice itself, c = re + i*im (propagate.py:243-247; binning > 1 would multiply slices)."""
     dt = np.dtype(dtype)
+    if phys.unknown_type == 'real_imag':
+        assert phys.binning == 1
+        return (delta_s + 1j * beta_s).astype(_cdtype(dt))
     k1 = dt.type(phys.k1)
     e = np.exp(-k1 * beta_s)
     ph = -dt.type(phys.sigma) * k1 * delta_s
@@ -420,9 +429,13 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
         for i in range(n_steps - 1, -1, -1):
             d, b, lo, hi = _slice_sums(tiles, i, phys.binning)
             c = _modulator(d, b, phys, dt)
-            z = np.conj(G) * kept[i]
-            gb = (-k1 * z.real).astype(dt)
-            gd = (sg * k1 * z.imag).astype(dt)
+            if phys.unknown_type == 'real_imag':
+                zc = G * np.conj(kept[i] / c)          # G_c = G_psi' * conj(psi), psi = psi'/c the pre-modulation field
+                gd, gb = zc.real.astype(dt), zc.imag.astype(dt)
+            else:
+                z = np.conj(G) * kept[i]
+                gb = (-k1 * z.real).astype(dt)
+                gd = (sg * k1 * z.imag).astype(dt)
             grad_tiles[:, :, :, lo:hi, 0] += gd[..., None]
             grad_tiles[:, :, :, lo:hi, 1] += gb[..., None]
             G = (G * np.conj(c)).astype(cdt)
@@ -443,7 +456,7 @@ def forward_adjoint_object(obj, coords_fp16, probes, pos_batch, meas, phys, dtyp
     obj_rot = rotate_fwd(obj, coords_fp16, dt) if coords_fp16 is not None else obj
     probes = np.asarray(probes)
     psize = probes.shape[-2:]
-    tiles, _ = extract_tiles(obj_rot, pos_batch, psize)
+    tiles, _ = extract_tiles(obj_rot, pos_batch, psize, phys.unknown_type)
     loss, pred, gt, gp = forward_adjoint_tiles(tiles, probes, meas, phys, dt, **loss_kw)
     g_rot = scatter_tiles_adj(gt, pos_batch, obj.shape)
     g_obj = rotate_adj(g_rot, coords_fp16, dt) if coords_fp16 is not None else g_rot

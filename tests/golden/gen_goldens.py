@@ -422,8 +422,50 @@ def gen_f9():
     save('F9_variants', **out)
 
 
+# ----------------------------------------------------------------------------- F10 (unknown_type='real_imag')
+def gen_f10():
+    """multislice_propagate_batch(type='real_imag') (propagate.py:243-249): slices ARE the complex transmission."""
+    out = {}
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    r = cases.rng(10)
+    shape = c['guess'].shape[:-1]
+    mag = 1.0 - 0.2 * r.uniform(size=shape)
+    ph = 0.8 * r.uniform(-1, 1, size=shape)
+    tiles = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    out['tiles'] = tiles
+    for fp in ('inf', 0):
+        meas = None
+        for fp64 in (True, False):
+            gs.run_fp64 = fp64
+            dt = torch.float64 if fp64 else torch.float32
+            t = torch.tensor(tiles, dtype=dt, requires_grad=True)
+            pr = torch.tensor(c['probes'][0].real.copy(), dtype=dt, requires_grad=True)
+            pi = torch.tensor(c['probes'][0].imag.copy(), dtype=dt, requires_grad=True)
+            ex_r, ex_i = multislice_propagate_batch(t, pr, pi, cases.ENERGY_EV, cases.PSIZE_CM, kernel=None, free_prop_cm=fp,
+                                                    binning=1, type='real_imag')
+            pred = w.norm(ex_r, ex_i)
+            if meas is None:
+                meas = (pred.detach().numpy() * (1 + 0.3 * cases.rng(11).uniform(-1, 1, size=pred.shape))).copy()
+                out['meas_%s' % fp] = meas
+            loss = w.mean((pred - torch.tensor(meas, dtype=dt)) ** 2)
+            g = torch.autograd.grad(loss, [t, pr, pi])
+            tag = '%s_%s' % (fp, '64' if fp64 else '32')
+            out['pred_' + tag] = pred.detach().numpy()
+            out['loss_' + tag] = np.array(loss.item())
+            out['grad_tiles_' + tag] = g[0].numpy()
+            out['grad_probe_real_' + tag] = g[1].numpy()
+            out['grad_probe_imag_' + tag] = g[2].numpy()
+    gs.run_fp64 = False
+    # padding semantics of pad_object for real_imag (util.py:1338-1350): real part padded with 1, imaginary with 0
+    o = torch.tensor(cases.rng(12).standard_normal((5, 6, 2, 2)))
+    padded, pad_arr = U.pad_object(o, [5, 6, 2], np.array([[-2, -1], [3, 4]]), [4, 4], unknown_type='real_imag')
+    out['pad_in'] = o.numpy(); out['pad_out'] = padded.numpy(); out['pad_arr'] = pad_arr
+    save('F10_real_imag', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9']
+    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -432,3 +474,4 @@ if __name__ == '__main__':
     if 'f8' in which: gen_f8()
     if 'f6' in which: gen_f6()
     if 'f9' in which: gen_f9()
+    if 'f10' in which: gen_f10()

@@ -1,6 +1,7 @@
 """Edge cases of the C ABI and the host layer on the GPU: error behaviour, ragged / overhanging inputs,
 forward-only and binned paths, determinism of the gradient path, full-field (config-2 shape) run."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -182,3 +183,32 @@ def test_two_d_mode_config1_shape_driver_vs_oracle(A, ctx, tmp_path):
     assert len(st['losses']) == len(losses) and np.allclose(st['losses'], losses, rtol=2e-4)
     upd = np.linalg.norm(ref - np.stack(guess, -1))
     assert np.linalg.norm(x - ref) < 5e-3 * upd, np.linalg.norm(x - ref) / upd
+
+
+def test_two_d_real_imag_driver_vs_oracle(A, ctx, tmp_path):
+    """Config 1's unknown type: 2-D ptychography with a complex-transmission object (unknown_type='real_imag'),
+    guess given as (magnitude, phase) and converted like the reference (adorym/util.py:118-122)."""
+    r = cases.rng(97)
+    Y, X, P = 44, 40, 16
+    mag_t = 1 - 0.3 * cases.smooth_field((Y, X, 1), 98)
+    ph_t = 0.8 * cases.smooth_field((Y, X, 1), 99)
+    truth = np.stack([mag_t * np.cos(ph_t), mag_t * np.sin(ph_t)], -1)
+    guess = [np.full((Y, X, 1), 0.9), np.full((Y, X, 1), 0.1)]
+    pos = np.array([(y, x) for y in range(-4, 36, 8) for x in range(-4, 32, 8)], dtype=float)
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    phys = O.Physics((P, P), 8000., 1e-6, unknown_type='real_imag')
+    tiles, _ = O.extract_tiles(truth, pos, (P, P), 'real_imag')
+    prj = np.abs(O.multislice_forward(tiles, probe, phys, 'float64'))[None].astype(np.float32)
+    st = A.reconstruct_ptychography(fname=prj, obj_size=(Y, X, 1), probe_pos=pos, energy_ev=8000., psize_cm=1e-6, free_prop_cm='inf',
+                                    unknown_type='real_imag', probe_type='supplied', probe_initial=[np.abs(probe), np.angle(probe)],
+                                    initial_guess=guess, minibatch_size=5, n_epochs=2, optimizer='adam', learning_rate=1e-3, gamma=0,
+                                    alpha_d=0, alpha_b=0, save_path=str(tmp_path), output_folder='ri', store_checkpoint=False,
+                                    use_checkpoint=False, return_state=True)
+    g0 = guess[0] * np.exp(1j * guess[1])
+    ref, losses, _ = O.reconstruct(prj.astype(np.float64), [g0.real, g0.imag], probe, pos, np.zeros(1, 'float32'), phys, n_epochs=2,
+                                   minibatch_size=5, optimizer='adam', learning_rate=1e-3, dtype='float64', two_d_mode=True, return_trace=True)
+    x = np.stack([st['delta'], st['beta']], -1)
+    assert np.allclose(st['losses'], losses, rtol=2e-4)
+    upd = np.linalg.norm(ref - np.stack([g0.real, g0.imag], -1))
+    assert np.linalg.norm(x - ref) < 5e-3 * upd
+    assert sorted(f for f in os.listdir(st['output_folder']) if f.startswith('obj_')) == ['obj_mag_ds_1.tiff', 'obj_phase_ds_1.tiff']

@@ -402,3 +402,45 @@ def test_probe_modes_vs_reference_and_oracle(A, ctx, free_prop_cm):
     # forward-only (predict) path with modes
     eng.multislice(d_probe, want_grad=False, want_pred=True)
     assert rel(eng.pred(), pred_ref) < 2e-6
+
+
+# --------------------------------------------------------------------------- unknown_type = 'real_imag'
+@pytest.mark.parametrize('fp', ['inf', 0])
+def test_real_imag_vs_reference(A, ctx, fp):
+    """Slices hold the complex transmission (adorym/propagate.py:243-249); pads are 1 + 0i (util.py:1338-1350)."""
+    g = load('F10_real_imag')
+    c = cases.tile_case_inputs('p12_s9_far_pos')
+    P, S, B = 12, 9, cases.TILE_B
+    obj = g['tiles'].reshape(B * P, P, S, 2)
+    pos = np.array([(b * P, 0) for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (B * P, P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=fp, unknown_type='real_imag')
+    d_grad = ctx.zeros(obj.shape)
+    d_gp = ctx.zeros((P, P, 2))
+    eng.set_batch(pos, g['meas_%s' % fp])
+    eng.rotate(ctx.array(obj, np.float32), None)
+    eng.multislice(ctx.array(c2(c['probes'][0])), grad_probe=d_gp, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    tag = '%s_' % fp
+    assert rel(eng.pred(), g['pred_' + tag + '64']) < 2e-6
+    assert abs(eng.loss() - g['loss_' + tag + '64']) <= 1e-5 * abs(g['loss_' + tag + '64'])
+    e, e_ref = rel(d_grad.get().reshape(B, P, P, S, 2), g['grad_tiles_' + tag + '64']), rel(g['grad_tiles_' + tag + '32'], g['grad_tiles_' + tag + '64'])
+    assert e < 1e-4 and e <= 3 * e_ref + 1e-5, (e, e_ref)
+    gp64 = np.stack([g['grad_probe_real_' + tag + '64'], g['grad_probe_imag_' + tag + '64']], -1)
+    assert rel(d_gp.get(), gp64) < 1e-4
+
+
+def test_real_imag_overhanging_tiles_vs_oracle(A, ctx):
+    r = cases.rng(95)
+    N, P, S = 20, 12, 4
+    mag, ph = 1 - 0.2 * r.uniform(size=(N, N, S)), 0.5 * r.uniform(-1, 1, (N, N, S))
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    pos = np.array([(-5, -5), (12, 14), (3, 2)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    phys = O.Physics((P, P), 5000., 1e-7, unknown_type='real_imag')
+    target = np.abs(r.standard_normal((3, P, P))) * 6
+    loss_o, _, g_o, _ = O.forward_adjoint_object(obj, None, probe, pos, target, phys, 'float64')
+    eng = A.MultisliceEngine(ctx, (N, N, S), (P, P), pos, 5000., 1e-7, unknown_type='real_imag')
+    d_grad = ctx.zeros(obj.shape)
+    loss = eng.loss_and_grad(ctx.array(obj, np.float32), d_grad, None, ctx.array(c2(probe)), pos, target)
+    assert abs(loss - loss_o) <= 1e-5 * abs(loss_o)
+    assert rel(d_grad.get(), g_o) < 1e-4

@@ -268,3 +268,25 @@ def test_f9_reweighted_l1():
     assert rel(wgt, g['rwl1_weight']) < 1e-13
     val, grad = O.reweighted_l1_value_grad(g['rwl1_obj'], wgt, 0.8, 0.3)
     assert abs(val - g['rwl1_val']) < 1e-13 * abs(g['rwl1_val']) and rel(grad, g['rwl1_grad']) < 1e-12
+
+
+# ------------------------------------------------------------------ F10 (unknown_type = 'real_imag')
+@pytest.mark.parametrize('fp', ['inf', 0])
+def test_f10_real_imag(fp):
+    g = load('F10_real_imag')
+    c = cases.tile_case_inputs('p12_s9_far_pos')
+    phys = O.Physics((12, 12), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=fp, unknown_type='real_imag')
+    loss, pred, gt, gp = O.forward_adjoint_tiles(g['tiles'], c['probes'], g['meas_%s' % fp], phys, 'float64')
+    tag = '%s_64' % fp
+    assert rel(pred, g['pred_' + tag]) < 1e-12 and abs(loss - g['loss_' + tag]) <= 1e-12 * abs(g['loss_' + tag])
+    assert rel(gt, g['grad_tiles_' + tag]) < 1e-11
+    assert rel(gp[0].real, g['grad_probe_real_' + tag]) < 1e-11 and rel(gp[0].imag, g['grad_probe_imag_' + tag]) < 1e-11
+
+
+def test_f10_real_imag_padding():
+    g = load('F10_real_imag')
+    tiles, pad = O.extract_tiles(g['pad_in'], np.array([[-2, -1], [3, 4]]), (4, 4), 'real_imag')
+    assert np.array_equal(pad, g['pad_arr'])
+    padded = g['pad_out']
+    for b, p_ in enumerate(np.array([[-2, -1], [3, 4]])):
+        assert np.array_equal(tiles[b], padded[p_[0] + pad[0, 0]: p_[0] + pad[0, 0] + 4, p_[1] + pad[1, 0]: p_[1] + pad[1, 0] + 4])
