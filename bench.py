@@ -55,10 +55,35 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         done += nb
         if t_used > 0.5 * seconds_budget or done >= 64:
             break
-    return {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
-                      '(oracle/adorym_oracle.py), rotation and optimiser excluded, %.1f s of CPU work, host has %d cores'
-                      % (done, P, S, t_used, os.cpu_count())}
+    out = {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
+           'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
+                     '(oracle/adorym_oracle.py), rotation and optimiser excluded, %.1f s of CPU work, host has %d cores'
+                     % (done, P, S, t_used, os.cpu_count())}
+    try:
+        out['reference_structured'] = cpu_baseline_torch(cfg, phys, probe)
+    except Exception as e:      # a reported extra, never fatal for the bench line
+        out['reference_structured'] = {'error': repr(e)}
+    return out
+
+
+def cpu_baseline_torch(cfg, phys, probe, nb=2):
+    """Second flavour (SURVEY.md 8d ii): the reference's own op structure -- PyTorch-CPU tensors, separate re/im,
+    strided slice selects, torch.autograd.grad -- restated in oracle/torch_structured.py and timed on all host cores
+    for one bounded minibatch of the same workload (full 256^3 object, tile gather + fwd + autograd backward)."""
+    import torch
+    from oracle import torch_structured as T
+    Y, X, Z = cfg['obj_size']
+    r = np.random.default_rng(1)
+    obj = np.stack([r.normal(8.7e-7, 1e-7, (Y, X, Z)), r.normal(5.1e-8, 1e-8, (Y, X, Z))], -1).astype(np.float32)
+    pos = cfg['probe_pos'][:nb].astype(int)
+    meas = np.abs(r.standard_normal((nb,) + tuple(cfg['probe_size']))).astype(np.float32)
+    T.loss_and_grad(obj[:, :, :4], pos, probe, phys.h, phys.k1, meas)          # warm-up (thread pool, FFT plans)
+    t0 = time.perf_counter()
+    T.loss_and_grad(obj, pos, probe, phys.h, phys.k1, meas)
+    dt = time.perf_counter() - t0
+    return {'value': nb / dt, 'unit': 'probe-positions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d positions of config 3 (256^3 object, P=72, 256 slices): tile gather + fwd + torch.autograd backward, fp32, '
+                      'reference op structure (oracle/torch_structured.py), %.1f s, torch %s' % (nb, dt, torch.__version__)}
 
 
 def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=3):

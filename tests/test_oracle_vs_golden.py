@@ -290,3 +290,22 @@ def test_f10_real_imag_padding():
     padded = g['pad_out']
     for b, p_ in enumerate(np.array([[-2, -1], [3, 4]])):
         assert np.array_equal(tiles[b], padded[p_[0] + pad[0, 0]: p_[0] + pad[0, 0] + 4, p_[1] + pad[1, 0]: p_[1] + pad[1, 0] + 4])
+
+
+def test_torch_structured_matches_oracle():
+    """The reference-structured PyTorch-autograd CPU baseline (oracle/torch_structured.py, bench.py's second
+    cpu_baseline flavour) computes the same loss / object gradient as the pinned NumPy oracle."""
+    import torch
+    from oracle import torch_structured as T
+    r = cases.rng(404)
+    Y, X, S, P, B = 20, 22, 5, 12, 3
+    obj = np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1)
+    pos = np.array([[-3, 2], [5, 12], [9, -1]])
+    probe = r.standard_normal((P, P)) + 1j * r.standard_normal((P, P))
+    meas = np.abs(r.standard_normal((B, P, P))) * 5
+    for ff in ('inf', 0):
+        phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=ff)
+        loss, g = T.loss_and_grad(obj, pos, probe, phys.h, phys.k1, meas, far_field=(ff == 'inf'), dtype=torch.float64)
+        l0, _, g0, _ = O.forward_adjoint_object(obj, None, probe, pos, meas, phys, 'float64')
+        assert abs(loss - l0) <= 1e-12 * abs(l0)
+        assert np.linalg.norm(g - g0) <= 1e-10 * np.linalg.norm(g0)
