@@ -329,7 +329,8 @@ def multislice_forward(tiles, probe, phys, dtype='float64', keep=False):
     """
     multislice_propagate_batch, non-projection delta_beta branch (propagate.py:195-270).
 
-    tiles [B,Py,Px,S,2]; probe complex [Py,Px] (one mode).  Returns the detector-plane
+    tiles [B,Py,Px,S,2]; probe complex [Py,Px] (one mode) or [B,Py,Px] (one, e.g. Fourier-shifted, probe per
+    position, forward_model.py:296-311).  Returns the detector-plane
     complex field [B,Py,Px] (and, with keep=True, the list of post-modulation fields psi'_s).
     """
     dt = np.dtype(dtype)
@@ -339,7 +340,8 @@ def multislice_forward(tiles, probe, phys, dtype='float64', keep=False):
     S = tiles.shape[3]
     n_steps = int(np.ceil(S / phys.binning))
     h = phys.h_cast(dt)
-    psi = np.broadcast_to(probe.astype(cdt), (B,) + probe.shape).copy()
+    probe = np.asarray(probe)
+    psi = probe.astype(cdt).copy() if probe.ndim == 3 else np.broadcast_to(probe.astype(cdt), (B,) + probe.shape).copy()
     kept = []
     for i in range(n_steps):
         d, b, lo, hi = _slice_sums(tiles, i, phys.binning)
@@ -387,8 +389,25 @@ def _dloss_dpred(pred, meas, loss_function_type, raw_data_type, poisson_multipli
     return (2. * pred * poisson_multiplier - a * poisson_multiplier * 2. / pred) / n
 
 
+def fourier_shift_phase(shape, shift, dtype):
+    """The multiplier of realign_image_fourier (util.py:380-390): exp(-2 PI i (fx*shift[1] + fy*shift[0])), PI = 3.14159265359,
+    frequencies and the argument evaluated in ``dtype`` like the reference's tensors."""
+    dt = np.dtype(dtype)
+    fy = np.fft.fftfreq(shape[0], 1).astype(dt)[:, None]
+    fx = np.fft.fftfreq(shape[1], 1).astype(dt)[None, :]
+    arg = (dt.type(-2) * dt.type(PI)) * (fx * dt.type(shift[1]) + fy * dt.type(shift[0]))
+    return (np.cos(arg) + 1j * np.sin(arg)).astype(_cdtype(dt))
+
+
+def fourier_shift(probes, shift, dtype='float64'):
+    """realign_image_fourier(probe_real, probe_imag, shift, axes=(1, 2)) on complex probes [..., Py, Px]."""
+    cdt = _cdtype(np.dtype(dtype))
+    ph = fourier_shift_phase(probes.shape[-2:], shift, dtype)
+    return np.fft.ifft2((np.fft.fft2(np.asarray(probes).astype(cdt)).astype(cdt) * ph).astype(cdt)).astype(cdt)
+
+
 def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_function_type='lsq',
-                          raw_data_type='magnitude', poisson_multiplier=1.):
+                          raw_data_type='magnitude', poisson_multiplier=1., shifts=None):
     """
     Loss + hand-derived gradient w.r.t. the tiles and the probe(s).  Replaces
     ``torch.autograd.grad`` (wrappers.py:322) over forward_model.py:337-375 +
@@ -396,6 +415,10 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
 
     Returns loss, pred [B,Py,Px], grad_tiles [B,Py,Px,S,2], grad_probes complex [M,Py,Px]
     (real part = dL/dprobe_real, imag part = dL/dprobe_imag).
+
+    ``shifts`` [B,2] (optional): sub-pixel probe position corrections; position b sees every mode Fourier-shifted by
+    shifts[b] (forward_model.py:296-311).  A fifth return value dL/dshifts [B,2] is appended and the probe gradient
+    is taken through the shift.
     """
     dt = np.dtype(dtype)
     cdt = _cdtype(dt)
@@ -407,7 +430,12 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
     n_steps = int(np.ceil(S / phys.binning))
     h = phys.h_cast(dt)
     fields, kepts = [], []
-    for p in probes:
+    if shifts is not None:
+        phases = np.stack([fourier_shift_phase(probes.shape[-2:], sh, dt) for sh in shifts])      # [B,Py,Px]
+        spectra = np.fft.fft2(probes.astype(cdt)).astype(cdt)                                      # [M,Py,Px]
+    for m, p in enumerate(probes):
+        if shifts is not None:
+            p = np.fft.ifft2((spectra[m][None] * phases).astype(cdt)).astype(cdt)                  # [B,Py,Px]
         f, k = multislice_forward(tiles, p, phys, dt, keep=True)
         fields.append(f)
         kepts.append(k)
@@ -441,7 +469,22 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
             G = (G * np.conj(c)).astype(cdt)
             if i > 0:
                 G = np.fft.ifft2(np.fft.fft2(G) * np.conj(h)).astype(cdt)
-        grad_probes[m] = G.sum(axis=0)
+        if shifts is None:
+            grad_probes[m] = G.sum(axis=0)
+        else:
+            # p_b = IFFT2(Phi_b * F), F = FFT2(p):  dL/dp = IFFT2(sum_b conj(Phi_b) FFT2(G_b));
+            # dL/ds = 2 PI sum_k f_k Im(conj(Ghat_k) Phi_k F_k),  Ghat = FFT2(G_b) / (Py Px)
+            Gh = np.fft.fft2(G)
+            grad_probes[m] = np.fft.ifft2((np.conj(phases) * Gh).sum(axis=0))
+            t = np.imag(np.conj(Gh / (Py * Px)) * phases * spectra[m][None])
+            fy = np.fft.fftfreq(Py, 1)[:, None]
+            fx = np.fft.fftfreq(Px, 1)[None, :]
+            if m == 0:
+                grad_shifts = np.zeros((B, 2), dtype=dt)
+            grad_shifts[:, 0] += 2 * PI * (t * fy).sum(axis=(1, 2))
+            grad_shifts[:, 1] += 2 * PI * (t * fx).sum(axis=(1, 2))
+    if shifts is not None:
+        return loss, pred, grad_tiles, grad_probes, grad_shifts
     return loss, pred, grad_tiles, grad_probes
 
 
@@ -494,6 +537,55 @@ def tv_value_grad(obj, gamma):
             s = np.sign(d)
             # d/da[i] of |a[i-1]-a[i]| = -s[i];  of |a[i]-a[i+1]| = +s[i+1]
             g[..., ch] += gamma * (np.roll(s, -1, axis=ax) - s) / V
+    return val, g
+
+
+def _tv_core(a):
+    """value*V and d/da of sum_axes sum|roll(a,1,ax) - a| for one scalar field."""
+    val = 0.
+    g = np.zeros_like(a)
+    for ax in range(3):
+        d = np.roll(a, 1, axis=ax) - a
+        val += np.sum(np.abs(d))
+        sgn = np.sign(d)
+        g += np.roll(sgn, -1, axis=ax) - sgn
+    return val, g
+
+
+def tv_value_grad_ri(obj, gamma):
+    """TVRegularizer, real_imag branch (regularizers.py:105-110): gamma * (TV(r^2 + i^2) + TV(arctan2(i, r)))."""
+    r, i = obj[..., 0], obj[..., 1]
+    V = r.size
+    u = r ** 2 + i ** 2
+    ph = np.arctan2(i, r)
+    vu, gu = _tv_core(u)
+    vp, gp = _tv_core(ph)
+    g = np.zeros_like(obj)
+    g[..., 0] = gamma * (gu * 2 * r - gp * i / u) / V
+    g[..., 1] = gamma * (gu * 2 * i + gp * r / u) / V
+    return gamma * (vu + vp) / V, g
+
+
+def l1_value_grad_ri(obj, alpha_d, alpha_b):
+    """L1Regularizer, real_imag branch (regularizers.py:38-45): alpha_d*mean| |o| - mean|o| | + alpha_b*mean|arg o|."""
+    r, i = obj[..., 0], obj[..., 1]
+    V = r.size
+    val = 0.
+    g = np.zeros_like(obj)
+    om = np.sqrt(r ** 2 + i ** 2)
+    if alpha_d not in (None, 0):
+        dev = om - om.mean()
+        val += alpha_d * np.mean(np.abs(dev))
+        sg = np.sign(dev)
+        gom = alpha_d * (sg - sg.mean()) / V            # d/d om_j of mean_k |om_k - mean(om)|
+        g[..., 0] += gom * r / om
+        g[..., 1] += gom * i / om
+    if alpha_b not in (None, 0):
+        ph = np.arctan2(i, r)
+        val += alpha_b * np.mean(np.abs(ph))
+        gph = alpha_b * np.sign(ph) / V
+        g[..., 0] += -gph * i / om ** 2
+        g[..., 1] += gph * r / om ** 2
     return val, g
 
 
@@ -590,6 +682,42 @@ def gaussian_probe(size, mag_sigma, phase_sigma, phase_max):
 # --------------------------------------------------------------------------------------
 # R17  DP-mode task list
 # --------------------------------------------------------------------------------------
+def generate_disk(shape, radius):
+    """util.py:1484-1492: soft-edged disk, clip(radius - r, 0, 1) with r measured from the array centre."""
+    radius = int(radius)
+    x = np.arange(shape[1]) - (shape[1] - 1) / 2
+    y = np.arange(shape[0]) - (shape[0] - 1) / 2
+    xx, yy = np.meshgrid(x, y)
+    return np.clip(radius - np.sqrt(xx ** 2 + yy ** 2), 0, 1)
+
+
+def aperture_defocus_probe(probe_size, aperture_radius, probe_defocus_cm, lmbda_nm, psize_cm, beamstop_radius=0, sign_convention=1):
+    """initialize_probe, 'aperture_defocus' branch (util.py:205-222): disk aperture (minus a beamstop disk) Fresnel-
+    propagated by the defocus distance with get_kernel / convolve_with_transfer_function, fp64."""
+    mag = generate_disk(probe_size, aperture_radius)
+    if beamstop_radius > 0:
+        mag = mag * (1 - generate_disk(probe_size, beamstop_radius))
+    h = get_kernel(probe_defocus_cm * 1e7, lmbda_nm, [psize_cm * 1e7] * 3, probe_size, sign_convention=sign_convention)
+    return np.fft.ifft2(np.fft.fft2(mag.astype(np.complex128)) * h)
+
+
+def rescale_probe(probe, data_first_angle, raw_data_type='magnitude', normalize_fft=False, sign_convention=1):
+    """initialize_probe, rescale_intensity tail (util.py:254-281).  ``probe`` complex [Py,Px] or [M,Py,Px];
+    ``data_first_angle`` = exchange/data[0:1].  Reproduces the reference's `len(probe_real) == 3` test (the per-mode
+    normalisation only triggers for exactly three modes... or a 3-row probe)."""
+    dat = np.asarray(data_first_angle, dtype=np.float64)
+    if raw_data_type == 'magnitude':
+        dat = dat ** 2
+    npix = np.prod(probe.shape[-2:])
+    target = np.sum(np.mean(np.abs(dat), axis=(0, 1)))
+    if not normalize_fft:
+        target = target / npix if sign_convention == 1 else target * npix
+    current = np.sum(probe.real ** 2 + probe.imag ** 2)
+    if len(probe) == 3:
+        current /= probe.shape[0]
+    return probe * np.sqrt(target / current)
+
+
 def split_tasks(arr, split_size):
     """adorym/util.py:1629-1635."""
     res = []
@@ -723,3 +851,65 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
     if return_trace:
         return obj, losses, first_grad
     return obj
+
+
+def reconstruct_2d(prj, obj_init, probes, probe_pos, phys, n_epochs=1, minibatch_size=1, learning_rate=1e-3,
+                   gamma=None, alpha_d=None, alpha_b=None, raw_data_type='magnitude', optimize_probe=False,
+                   probe_learning_rate=1e-3, optimize_all_probe_pos=False, all_probe_pos_learning_rate=1e-2,
+                   dtype='float64', return_trace=False):
+    """
+    reconstruct_ptychography in two_d_mode with the config-1 feature set (ptychography.py:783-1295 +
+    optimizers.py:1000-1049): complex-transmission or delta/beta object [Y,X,1,2] updated by Adam, optional Adam
+    on the probe modes and on the per-position sub-pixel corrections (re-centred after every update), regularisers
+    of either unknown type.  ``obj_init`` = (channel0, channel1) already in the unknown's representation;
+    ``probes`` complex [M,Py,Px]; ``probe_pos`` float [n_pos,2] (non-integer parts become the initial corrections).
+    """
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
+    m, v = np.zeros_like(obj), np.zeros_like(obj)
+    probes = np.asarray(probes).astype(cdt)
+    pst = np.stack([probes.real, probes.imag], -1).astype(dt)
+    pm, pv = np.zeros_like(pst), np.zeros_like(pst)
+    probe_pos = np.asarray(probe_pos, dtype=float)
+    n_pos = len(probe_pos)
+    pos_int = np.round(probe_pos).astype(int)
+    corr = np.tile(probe_pos - pos_int, [1, 1, 1]).astype(dt)               # [n_theta=1, n_pos, 2]
+    cm, cv = np.zeros_like(corr), np.zeros_like(corr)
+    ri = phys.unknown_type == 'real_imag'
+    losses, first_grad = [], None
+    for i_epoch in range(n_epochs):
+        batches = epoch_task_list(i_epoch, 1, n_pos, minibatch_size, 1, 'immediate', two_d_mode=True)
+        n_batch = len(batches)
+        i_opt_batch = 0
+        for i_batch in range(n_batch):
+            _, ind = rank_batch(batches, i_batch, 0, minibatch_size, 1)
+            use_shift = optimize_all_probe_pos or np.any(corr > 1e-3)
+            tiles, _ = extract_tiles(obj, pos_int[ind], probes.shape[-2:], phys.unknown_type)
+            pc = (pst[..., 0] + 1j * pst[..., 1]).astype(cdt)
+            res = forward_adjoint_tiles(tiles, pc, prj[0, ind], phys, dt, raw_data_type=raw_data_type,
+                                        shifts=corr[0, ind] if use_shift else None)
+            loss, gt, gp = res[0], res[2], res[3]
+            g = scatter_tiles_adj(gt, pos_int[ind], obj.shape)
+            if alpha_d not in (None, 0) or alpha_b not in (None, 0):
+                rv, rg = (l1_value_grad_ri if ri else l1_value_grad)(obj, alpha_d, alpha_b)
+                loss += rv; g = g + rg
+            if gamma not in (None, 0):
+                rv, rg = (tv_value_grad_ri if ri else tv_value_grad)(obj, gamma)
+                loss += rv; g = g + rg
+            if first_grad is None:
+                first_grad = g.copy()
+            obj, m, v = adam_step(obj, g.astype(dt), m, v, i_opt_batch, step_size=learning_rate)
+            if optimize_probe:
+                pst, pm, pv = adam_step(pst, np.stack([gp.real, gp.imag], -1).astype(dt), pm, pv, i_opt_batch,
+                                        step_size=probe_learning_rate)
+            if optimize_all_probe_pos:
+                gc = np.zeros_like(corr)
+                gc[0, ind] = res[4]
+                corr, cm, cv = adam_step(corr, gc, cm, cv, i_opt_batch, step_size=all_probe_pos_learning_rate)
+                corr = corr - corr.mean(axis=(0, 1))
+            losses.append(float(loss))
+            if i_batch == n_batch - 1:
+                i_opt_batch += 1
+    out = dict(obj=obj, probes=pst[..., 0] + 1j * pst[..., 1], pos_corr=corr, losses=losses, first_grad=first_grad)
+    return out

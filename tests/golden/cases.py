@@ -123,3 +123,30 @@ def e2e_inputs():
     ph = r.uniform(-np.pi, np.pi, (P, P))          # random-phase probe => well-conditioned far field
     return dict(truth=(truth_d, truth_b), guess=(guess_d, guess_b), probe_pos=probe_pos, theta_ls=theta_ls,
                 probe_mag=mag, probe_phase=ph)
+
+
+# ---------------------------------------------------------------- F11: config-1-shaped 2-D ptychography (f2 row)
+C1MINI = dict(Y=40, X=44, P=16, M=2, energy_ev=8801.121930115722, psize_cm=1.32789376566526e-06, minibatch_size=5, n_dp_batch=2)
+
+
+def c1mini_inputs():
+    """2-D complex-transmission object, two incoherent probe modes, raster scan with sub-pixel positions."""
+    c = C1MINI
+    Y, X, P, M = c['Y'], c['X'], c['P'], c['M']
+    mag_t = 1 - 0.35 * smooth_field((Y, X, 1), 111)
+    ph_t = 0.9 * smooth_field((Y, X, 1), 112) - 0.4
+    guess_mag = np.full((Y, X, 1), 0.85) + 0.02 * smooth_field((Y, X, 1), 113)
+    guess_ph = 0.05 * smooth_field((Y, X, 1), 114)
+    r = rng(115)
+    grid = np.array([(y, x) for y in range(-5, 32, 7) for x in range(-6, 36, 8)], dtype=float)
+    pos_true = grid + r.uniform(-0.45, 0.45, grid.shape)            # where the data were taken
+    pos_nominal = grid + r.uniform(-0.3, 0.3, grid.shape)           # what the reconstruction is told (non-integer)
+    py = np.arange(P) - (P - 1.) / 2
+    xx, yy = np.meshgrid(py, py)
+    env = np.exp(-(xx ** 2 + yy ** 2) / (2 * 4. ** 2))
+    pm = np.stack([env * (0.6 + 0.4 * r.uniform(size=(P, P))) * (1.0 if m == 0 else 0.35) for m in range(M)])
+    pp = np.stack([r.uniform(-np.pi, np.pi, (P, P)) for m in range(M)])
+    guess_pm = pm * (1 + 0.1 * r.uniform(-1, 1, pm.shape))
+    guess_pp = pp + 0.1 * r.uniform(-1, 1, pp.shape)
+    return dict(truth=(mag_t, ph_t), guess=(guess_mag, guess_ph), pos_true=pos_true, pos_nominal=pos_nominal,
+                probe_true=(pm, pp), probe_guess=(guess_pm, guess_pp))

@@ -240,7 +240,7 @@ def gen_f7():
 
 
 # ----------------------------------------------------------------------------- F6 / F8 (driver)
-def run_driver(prj, obj_size, probe_pos, theta_end, n_theta, extra, record):
+def run_driver(prj, obj_size, probe_pos, theta_end, n_theta, extra, record, ri=False):
     """Run the reference driver in a scratch cwd; record per-minibatch (i_theta, ind) / loss / first grad."""
     import adorym.ptychography as PT
     import adorym.differentiator as DF
@@ -277,10 +277,14 @@ def run_driver(prj, obj_size, probe_pos, theta_end, n_theta, extra, record):
             with open(os.path.join('out', 'convergence', 'loss_rank_0.txt')) as f:
                 lines = f.read().strip().split('\n')[1:]
             record['losses'] = np.array([float(l.split(',')[2]) for l in lines])
-            key_d = [k for k in TIFFS if k.endswith('delta_ds_1')]
-            key_b = [k for k in TIFFS if k.endswith('beta_ds_1')]
-            record['delta'] = TIFFS[key_d[0]].copy()
-            record['beta'] = TIFFS[key_b[0]].copy()
+            if ri:
+                record['mag'] = TIFFS[[k for k in TIFFS if k.endswith('obj_mag_ds_1')][0]].copy()
+                record['phase'] = TIFFS[[k for k in TIFFS if k.endswith('obj_phase_ds_1')][0]].copy()
+            else:
+                key_d = [k for k in TIFFS if k.endswith('delta_ds_1')]
+                key_b = [k for k in TIFFS if k.endswith('beta_ds_1')]
+                record['delta'] = TIFFS[key_d[0]].copy()
+                record['beta'] = TIFFS[key_b[0]].copy()
         finally:
             os.chdir(cwd)
             DF.Differentiator.get_gradients = orig_get
@@ -463,9 +467,156 @@ def gen_f10():
     out['pad_in'] = o.numpy(); out['pad_out'] = padded.numpy(); out['pad_arr'] = pad_arr
     save('F10_real_imag', **out)
 
+# ----------------------------------------------------------------------------- F11 (f2 row: sub-pixel positions, real_imag regularisers, probe init)
+def _shifted_pred(tiles, pr, pi, shifts, kind, free_prop_cm, energy, psize):
+    """The probe-shift branch of PtychographyModel.predict (forward_model.py:296-375) on explicit tiles."""
+    B = tiles.shape[0]
+    prl, pil = [], []
+    for j in range(B):
+        a, b = U.realign_image_fourier(pr, pi, shifts[j], axes=(1, 2), device=None)
+        prl.append(a); pil.append(b)
+    prl, pil = w.stack(prl), w.stack(pil)                       # [B, M, y, x]
+    ex_int = None
+    for m in range(pr.shape[0]):
+        er, ei = multislice_propagate_batch(tiles, prl[:, m], pil[:, m], energy, psize, kernel=None, free_prop_cm=free_prop_cm,
+                                            binning=1, type=kind)
+        ex_int = er ** 2 + ei ** 2 if ex_int is None else ex_int + er ** 2 + ei ** 2
+    return w.sqrt(ex_int), prl, pil
+
+
+def gen_f11():
+    out = {}
+    C = cases.C1MINI
+    r = cases.rng(1100)
+    # (a) realign_image_fourier (util.py:380-397) on a stack of modes
+    P, M = 16, 2
+    pr0 = r.standard_normal((M, P, P)); pi0 = r.standard_normal((M, P, P))
+    out['shift_probe'] = pr0 + 1j * pi0
+    for k, sh in enumerate([(0.37, -1.21), (-2.5, 0.0), (0.0, 0.0)]):
+        for fp64 in (True, False):
+            gs.run_fp64 = fp64
+            dt = torch.float64 if fp64 else torch.float32
+            a, b = U.realign_image_fourier(torch.tensor(pr0, dtype=dt), torch.tensor(pi0, dtype=dt), torch.tensor(sh, dtype=dt), axes=(1, 2))
+            out['shift%d_%s' % (k, '64' if fp64 else '32')] = a.numpy() + 1j * b.numpy()
+        out['shift%d_s' % k] = np.array(sh)
+    # (b) gradients w.r.t. the per-position shifts, the probe modes and the tiles
+    for name, kind, S, fp in (('db_s5_far', 'delta_beta', 5, 'inf'), ('ri_s1_far', 'real_imag', 1, 'inf'), ('ri_s3_near', 'real_imag', 3, 0)):
+        B, P = 3, 12
+        rr = cases.rng(cases.hash_name('f11' + name))
+        if kind == 'delta_beta':
+            tiles = np.stack([rr.uniform(0, 2e-3, (B, P, P, S)), rr.uniform(0, 2e-4, (B, P, P, S))], -1)
+        else:
+            mag = 1 - 0.3 * rr.uniform(size=(B, P, P, S)); ph = 0.7 * rr.uniform(-1, 1, (B, P, P, S))
+            tiles = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+        probe = rr.standard_normal((M, P, P)) + 1j * rr.standard_normal((M, P, P))
+        probe[1] *= 0.4
+        shifts = rr.uniform(-0.8, 0.8, (B, 2))
+        out[name + '_tiles'] = tiles; out[name + '_probe'] = probe; out[name + '_shifts'] = shifts
+        meas = None
+        for fp64 in (True, False):
+            gs.run_fp64 = fp64
+            dt = torch.float64 if fp64 else torch.float32
+            t = torch.tensor(tiles, dtype=dt, requires_grad=True)
+            pr = torch.tensor(probe.real.copy(), dtype=dt, requires_grad=True)
+            pi = torch.tensor(probe.imag.copy(), dtype=dt, requires_grad=True)
+            sh = torch.tensor(shifts, dtype=dt, requires_grad=True)
+            pred, _, _ = _shifted_pred(t, pr, pi, sh, kind, fp, cases.ENERGY_EV, cases.PSIZE_CM)
+            if meas is None:
+                meas = (pred.detach().numpy() * (1 + 0.3 * cases.rng(1101).uniform(-1, 1, size=pred.shape))).copy()
+                out[name + '_meas'] = meas
+            loss = w.mean((pred - torch.tensor(meas, dtype=dt)) ** 2)
+            g = torch.autograd.grad(loss, [t, pr, pi, sh])
+            tag = name + ('_64' if fp64 else '_32')
+            out[tag + '_pred'] = pred.detach().numpy(); out[tag + '_loss'] = np.array(loss.item())
+            out[tag + '_grad_tiles'] = g[0].numpy(); out[tag + '_grad_probe'] = g[1].numpy() + 1j * g[2].numpy()
+            out[tag + '_grad_shifts'] = g[3].numpy()
+    # (c) real_imag regularisers (regularizers.py:38-45, 105-110)
+    gs.run_fp64 = True
+    mag = 1 - 0.3 * r.uniform(size=(6, 7, 3)); ph = 2.5 * r.uniform(-1, 1, (6, 7, 3))
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    out['reg_obj'] = obj
+    o = torch.tensor(obj, dtype=torch.float64, requires_grad=True)
+    for nm, reg in (('tv', adorym.TVRegularizer(0.7, unknown_type='real_imag')), ('l1', adorym.L1Regularizer(0.8, 0.3, unknown_type='real_imag'))):
+        val = reg.get_value(o)
+        out['reg_%s_val' % nm] = np.array(val.item())
+        out['reg_%s_grad' % nm] = torch.autograd.grad(val, [o])[0].numpy()
+    gs.run_fp64 = False
+    # (d) initialize_probe: aperture_defocus (+ beamstop), rescale_intensity against a data file (util.py:205-219, 254-281)
+    Pp = 16
+    dat = np.abs(cases.rng(1102).standard_normal((1, 6, Pp, Pp))) * 30
+    STORE['probe_data.h5'] = {'exchange/data': dat}
+    out['pinit_data'] = dat
+    lm = 1240. / C['energy_ev']
+    # The reference evaluates the aperture_defocus branch with override_backend='autograd' (NumPy fp64); that package is
+    # absent here, so the same reference pieces (generate_disk, get_kernel, convolve_with_transfer_function) are driven
+    # through the PyTorch backend in fp64, and the rescaling is pinned through the 'supplied' branch of initialize_probe.
+    gs.run_fp64 = True
+    for k, (ar, br, dcm, sg) in enumerate(((5, 2, 0.0069, 1), (6, 0, 0.004, 1), (5, 2, 0.0069, -1))):
+        mag = U.generate_disk([Pp, Pp], ar)
+        if br > 0:
+            mag = mag * (1 - U.generate_disk([Pp, Pp], br))
+        hk = get_kernel(dcm * 1e7, lm, [C['psize_cm'] * 1e7] * 3, [Pp, Pp], sign_convention=sg)
+        a, b = w.convolve_with_transfer_function(torch.tensor(mag, dtype=torch.float64), torch.tensor(np.zeros_like(mag), dtype=torch.float64),
+                                                 torch.tensor(np.real(hk)), torch.tensor(np.imag(hk)))
+        out['pinit_ad%d' % k] = a.numpy() + 1j * b.numpy()
+        out['pinit_ad%d_args' % k] = np.array([ar, br, dcm, sg], dtype=float)
+    gs.run_fp64 = False
+    pm_ = np.abs(cases.rng(1103).standard_normal((3, Pp, Pp))); pp_ = cases.rng(1104).uniform(-3, 3, (3, Pp, Pp))
+    out['pinit_sup_mag'] = pm_; out['pinit_sup_phase'] = pp_
+    for k, (rdt, nf, sg, nm) in enumerate((('intensity', False, 1, 3), ('magnitude', True, 1, 2), ('intensity', False, -1, 1))):
+        a, b = U.initialize_probe([Pp, Pp], 'supplied', probe_initial=[pm_[:nm] if nm > 1 else pm_[0], pp_[:nm] if nm > 1 else pp_[0]],
+                                  rescale_intensity=True, save_path='.', fname='probe_data.h5',
+                                  raw_data_type=rdt, stdout_options={'save_stdout': False, 'output_folder': '.', 'timestamp': ''},
+                                  sign_convention=sg, normalize_fft=nf, n_probe_modes=nm)
+        out['pinit_rescale%d' % k] = a + 1j * b
+    # (e) end-to-end driver, config-1 shape
+    import adorym.ptychography as PT
+    inp = cases.c1mini_inputs()
+    Y, X, P, M = C['Y'], C['X'], C['P'], C['M']
+    gs.run_fp64 = True
+    truth = np.stack([inp['truth'][0] * np.cos(inp['truth'][1]), inp['truth'][0] * np.sin(inp['truth'][1])], -1)
+    pos_t = inp['pos_true']; pos_i = np.round(pos_t).astype(int)
+    o = torch.tensor(truth, dtype=torch.float64)
+    op, pad = U.pad_object(o, [Y, X, 1], pos_i, [P, P], unknown_type='real_imag')
+    tiles = torch.stack([op[y + pad[0, 0]:y + pad[0, 0] + P, x + pad[1, 0]:x + pad[1, 0] + P] for y, x in pos_i])
+    ptrue = inp['probe_true'][0] * np.exp(1j * inp['probe_true'][1])
+    pred, _, _ = _shifted_pred(tiles, torch.tensor(ptrue.real.copy()), torch.tensor(ptrue.imag.copy()),
+                               torch.tensor(pos_t - pos_i), 'real_imag', 'inf', C['energy_ev'], C['psize_cm'])
+    prj = (pred.numpy() ** 2)[None].astype(np.float32)           # intensity data
+    out['e2e_prj'] = prj
+    gs.run_fp64 = False
+    orig_up = PT.update_parameters
+    for fp64 in (True, False):
+        rec = {}
+        def rec_up(opt_ls, optimizable_params, kw, _rec=rec):
+            res = orig_up(opt_ls, optimizable_params, kw)
+            _rec['pos_corr'] = res['probe_pos_correction'].detach().numpy().copy()
+            _rec['probe'] = res['probe_real'].detach().numpy().copy() + 1j * res['probe_imag'].detach().numpy().copy()
+            return res
+        PT.update_parameters = rec_up
+        try:
+            run_driver(prj.astype(np.float64), [Y, X, 1], inp['pos_nominal'], 0, 1,
+                       dict(minibatch_size=C['minibatch_size'], n_epochs=2, two_d_mode=True, energy_ev=C['energy_ev'], psize_cm=C['psize_cm'],
+                            initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='supplied',
+                            probe_initial=[inp['probe_guess'][0], inp['probe_guess'][1]], n_probe_modes=M, rescale_probe_intensity=True,
+                            raw_data_type='intensity', optimize_probe=True, probe_learning_rate=1e-3, optimize_all_probe_pos=True,
+                            all_probe_pos_learning_rate=1e-2, unknown_type='real_imag', gamma=1e-6, alpha_d=None, alpha_b=None,
+                            optimizer='adam', learning_rate=1e-3, n_dp_batch=C['n_dp_batch'], run_float64=fp64,
+                            random_guess_means_sigmas=(1., 0., 0.001, 0.002)), rec, ri=True)
+        finally:
+            PT.update_parameters = orig_up
+        tag = '_64' if fp64 else '_32'
+        out['e2e_obj' + tag] = np.stack([rec['mag'] * np.cos(rec['phase']), rec['mag'] * np.sin(rec['phase'])], -1)
+        out['e2e_losses' + tag] = rec['losses']
+        out['e2e_pos_corr' + tag] = rec['pos_corr']
+        out['e2e_probe' + tag] = rec['probe']
+        out['e2e_first_grad' + tag] = rec['first_grad']
+    gs.run_fp64 = False
+    save('F11_c1', **out)
+
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10']
+    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -475,3 +626,4 @@ if __name__ == '__main__':
     if 'f6' in which: gen_f6()
     if 'f9' in which: gen_f9()
     if 'f10' in which: gen_f10()
+    if 'f11' in which: gen_f11()

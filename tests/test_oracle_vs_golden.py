@@ -309,3 +309,83 @@ def test_torch_structured_matches_oracle():
         l0, _, g0, _ = O.forward_adjoint_object(obj, None, probe, pos, meas, phys, 'float64')
         assert abs(loss - l0) <= 1e-12 * abs(l0)
         assert np.linalg.norm(g - g0) <= 1e-10 * np.linalg.norm(g0)
+
+
+# ------------------------------------------------------------------------------------ F11 (f2 row)
+def _f11():
+    return load('F11_c1')
+
+
+def test_f11_fourier_shift():
+    f = _f11()
+    for k in range(3):
+        out = O.fourier_shift(f['shift_probe'], f['shift%d_s' % k], 'float64')
+        assert np.abs(out - f['shift%d_64' % k]).max() < 1e-12
+        out32 = O.fourier_shift(f['shift_probe'], f['shift%d_s' % k], 'float32')
+        assert np.abs(out32 - f['shift%d_32' % k]).max() < 2e-5 * np.abs(f['shift%d_64' % k]).max()
+
+
+@pytest.mark.parametrize('name,kind,fp', [('db_s5_far', 'delta_beta', 'inf'), ('ri_s1_far', 'real_imag', 'inf'),
+                                          ('ri_s3_near', 'real_imag', 0)])
+def test_f11_position_gradients(name, kind, fp):
+    f = _f11()
+    P = f[name + '_probe'].shape[-1]
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=fp, unknown_type=kind)
+    loss, pred, gt, gp, gs = O.forward_adjoint_tiles(f[name + '_tiles'], f[name + '_probe'], f[name + '_meas'], phys, 'float64',
+                                                     shifts=f[name + '_shifts'])
+    t = name + '_64'
+    assert abs(loss - f[t + '_loss']) < 1e-11 * abs(f[t + '_loss'])
+    assert np.abs(pred - f[t + '_pred']).max() < 1e-10 * np.abs(pred).max()
+    for a, b in ((gt, f[t + '_grad_tiles']), (gp, f[t + '_grad_probe']), (gs, f[t + '_grad_shifts'])):
+        assert np.linalg.norm(a - b) < 1e-9 * np.linalg.norm(b)
+
+
+def test_f11_real_imag_regularisers():
+    f = _f11()
+    v, g = O.tv_value_grad_ri(f['reg_obj'], 0.7)
+    assert abs(v - f['reg_tv_val']) < 1e-12 * abs(v)
+    assert np.abs(g - f['reg_tv_grad']).max() < 1e-12 * np.abs(g).max()
+    v, g = O.l1_value_grad_ri(f['reg_obj'], 0.8, 0.3)
+    assert abs(v - f['reg_l1_val']) < 1e-12 * abs(v)
+    assert np.abs(g - f['reg_l1_grad']).max() < 1e-12 * np.abs(g).max()
+
+
+def test_f11_probe_initialisers():
+    f = _f11()
+    C = cases.C1MINI
+    lm = 1240. / C['energy_ev']
+    for k in range(3):
+        ar, br, dcm, sg = f['pinit_ad%d_args' % k]
+        p = O.aperture_defocus_probe((16, 16), ar, dcm, lm, C['psize_cm'], beamstop_radius=br, sign_convention=int(sg))
+        assert np.abs(p - f['pinit_ad%d' % k]).max() < 1e-12
+    pm, pp = f['pinit_sup_mag'], f['pinit_sup_phase']
+    for k, (rdt, nf, sg, nm) in enumerate((('intensity', False, 1, 3), ('magnitude', True, 1, 2), ('intensity', False, -1, 1))):
+        pr = pm[:nm] * np.exp(1j * pp[:nm]) if nm > 1 else pm[0] * np.exp(1j * pp[0])
+        out = O.rescale_probe(pr, f['pinit_data'], rdt, nf, sg)
+        assert np.abs(out - f['pinit_rescale%d' % k]).max() < 1e-10 * np.abs(out).max()
+
+
+def _c1_oracle_run(dtype, f):
+    C = cases.C1MINI
+    inp = cases.c1mini_inputs()
+    P = C['P']
+    phys = O.Physics((P, P), C['energy_ev'], C['psize_cm'], free_prop_cm='inf', unknown_type='real_imag')
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    pg = inp['probe_guess'][0] * np.exp(1j * inp['probe_guess'][1])
+    prj = f['e2e_prj'].astype(np.float64)
+    pg = O.rescale_probe(pg, prj[0:1], 'intensity', False, 1)
+    return O.reconstruct_2d(prj, [g0.real, g0.imag], pg, inp['pos_nominal'], phys, n_epochs=2, minibatch_size=C['minibatch_size'],
+                            learning_rate=1e-3, gamma=1e-6, raw_data_type='intensity', optimize_probe=True, probe_learning_rate=1e-3,
+                            optimize_all_probe_pos=True, all_probe_pos_learning_rate=1e-2, dtype=dtype)
+
+
+def test_f11_end_to_end_config1_shape():
+    """The reference driver on a config-1-shaped problem (2-D, real_imag unknowns, 2 probe modes, intensity data, probe
+    rescaling, Adam on object + probe + sub-pixel position corrections, TV on |o|^2 and arg o)."""
+    f = _f11()
+    out = _c1_oracle_run('float64', f)
+    assert np.allclose(out['losses'], f['e2e_losses_64'], rtol=1e-9)
+    assert np.linalg.norm(out['first_grad'] - f['e2e_first_grad_64']) < 1e-9 * np.linalg.norm(f['e2e_first_grad_64'])
+    assert np.abs(out['obj'] - f['e2e_obj_64']).max() < 2e-6          # the golden object went through mag/phase fp32 TIFFs
+    assert np.abs(out['probes'] - f['e2e_probe_64']).max() < 1e-9 * np.abs(f['e2e_probe_64']).max()
+    assert np.abs(out['pos_corr'] - f['e2e_pos_corr_64']).max() < 1e-8
