@@ -55,6 +55,10 @@ SIGNATURES = {
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_multislice_fwd_adj_pp': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_probe_shift': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
+    'adm_probe_shift_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    'adm_center_rows': (_I, [_VP, _VP, _SZ, _I]),
     'adm_tile_grad_accumulate': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),

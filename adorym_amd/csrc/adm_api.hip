@@ -214,6 +214,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->Xp = d.pad_x0 + d.obj_x + d.pad_x1;
     p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
     p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
+    p->reg_stats = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
@@ -240,6 +241,7 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->h_dev) adm_free(plan->ctx, plan->h_dev);
     if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
     if (plan->twid_dev) adm_free(plan->ctx, plan->twid_dev);
+    if (plan->reg_stats) (void)hipFree(plan->reg_stats);
     delete plan;
     return ADM_OK;
 }
@@ -269,9 +271,9 @@ size_t ws_off_cover(const adm_plan* plan, int batch) { return ws_off_gtile(plan,
 size_t ws_off_det(const adm_plan* plan, int batch) { return ws_off_cover(plan, batch) + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64; }
 }  // namespace adm
 
-extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                                      const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
-                                      float grad_scale, void* workspace, size_t workspace_bytes) {
+static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                           const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
+                           float grad_scale, void* workspace, size_t workspace_bytes, bool per_position) {
     if (!plan || !obj_rot || !probe || !pos || !target || !loss_sum)
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: batch must be positive");
@@ -317,6 +319,59 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
     p.loss_type = d.loss_type;
     p.poisson_mult = d.poisson_multiplier;
     p.real_imag = d.unknown_type;
+    if (per_position) {
+        p.probe_bstride = p.gprobe_bstride = (size_t)d.n_modes * d.probe_y * d.probe_x;
+        if (grad_probe && want_grad)
+            ADM_HIP(hipMemsetAsync(grad_probe, 0, (size_t)batch * p.gprobe_bstride * sizeof(float2), plan->ctx->stream));
+    }
     ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                                      const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
+                                      float grad_scale, void* workspace, size_t workspace_bytes) {
+    return multislice_impl(plan, obj_rot, probe, pos, batch, target, want_grad, grad_probe, pred, loss_sum, grad_scale, workspace,
+                           workspace_bytes, false);
+}
+
+extern "C" int adm_multislice_fwd_adj_pp(adm_plan* plan, const float* obj_rot, const float* probes, const int32_t* pos, int batch,
+                                         const float* target, int want_grad, float* grad_probes, float* pred, float* loss_sum,
+                                         float grad_scale, void* workspace, size_t workspace_bytes) {
+    return multislice_impl(plan, obj_rot, probes, pos, batch, target, want_grad, grad_probes, pred, loss_sum, grad_scale, workspace,
+                           workspace_bytes, true);
+}
+
+extern "C" int adm_probe_shift(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,
+                               float* probes_out) {
+    if (!plan || !probe || !shifts || !probes_out) return fail(ADM_ERR_INVALID, "adm_probe_shift: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_probe_shift: batch must be positive");
+    ShiftParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.probe = (const float2*)probe;
+    q.shifts = (const float2*)shifts;
+    q.index = index;
+    q.probes_out = (float2*)probes_out;
+    q.twid = plan->twid_dev;
+    q.n_modes = plan->d.n_modes;
+    ADM_HIP(shift_launch(plan->d.probe_x, q, batch, false, plan->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_probe_shift_adj(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,
+                                   const float* grad_probes, float* grad_probe, float* grad_shifts) {
+    if (!plan || !probe || !shifts || !grad_probes || !grad_shifts) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: batch must be positive");
+    ShiftParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.probe = (const float2*)probe;
+    q.shifts = (const float2*)shifts;
+    q.index = index;
+    q.grad_probes = (const float2*)grad_probes;
+    q.grad_probe = (float2*)grad_probe;
+    q.grad_shifts = grad_shifts;
+    q.twid = plan->twid_dev;
+    q.n_modes = plan->d.n_modes;
+    ADM_HIP(shift_launch(plan->d.probe_x, q, batch, true, plan->ctx->stream));
     return ADM_OK;
 }

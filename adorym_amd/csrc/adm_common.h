@@ -27,6 +27,7 @@ struct adm_plan {
     float2* h_dev;         // [Py*Px] slice transfer function
     float2* hfree_dev;     // [Py*Px] or nullptr
     float2* twid_dev;      // [Px] exp(-2 pi i j / N)
+    float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
 };
 
 namespace adm {
@@ -59,6 +60,20 @@ struct MsParams {
     int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
     float poisson_mult;
     int real_imag;             // unknown_type == 'real_imag'
+    size_t probe_bstride;      // float2 elements between the probes of consecutive positions (0 = one shared probe set)
+    size_t gprobe_bstride;     // same for grad_probe (per-position gradients when the probes are per position)
+};
+// per-position sub-pixel probe shifts (adorym/util.py:380-397, forward_model.py:296-311)
+struct ShiftParams {
+    const float2* probe;       // [M][P][P]
+    const float2* shifts;      // (sy, sx) entries; entry of position b = shifts[index ? index[b] : b]
+    const int* index;          // [B] or nullptr
+    float2* probes_out;        // forward: [B][M][P][P]
+    const float2* grad_probes; // adjoint: [B][M][P][P]
+    float2* grad_probe;        // adjoint: [M][P][P] accumulated (atomics) or nullptr
+    float* grad_shifts;        // adjoint: accumulated (atomics) at [index ? index[b] : b][2]
+    const float2* twid;
+    int n_modes;
 };
 int ms_threads_for(int n);
 int ms_r2_for(int n);
@@ -68,6 +83,7 @@ size_t ws_off_cover(const adm_plan* plan, int batch);
 size_t ws_off_det(const adm_plan* plan, int batch);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
+hipError_t shift_launch(int n, const ShiftParams& q, int batch, bool adjoint, hipStream_t st);
 }  // namespace adm
 
 #define ADM_HIP(call)                                          \

@@ -611,7 +611,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     float lsum = 0.f;
     if (!MULTI) {
         // ================= single probe mode: everything stays in registers =================
-        load_probe<N, R1, R2>(c, a, p.probe);
+        load_probe<N, R1, R2>(c, a, p.probe + (size_t)b * p.probe_bstride);
         fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
         detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
         if (p.det_mode == ADM_DET_FARFIELD_) {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
         rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
-        add_probe_grad<N, R1, R2>(c, a, p.grad_probe);
+        add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
         // pred = sqrt(sum_m |Psi_m|^2): the detector-plane fields of all modes are parked in HBM (thread-native
@@ -656,7 +656,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 #pragma unroll
         for (int k = 0; k < GE::G; ++k) inten[k] = 0.f;
         for (int m = 0; m < M; ++m) {
-            load_probe<N, R1, R2>(c, a, p.probe + (size_t)m * N * N);
+            load_probe<N, R1, R2>(c, a, p.probe + (size_t)b * p.probe_bstride + (size_t)m * N * N);
             fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
             detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
             float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
             if (m == 0) rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
             else rev_sweep<N, R1, R2, BIN1, true, RI>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
-            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)m * N * N : nullptr);
+            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride + (size_t)m * N * N : nullptr);
         }
     }
 }
@@ -734,6 +734,147 @@ template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int
         if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, false>), g, t, 0, st, p);
         else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, false, false>), g, t, 0, st, p);
     }
+    return hipGetLastError();
+}
+
+
+// =====================================================================================================================
+// Sub-pixel probe positions: position b sees every probe mode Fourier-shifted by its correction (sy, sx)
+//     p_b = IFFT2( Phi_b * FFT2(p) ),   Phi_b(ky,kx) = exp(-2 PI i (fx*sx + fy*sy)),  f = fftfreq      (adorym/util.py:380-397)
+// and the adjoint:  dL/dp += IFFT2( conj(Phi_b) * FFT2(G_b) ),  dL/ds = 2 PI sum_k f_k Im( conj(Ghat_k) Phi_k F_k ),
+// Ghat = FFT2(G_b) / N^2, F = FFT2(p).  Same LDS transform machinery and thread <-> frequency map as the multislice kernel.
+// =====================================================================================================================
+template <int N, int R1, int R2>
+__device__ __forceinline__ void init_ctx(Ctx<N, R1, R2>& c, cf* fld, const float2* __restrict__ twid, int& tc2, int& kx) {
+    using GE = Geo<N, R1, R2>;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane / GE::G;
+    c.fld = fld;
+    c.hl = nullptr;
+    c.t = lane % GE::G;
+    c.line = wave * GE::LPW + li;
+    const bool line_ok = (li < GE::LPW) && (c.line < N);
+    c.act1 = line_ok && (c.t < R2);
+    c.act2 = line_ok && (c.t < R1);
+    if (!line_ok) c.line = 0;
+    tc2 = c.t % R1;
+    c.row_p1 = c.line * GE::Q + c.t * GE::ROW_P1_T;
+    c.row_p2 = c.line * GE::Q + tc2 * GE::ROW_P2_T;
+    c.col_p1 = GE::posx(c.line) + c.t * GE::COL_P1_T;
+    c.col_p2 = GE::posx(c.line) + tc2 * GE::COL_P2_T;
+#pragma unroll
+    for (int k = 0; k < R1; ++k) c.tw[k] = twid[(c.t * k) % N];
+    kx = freq_of_pos<R1, R2>(c.line);
+}
+
+template <int N> __device__ __forceinline__ float fftfreq_f(int k) {
+    return (float)((double)(k < (N + 1) / 2 ? k : k - N) / (double)N);
+}
+
+// Phi for the R2 spectral elements this thread holds in the pass-2 column role
+template <int N, int R1, int R2>
+__device__ __forceinline__ void shift_phases(cf (&ph)[R2], float (&fy)[R2], float fx, float2 s, int tc2) {
+#pragma clang fp contract(off)
+    const float m2pi = (float)(-2.0 * 3.14159265359);
+#pragma unroll
+    for (int k = 0; k < R2; ++k) {
+        fy[k] = fftfreq_f<N>(tc2 + R1 * k);
+        const float arg = m2pi * (fx * s.y + fy[k] * s.x);
+        float sn, cs;
+        sincos_fast(arg, sn, cs);
+        ph[k] = make_float2(cs, sn);
+    }
+}
+
+template <int N, int R1, int R2>
+__global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_kernel(ShiftParams q) {
+    using GE = Geo<N, R1, R2>;
+    __shared__ cf fld[GE::FLD];
+    Ctx<N, R1, R2> c;
+    int tc2, kx;
+    init_ctx<N, R1, R2>(c, fld, q.twid, tc2, kx);
+    const int b = blockIdx.x / q.n_modes, m = blockIdx.x % q.n_modes;
+    const float2 s = q.shifts[q.index ? q.index[b] : b];
+    cf ph[R2];
+    float fy[R2];
+    shift_phases<N, R1, R2>(ph, fy, fftfreq_f<N>(kx), s, tc2);
+    cf a[R1], bb[R2];
+    load_probe<N, R1, R2>(c, a, q.probe + (size_t)m * N * N);
+    fft2_to_regs<N, R1, R2>(c, a, bb);
+    const float inv = (float)(1.0 / ((double)N * N));
+    if (c.act2) {
+#pragma unroll
+        for (int k = 0; k < R2; ++k) bb[k] = cscale(cmul(bb[k], ph[k]), inv);
+    }
+    ifft2_from_regs<N, R1, R2>(c, bb, a);
+    if (c.act1) {
+        float2* o = q.probes_out + (size_t)blockIdx.x * N * N + c.line * N + c.t;
+#pragma unroll
+        for (int k = 0; k < R1; ++k) o[k * R2] = a[k];
+    }
+}
+
+template <int N, int R1, int R2>
+__global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(ShiftParams q) {
+    using GE = Geo<N, R1, R2>;
+    __shared__ cf fld[GE::FLD];
+    __shared__ float red[2 * GE::NWAVES];
+    Ctx<N, R1, R2> c;
+    int tc2, kx;
+    init_ctx<N, R1, R2>(c, fld, q.twid, tc2, kx);
+    const int b = blockIdx.x;
+    const int e = q.index ? q.index[b] : b;
+    const float2 s = q.shifts[e];
+    cf ph[R2];
+    float fy[R2];
+    const float fx = fftfreq_f<N>(kx);
+    shift_phases<N, R1, R2>(ph, fy, fx, s, tc2);
+    const float inv = (float)(1.0 / ((double)N * N));
+    float gy = 0.f, gx = 0.f;
+    for (int m = 0; m < q.n_modes; ++m) {
+        cf a[R1], bf[R2], bg[R2];
+        load_probe<N, R1, R2>(c, a, q.probe + (size_t)m * N * N);
+        fft2_to_regs<N, R1, R2>(c, a, bf);
+        __syncthreads();
+        load_probe<N, R1, R2>(c, a, q.grad_probes + ((size_t)b * q.n_modes + m) * N * N);
+        fft2_to_regs<N, R1, R2>(c, a, bg);
+        if (c.act2) {
+#pragma unroll
+            for (int k = 0; k < R2; ++k) {
+                const cf gh = cscale(bg[k], inv);                 // Ghat
+                const cf pf = cmul(ph[k], bf[k]);                 // Phi * F
+                const float im = gh.x * pf.y - gh.y * pf.x;       // Im(conj(Ghat) * Phi F)
+                gy += fy[k] * im;
+                gx += fx * im;
+                bg[k] = cmulc(gh, ph[k]);                         // conj(Phi) * Ghat  -> inverse transform below
+            }
+        }
+        ifft2_from_regs<N, R1, R2>(c, bg, a);
+        add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr);
+        __syncthreads();
+    }
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        gy += __shfl_down(gy, off, 64);
+        gx += __shfl_down(gx, off, 64);
+    }
+    if (lane == 0) { red[2 * wave] = gy; red[2 * wave + 1] = gx; }
+    __syncthreads();
+    if (tid == 0) {
+        float sy = 0.f, sx = 0.f;
+        for (int w = 0; w < GE::NWAVES; ++w) { sy += red[2 * w]; sx += red[2 * w + 1]; }
+        const float twopi = (float)(2.0 * 3.14159265359);
+        atomicAdd(q.grad_shifts + 2 * (size_t)e, twopi * sy);
+        atomicAdd(q.grad_shifts + 2 * (size_t)e + 1, twopi * sx);
+    }
+}
+
+template <int N, int R1, int R2> static hipError_t launch_shift(const ShiftParams& q, int batch, bool adjoint, hipStream_t st) {
+    using GE = Geo<N, R1, R2>;
+    if (adjoint) hipLaunchKernelGGL((probe_shift_adj_kernel<N, R1, R2>), dim3(batch), dim3(GE::NT), 0, st, q);
+    else hipLaunchKernelGGL((probe_shift_kernel<N, R1, R2>), dim3(batch * q.n_modes), dim3(GE::NT), 0, st, q);
     return hipGetLastError();
 }
 
@@ -768,6 +909,15 @@ int ms_r1_for(int n) {
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st) {
     switch (n) {
 #define X(N_, A_, B_) case N_: return launch<N_, A_, B_>(p, batch, st);
+        ADM_FOR_EACH_SIZE(X)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t shift_launch(int n, const ShiftParams& q, int batch, bool adjoint, hipStream_t st) {
+    switch (n) {
+#define X(N_, A_, B_) case N_: return launch_shift<N_, A_, B_>(q, batch, adjoint, st);
         ADM_FOR_EACH_SIZE(X)
 #undef X
         default: return hipErrorInvalidValue;

@@ -299,6 +299,115 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__
     }
 }
 
+// real_imag branches (adorym/regularizers.py:38-45, 105-110): the regularised quantities are u = re^2 + im^2 (TV),
+// |o| = sqrt(u) (L1, about its mean) and phi = atan2(im, re) (TV and L1); chain rule back to (re, im).
+// stats[0] = sum |o|, stats[1] = sum sgn(|o| - mean|o|) (filled by the two pre-passes when alpha_d != 0).
+__global__ __launch_bounds__(256) void ri_stats_kernel(const float2* __restrict__ x, size_t V, float* stats, int pass) {
+    float acc = 0.f;
+    const float mean = pass ? stats[0] / (float)V : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 o = x[i];
+        const float om = sqrtf(o.x * o.x + o.y * o.y);
+        acc += pass ? sgn(om - mean) : om;
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stats + pass, red[0] + red[1] + red[2] + red[3]);
+}
+
+__device__ __forceinline__ void ri_up(const float2* __restrict__ x, size_t i, float& u, float& ph) {
+    const float2 o = x[i];
+    u = o.x * o.x + o.y * o.y;
+    ph = atan2f(o.y, o.x);
+}
+
+__global__ __launch_bounds__(256) void reg_grad_ri_kernel(const float2* __restrict__ x, float2* __restrict__ g, int Y, int X, int Z,
+                                                          float a_d, float a_b, float gamma, const float* __restrict__ stats,
+                                                          float* reg_value) {
+    const size_t V = (size_t)Y * X * Z;
+    const float invV = 1.0f / (float)V;
+    float val = 0.f;
+    const float mean_om = (a_d != 0.f) ? stats[0] * invV : 0.f;
+    const float mean_sg = (a_d != 0.f) ? stats[1] * invV : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x) {
+        size_t vox = i;
+        const int z = (int)(vox % Z);
+        vox /= Z;
+        const int xx = (int)(vox % X);
+        const int y = (int)(vox / X);
+        const float2 o = x[i];
+        const float u = o.x * o.x + o.y * o.y;
+        const float ph = atan2f(o.y, o.x);
+        float gr = 0.f, gi = 0.f;
+        if (a_d != 0.f) {
+            const float om = sqrtf(u);
+            const float dev = om - mean_om;
+            const float gom = a_d * (sgn(dev) - mean_sg) * invV;
+            gr += gom * o.x / om;
+            gi += gom * o.y / om;
+            val += a_d * fabsf(dev) * invV;
+        }
+        if (a_b != 0.f) {
+            const float gph = a_b * sgn(ph) * invV;
+            gr += -gph * o.y / u;
+            gi += gph * o.x / u;
+            val += a_b * fabsf(ph) * invV;
+        }
+        if (gamma != 0.f) {
+            const size_t sz = 1, sx = (size_t)Z, sy = (size_t)Z * X;
+            float um, pm, up, pp, gu = 0.f, gp = 0.f;
+            ri_up(x, i - (size_t)z * sz + (size_t)((z + Z - 1) % Z) * sz, um, pm);
+            ri_up(x, i - (size_t)z * sz + (size_t)((z + 1) % Z) * sz, up, pp);
+            gu += sgn(u - up) - sgn(um - u); gp += sgn(ph - pp) - sgn(pm - ph);
+            val += gamma * invV * (fabsf(um - u) + fabsf(pm - ph));
+            ri_up(x, i - (size_t)xx * sx + (size_t)((xx + X - 1) % X) * sx, um, pm);
+            ri_up(x, i - (size_t)xx * sx + (size_t)((xx + 1) % X) * sx, up, pp);
+            gu += sgn(u - up) - sgn(um - u); gp += sgn(ph - pp) - sgn(pm - ph);
+            val += gamma * invV * (fabsf(um - u) + fabsf(pm - ph));
+            ri_up(x, i - (size_t)y * sy + (size_t)((y + Y - 1) % Y) * sy, um, pm);
+            ri_up(x, i - (size_t)y * sy + (size_t)((y + 1) % Y) * sy, up, pp);
+            gu += sgn(u - up) - sgn(um - u); gp += sgn(ph - pp) - sgn(pm - ph);
+            val += gamma * invV * (fabsf(um - u) + fabsf(pm - ph));
+            gr += gamma * invV * (gu * 2.f * o.x - gp * o.y / u);
+            gi += gamma * invV * (gu * 2.f * o.y + gp * o.x / u);
+        }
+        float2 gv = g[i];
+        gv.x += gr;
+        gv.y += gi;
+        g[i] = gv;
+    }
+    if (reg_value) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reg_value, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// x[r][c] -= mean_r x[r][c]   (adorym/optimizers.py:1046-1048), one workgroup
+__global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x, size_t n_rows, int n_cols) {
+    __shared__ float red[4];
+    __shared__ float mean;
+    for (int c = 0; c < n_cols; ++c) {
+        float acc = 0.f;
+        for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) acc += x[r * n_cols + c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) mean = (red[0] + red[1] + red[2] + red[3]) / (float)n_rows;
+        __syncthreads();
+        const float mu = mean;
+        for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) x[r * n_cols + c] -= mu;
+        __syncthreads();
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Fused optimiser steps.  AdamOptimizer.apply_gradient (adorym/optimizers.py:309-318):
 //   m = b1*m; m = m + (1-b1)*g; v = b2*v; v = v + (1-b2)*g^2;
@@ -511,8 +620,32 @@ extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, flo
     if (!plan || !obj || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad: null argument");
     const adm_plan_desc& d = plan->d;
     const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
-    hipLaunchKernelGGL(reg_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, plan->ctx->stream, obj, grad_obj, d.obj_y, d.obj_x,
+    hipStream_t st = plan->ctx->stream;
+    if (d.unknown_type == 1) {
+        const size_t V = n / 2;
+        if (alpha_d != 0.f) {
+            if (!plan->reg_stats) ADM_HIP(hipMalloc((void**)&plan->reg_stats, 2 * sizeof(float)));
+            ADM_HIP(hipMemsetAsync(plan->reg_stats, 0, 2 * sizeof(float), st));
+            int nb = stream_grid(V);
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 0);
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 1);
+        }
+        hipLaunchKernelGGL(reg_grad_ri_kernel, dim3(stream_grid(V)), dim3(256), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y,
+                           d.obj_x, d.obj_z, alpha_d, alpha_b, gamma, (const float*)plan->reg_stats, reg_value);
+        ADM_HIP(hipGetLastError());
+        return ADM_OK;
+    }
+    hipLaunchKernelGGL(reg_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x,
                        d.obj_z, alpha_d, alpha_b, gamma, reg_value);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols) {
+    if (!ctx || !x) return fail(ADM_ERR_INVALID, "adm_center_rows: null argument");
+    if (n_rows == 0 || n_cols <= 0) return ADM_OK;
+    hipLaunchKernelGGL(center_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n_rows, n_cols);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -105,13 +105,40 @@ class PtychographyModel(ForwardModel):
     # ------------------------------------------------------------------ helpers
     def _check_static(self, probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset):
         cv = self.common_vars
-        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset',
-                     'optimize_all_probe_pos', 'optimize_tilt'):
+        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset', 'optimize_tilt'):
             if cv.get(flag):
                 raise NotImplementedError('%s is outside the accelerated path (SURVEY section 8 f2)' % flag)
-        if probe_pos_correction is not None and np.any(np.asarray(probe_pos_correction) > 1e-3):
-            # forward_model.py:298 -- fractional positions shift the probe in Fourier space
-            raise NotImplementedError('sub-pixel probe position corrections are outside the accelerated path (f2)')
+
+    def _shift_args(self, probe_pos_correction, this_i_theta, this_ind_batch):
+        """forward_model.py:297-311: the probes are Fourier-shifted per position when the corrections are being optimised or
+        any of them exceeds 1e-3 (sic: positive values only).  Returns (shifts DeviceArray [n_theta*n_pos, 2], index
+        DeviceArray int32 [B]) or (None, None)."""
+        if probe_pos_correction is None:
+            return None, None
+        if isinstance(probe_pos_correction, DeviceArray):
+            dev = probe_pos_correction
+            active = bool(self.common_vars.get('optimize_all_probe_pos')) or getattr(self, '_static_shift_active', None)
+            if active is None:
+                active = self._static_shift_active = bool(np.any(dev.get() > 1e-3))
+        else:
+            host = np.ascontiguousarray(np.asarray(probe_pos_correction, dtype=np.float32))
+            active = bool(self.common_vars.get('optimize_all_probe_pos')) or bool(np.any(host > 1e-3))
+            if not active:
+                return None, None
+            key = (host.shape, host.tobytes())
+            if getattr(self, '_corr_key', None) != key:
+                self._corr_dev = self.device.array(host)
+                self._corr_key = key
+            dev = self._corr_dev
+        if not active:
+            return None, None
+        n_pos = dev.shape[-2] if len(dev.shape) >= 2 else dev.size // 2
+        idx = (int(this_i_theta) * n_pos + np.asarray(this_ind_batch, dtype=np.int64)).astype(np.int32)
+        if getattr(self, '_idx_dev', None) is None or self._idx_dev.size < len(idx):
+            self._idx_dev = DeviceArray(self.device, (max(len(idx), 64),), np.int32)
+        view = self._idx_dev.view(0, (len(idx),))
+        view.set(idx)
+        return dev, view
 
     def _coords(self, this_i_theta):
         cv = self.common_vars
@@ -132,7 +159,7 @@ class PtychographyModel(ForwardModel):
         return self._probe_dev
 
     def _run(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad, grad_obj=None,
-             want_probe_grad=False, want_pred=False):
+             want_probe_grad=False, want_pred=False, probe_pos_correction=None, this_ind_batch=None, want_shift_grad=False):
         eng = self.engine
         probe = self._probe(probe_real, probe_imag)
         coords = self._coords(this_i_theta)
@@ -144,14 +171,23 @@ class PtychographyModel(ForwardModel):
             if self._grad_probe_dev is None or self._grad_probe_dev.shape != probe.shape:
                 self._grad_probe_dev = self.device.empty(probe.shape)
             gp = self._grad_probe_dev.zero_()
+        shifts, idx = self._shift_args(probe_pos_correction, this_i_theta, this_ind_batch)
+        gsh = None
+        if want_shift_grad:
+            if shifts is None:
+                raise RuntimeError('gradient w.r.t. probe_pos_correction requested but no corrections were passed')
+            if getattr(self, '_grad_shift_dev', None) is None or self._grad_shift_dev.shape != shifts.shape:
+                self._grad_shift_dev = self.device.empty(shifts.shape)
+            gsh = self._grad_shift_dev.zero_()
         B = len(np.asarray(this_pos_batch).reshape(-1, 2))
         mb = B // self.batch_group
         gs = 2.0 / (mb * eng.probe_size[0] * eng.probe_size[1])     # each reference minibatch is a mean over ITS positions
-        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs)
+        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
+                       shift_index=idx, grad_shifts=gsh)
         self._last_mb = mb
         if want_grad:
             eng.rotate_adjoint(grad_obj, coords, yr)
-        return gp
+        return gp, gsh
 
     def _regularize(self, obj, grad_obj):
         """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value."""
@@ -184,7 +220,8 @@ class PtychographyModel(ForwardModel):
         self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
         B = len(this_pos_batch)
         zeros = np.zeros((B,) + tuple(self.engine.probe_size), np.float32)
-        self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, zeros, want_grad=False, want_pred=True)
+        self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, zeros, want_grad=False, want_pred=True,
+                  probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch)
         self.i_call += 1
         return self.engine.pred()
 
@@ -194,7 +231,8 @@ class PtychographyModel(ForwardModel):
             self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
             target = self.get_data(this_i_theta, this_ind_batch, theta_downsample=self.common_vars.get('theta_downsample'),
                                    ds_level=self.common_vars.get('ds_level', 1))
-            self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=False)
+            self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=False,
+                      probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch)
             loss = self.engine.loss(last=self._last_mb) + self._regularize(obj, None)
             self.current_loss = float(loss)
             return self.current_loss
@@ -212,20 +250,22 @@ class PtychographyModel(ForwardModel):
         target = self.get_data(this_i_theta, this_ind_batch, theta_downsample=self.common_vars.get('theta_downsample'),
                                ds_level=self.common_vars.get('ds_level', 1))
         i_pr, i_pi = self.get_argument_index('probe_real'), self.get_argument_index('probe_imag')
+        i_pc = self.get_argument_index('probe_pos_correction')
         want_probe = (i_pr in opt_args_ls) or (i_pi in opt_args_ls)
-        gp = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
-                       want_probe_grad=want_probe)
+        gp, gsh = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
+                            want_probe_grad=want_probe, probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch,
+                            want_shift_grad=i_pc in opt_args_ls)
         reg = self._regularize(obj, grad_obj)
         self.current_loss = float(self.engine.loss(last=self._last_mb) + reg)
         out = []
-        gph = gp.get() if gp is not None else None
         for i in opt_args_ls:
             if i == 0:
                 out.append(grad_obj)
-            elif i == i_pr:
-                out.append(gph[..., 0])
-            elif i == i_pi:
-                out.append(gph[..., 1])
+            elif i in (i_pr, i_pi):
+                # both entries reference ONE interleaved device array [n_modes,Py,Px,2] (real, imag): no host round trip
+                out.append(gp)
+            elif i == i_pc:
+                out.append(gsh)             # DeviceArray, dense like probe_pos_correction (zero outside this minibatch)
             else:
                 raise NotImplementedError("gradient w.r.t. '%s' is outside the accelerated path" % self.argument_ls[i])
         return tuple(out)

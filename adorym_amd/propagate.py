@@ -195,17 +195,44 @@ class MultisliceEngine(object):
         self._B = B
         return B
 
-    def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, accumulate=True):
+    def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, accumulate=True,
+                   shifts=None, shift_index=None, grad_shifts=None):
         """Launch the fused kernel on the batch given to set_batch().  Returns nothing; read
-        results with loss() / pred()."""
+        results with loss() / pred().
+
+        ``shifts`` (DeviceArray float [n_entries,2] = (sy, sx)) switches to one Fourier-shifted probe set per position
+        (adorym/forward_model.py:296-311); position b uses entry ``shift_index[b]`` (DeviceArray int32 [B]; None = b).
+        With want_grad, ``grad_probe`` (+=) and ``grad_shifts`` (float [n_entries,2], +=) then receive the gradients
+        taken through the shift."""
         B = self._B
         Py, Px = self.probe_size
         if grad_scale is None:
             grad_scale = 2.0 / (B * Py * Px)          # d mean((pred-target)^2) / d pred
-        check(self.ctx.lib.adm_multislice_fwd_adj(
-            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
-            1 if want_grad else 0, grad_probe.ptr if grad_probe is not None else None,
-            self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
+        lib = self.ctx.lib
+        if shifts is None:
+            check(lib.adm_multislice_fwd_adj(
+                self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
+                1 if want_grad else 0, grad_probe.ptr if grad_probe is not None else None,
+                self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
+        else:
+            M = self.n_probe_modes
+            if getattr(self, '_probes_b', None) is None or self._probes_b.shape[0] < B:
+                self._probes_b = DeviceArray(self.ctx, (max(B, self.max_batch), M, Py, Px, 2), np.float32)
+                self._gprobes_b = DeviceArray(self.ctx, (max(B, self.max_batch), M, Py, Px, 2), np.float32)
+            idx = shift_index.ptr if shift_index is not None else None
+            need_adj = want_grad and (grad_probe is not None or grad_shifts is not None)
+            check(lib.adm_probe_shift(self.plan.handle, probe.ptr, shifts.ptr, idx, B, self._probes_b.ptr))
+            check(lib.adm_multislice_fwd_adj_pp(
+                self.plan.handle, self.obj_rot.ptr, self._probes_b.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
+                1 if want_grad else 0, self._gprobes_b.ptr if need_adj else None,
+                self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale), self._ws.ptr, self._ws.nbytes))
+            if need_adj:
+                if grad_shifts is None:
+                    if getattr(self, '_gshift_dummy', None) is None or self._gshift_dummy.size != shifts.size:
+                        self._gshift_dummy = DeviceArray(self.ctx, (shifts.size,), np.float32)
+                    grad_shifts = self._gshift_dummy
+                check(lib.adm_probe_shift_adj(self.plan.handle, probe.ptr, shifts.ptr, idx, B, self._gprobes_b.ptr,
+                                              grad_probe.ptr if grad_probe is not None else None, grad_shifts.ptr))
         if want_grad and accumulate:
             self.accumulate_tiles()
 

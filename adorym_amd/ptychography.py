@@ -167,9 +167,8 @@ def reconstruct_ptychography(
     if unknown_type not in ('delta_beta', 'real_imag'):
         raise ValueError("unknown_type must be 'delta_beta' or 'real_imag'")
     if unknown_type == 'real_imag':
-        # accelerated subset for complex-transmission unknowns: no regularisers / masks / object-type constraints yet
-        _not_implemented(regularizers not in (None, []) or alpha_d not in (0, None) or alpha_b not in (0, None) or gamma not in (0, None),
-                         "regularisers with unknown_type='real_imag' (pass gamma=0, alpha_d=0, alpha_b=0)")
+        # accelerated subset for complex-transmission unknowns: no masks / object-type constraints / binning yet
+        _not_implemented(reweighted_l1, "reweighted L1 with unknown_type='real_imag'")
         _not_implemented(finite_support_mask_path is not None, "finite support mask with unknown_type='real_imag'")
         _not_implemented(object_type != 'normal', "object_type='%s' with unknown_type='real_imag'" % object_type)
         _not_implemented(binning != 1, "binning > 1 with unknown_type='real_imag'")
@@ -180,13 +179,12 @@ def reconstruct_ptychography(
     _not_implemented(beamstop is not None, 'beamstop')
     _not_implemented(not common_probe_pos, 'common_probe_pos=False')
     _not_implemented(not shared_probe_among_angles, 'shared_probe_among_angles=False')
-    _not_implemented(rescale_probe_intensity or probe_extra_defocus_cm is not None, 'probe rescaling / extra defocus')
     _not_implemented(update_using_external_algorithm is not None, 'update_using_external_algorithm')
     _not_implemented(shrink_cycle is not None, 'shrink-wrap mask updates')
     _not_implemented(initial_tilt is not None, 'initial_tilt')
     _not_implemented(interpolation != 'bilinear', "interpolation='%s'" % interpolation)
     for nm, flag in (('optimize_probe_defocusing', optimize_probe_defocusing), ('optimize_probe_pos_offset', optimize_probe_pos_offset),
-                     ('optimize_prj_pos_offset', optimize_prj_pos_offset), ('optimize_all_probe_pos', optimize_all_probe_pos),
+                     ('optimize_prj_pos_offset', optimize_prj_pos_offset),
                      ('optimize_slice_pos', optimize_slice_pos), ('optimize_free_prop', optimize_free_prop),
                      ('optimize_prj_affine', optimize_prj_affine), ('optimize_tilt', optimize_tilt),
                      ('optimize_ctf_lg_kappa', optimize_ctf_lg_kappa)):
@@ -359,7 +357,7 @@ def reconstruct_ptychography(
                        theta_ls=theta_ls, energy_ev=energy_ev, psize_cm=psize_cm, h=h, free_prop_cm=free_prop_cm,
                        minibatch_size=minibatch_size, n_probe_modes=n_probe_modes, beamstop=beamstop,
                        optimize_probe_defocusing=False, optimize_probe_pos_offset=False, optimize_prj_pos_offset=False,
-                       optimize_all_probe_pos=False, optimize_tilt=False, output_folder=output_folder, debug=debug)
+                       optimize_all_probe_pos=optimize_all_probe_pos, optimize_tilt=False, output_folder=output_folder, debug=debug)
     _not_implemented(rotate_out_of_loop, 'rotate_out_of_loop')
     fm_args = dict(loss_function_type=loss_function_type, distribution_mode=distribution_mode, device=ctx,
                    common_vars_dict=common_vars, raw_data_type=raw_data_type, run_bfloat16=run_bfloat16, run_float64=run_float64)
@@ -398,7 +396,11 @@ def reconstruct_ptychography(
     if rank == 0:
         pk = dict(kwargs)
         pk.update(lmbda_nm=lmbda_nm, psize_cm=psize_cm, normalize_fft=normalize_fft, n_probe_modes=n_probe_modes)
-        pr0, pi0 = initialize_probe(probe_size, probe_type, pupil_function=pupil_function, probe_initial=probe_initial, **pk)
+        pk.pop('raw_data_type', None)
+        pr0, pi0 = initialize_probe(probe_size, probe_type, pupil_function=pupil_function, probe_initial=probe_initial,
+                                    rescale_intensity=rescale_probe_intensity, extra_defocus_cm=probe_extra_defocus_cm,
+                                    sign_convention=sign_convention, raw_data_type=raw_data_type,
+                                    data_first_angle=np.asarray(prj[0:1]) if rescale_probe_intensity else None, **pk)
         if n_probe_modes == 1:
             probe_real = np.stack([np.squeeze(pr0)]) if pr0.ndim != 3 else pr0[:1]
             probe_imag = np.stack([np.squeeze(pi0)]) if pi0.ndim != 3 else pi0[:1]
@@ -440,6 +442,23 @@ def reconstruct_ptychography(
         opt_args_ls = opt_args_ls + [forward_model.get_argument_index('probe_real'), forward_model.get_argument_index('probe_imag')]
         opt_ls.append(opt_probe)
         probe_grad_dev = ctx.zeros(probe_dev.shape)
+
+    opt_probe_pos = None
+    if optimize_all_probe_pos:
+        # optimizers.py:877-889: Adam on probe_pos_correction [n_theta, n_pos, 2], kept on the device
+        if optimizer_all_probe_pos is not None:
+            opt_probe_pos = optimizer_all_probe_pos
+            opt_probe_pos.name = 'probe_pos_correction'
+        else:
+            opt_probe_pos = AdamOptimizer('probe_pos_correction', output_folder=output_folder,
+                                          options_dict={'step_size': all_probe_pos_learning_rate}, forward_model=forward_model)
+        corr_shape = list(optimizable_params['probe_pos_correction'].shape)
+        optimizable_params['probe_pos_correction'] = ctx.array(optimizable_params['probe_pos_correction'], np.float32)
+        opt_probe_pos.create_param_arrays(corr_shape, device=ctx)
+        opt_probe_pos.set_index_in_grad_return(len(opt_args_ls))
+        opt_args_ls = opt_args_ls + [forward_model.get_argument_index('probe_pos_correction')]
+        opt_ls.append(opt_probe_pos)
+        pos_grad_dev = ctx.zeros(corr_shape)
 
     diff = Differentiator()
     calculate_loss = forward_model.get_loss_function()
@@ -546,6 +565,8 @@ def reconstruct_ptychography(
                 state.zero_grad()
                 if optimize_probe:
                     probe_grad_dev.zero_()
+                if optimize_all_probe_pos:
+                    pos_grad_dev.zero_()
             grad_func_args = {}
             for arg in forward_model.argument_ls:
                 if arg == 'obj':
@@ -566,9 +587,11 @@ def reconstruct_ptychography(
             if initialize_gradients:
                 initialize_gradients = False
             if optimize_probe:
-                g = np.ascontiguousarray(np.stack([grads[1], grads[2]], -1), dtype=np.float32)
-                tmp = ctx.array(g)
-                _lib.check(ctx.lib.adm_axpy(ctx.handle, probe_grad_dev.ptr, tmp.ptr, 1.0, tmp.size))
+                gpd = grads[opt_probe.index_in_grad_returns]       # interleaved (real, imag) device array
+                _lib.check(ctx.lib.adm_axpy(ctx.handle, probe_grad_dev.ptr, gpd.ptr, 1.0, gpd.size))
+            if optimize_all_probe_pos:
+                gcd = grads[opt_args_ls.index(forward_model.get_argument_index('probe_pos_correction'))]
+                _lib.check(ctx.lib.adm_axpy(ctx.handle, pos_grad_dev.ptr, gcd.ptr, 1.0, gcd.size))
 
             if update_scheme == 'per angle' and not is_last_batch_of_this_theta:
                 continue
@@ -597,6 +620,17 @@ def reconstruct_ptychography(
                 else:
                     print_flush('  Probe is not updated because current batch is out of the specified range ({}, {}).'.format(
                         probe_update_delay, probe_update_limit), 0, rank, **stdout_options)
+
+            # ---- sub-pixel probe positions (optimizers.py:1037-1049) ----
+            if optimize_all_probe_pos and i_batch + i_epoch * n_batch >= other_params_update_delay:
+                corr_dev = optimizable_params['probe_pos_correction']
+                if n_ranks > 1:
+                    g = comm.torch.from_numpy(pos_grad_dev.get()).to(comm.device)
+                    comm.all_reduce_sum(g)
+                    pos_grad_dev.set(g.cpu().numpy())
+                opt_probe_pos.apply_gradient(corr_dev, pos_grad_dev, i_opt_batch, **opt_probe_pos.options_dict)
+                # prevent position drifting: subtract the mean over (theta, position)
+                _lib.check(ctx.lib.adm_center_rows(ctx.handle, corr_dev.ptr, corr_dev.size // 2, 2))
 
             # ---- finishing a batch (ptychography.py:1231-1271) ----
             current_loss = forward_model.current_loss
@@ -640,6 +674,8 @@ def reconstruct_ptychography(
     if return_state:
         arr = obj.arr.get()
         pa = probe_dev.get()
+        pc = optimizable_params['probe_pos_correction']
         return {'delta': arr[..., 0], 'beta': arr[..., 1], 'probe_real': pa[..., 0], 'probe_imag': pa[..., 1],
+                'probe_pos_correction': pc.get() if hasattr(pc, 'get') else np.asarray(pc),
                 'losses': loss_history, 'output_folder': output_folder}
     return None

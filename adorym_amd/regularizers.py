@@ -1,14 +1,15 @@
 """Regulariser descriptors with the reference's constructor signatures (adorym/regularizers.py).
-The values / gradients are evaluated on the GPU by adm_reg_grad (L1 + TV fused in one pass)."""
+The values / gradients are evaluated on the GPU by adm_reg_grad (L1 + TV fused in one pass; the plan's
+unknown_type selects the delta_beta or the real_imag definition, regularizers.py:30-46 / 95-110)."""
 
 
 class Regularizer(object):
     """adorym/regularizers.py:5-15."""
 
     def __init__(self, unknown_type='delta_beta'):
+        if unknown_type not in ('delta_beta', 'real_imag'):
+            raise ValueError("unknown_type must be 'delta_beta' or 'real_imag'")
         self.unknown_type = unknown_type
-        if unknown_type != 'delta_beta':
-            raise NotImplementedError("unknown_type='real_imag' regularisers are outside the accelerated path")
 
     def weights(self):
         """(alpha_d, alpha_b, gamma) contribution of this term."""
@@ -45,6 +46,8 @@ class ReweightedL1Regularizer(Regularizer):
 
     def __init__(self, alpha_d, alpha_b, unknown_type='delta_beta'):
         super(ReweightedL1Regularizer, self).__init__(unknown_type)
+        if unknown_type != 'delta_beta':
+            raise NotImplementedError("reweighted L1 with unknown_type='real_imag' is outside the accelerated path")
         self.alpha_d = alpha_d
         self.alpha_b = alpha_b
         self.weight_l1 = None

@@ -65,25 +65,70 @@ def mag_phase_to_real_imag(mag, phase):
     return a.real, a.imag
 
 
-def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=None, **kwargs):
-    """adorym/util.py:198-283, the branches that need no data file: 'gaussian', 'plane',
-    'supplied'/'fixed'.  Returns (probe_real, probe_imag) as float64 arrays."""
+def generate_disk(shape, radius):
+    """adorym/util.py:1484-1492: soft-edged disk clip(radius - r, 0, 1) about the array centre."""
+    radius = int(radius)
+    x = np.arange(shape[1]) - (shape[1] - 1) / 2
+    y = np.arange(shape[0]) - (shape[0] - 1) / 2
+    xx, yy = np.meshgrid(x, y)
+    return np.clip(radius - np.sqrt(xx ** 2 + yy ** 2), 0, 1)
+
+
+def _fresnel_propagate_host(probe_real, probe_imag, dist_nm, lmbda_nm, voxel_nm, sign_convention=1):
+    """adorym/propagate.py:537-553 on the host in float64 (the reference runs this one-off initialisation through its NumPy
+    backend as well, override_backend='autograd')."""
+    from .propagate import get_kernel
+    h = get_kernel(dist_nm, lmbda_nm, voxel_nm, probe_real.shape[-2:], sign_convention=sign_convention)
+    out = np.fft.ifft2(np.fft.fft2(probe_real + 1j * probe_imag) * h)
+    return out.real, out.imag
+
+
+def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=None, rescale_intensity=False,
+                     extra_defocus_cm=None, sign_convention=1, data_first_angle=None, **kwargs):
+    """adorym/util.py:198-283: 'gaussian', 'aperture_defocus', 'plane', 'supplied'/'fixed' (+ pupil, extra defocus,
+    intensity rescaling).  ``data_first_angle`` = exchange/data[0:1] (the reference re-opens the HDF5 file for it).
+    Returns (probe_real, probe_imag) as float64 arrays."""
     if probe_type == 'gaussian':
         mag, phase = generate_gaussian_map(probe_size, 1, kwargs['probe_mag_sigma'], kwargs['probe_phase_max'],
                                            kwargs['probe_phase_sigma'])
         probe_real, probe_imag = mag_phase_to_real_imag(mag, phase)
+    elif probe_type == 'aperture_defocus':
+        mag = generate_disk(probe_size, kwargs['aperture_radius'])
+        beamstop_radius = kwargs.get('beamstop_radius', 0)
+        if beamstop_radius > 0:
+            mag = mag * (1 - generate_disk(probe_size, beamstop_radius))
+        probe_real, probe_imag = _fresnel_propagate_host(mag, np.zeros_like(mag), kwargs['probe_defocus_cm'] * 1e7, kwargs['lmbda_nm'],
+                                                         [kwargs['psize_cm'] * 1e7] * 3, sign_convention)
     elif probe_type in ('supplied', 'fixed'):
         probe_real, probe_imag = mag_phase_to_real_imag(np.asarray(probe_initial[0]), np.asarray(probe_initial[1]))
     elif probe_type == 'plane':
         probe_real = np.ones(probe_size)
         probe_imag = np.zeros(probe_size)
-    elif probe_type in ('aperture_defocus', 'ifft'):
-        raise NotImplementedError("probe_type '%s' is outside the accelerated path (SURVEY section 8 f2)" % probe_type)
+    elif probe_type == 'ifft':
+        raise NotImplementedError("probe_type 'ifft' is outside the accelerated path")
     else:
         raise ValueError("Invalid wavefront type. Choose from 'plane', 'fixed', 'supplied'.")
     if pupil_function is not None:
         probe_real = probe_real * pupil_function
         probe_imag = probe_imag * pupil_function
+    if extra_defocus_cm is not None:
+        probe_real, probe_imag = _fresnel_propagate_host(probe_real, probe_imag, extra_defocus_cm * 1e7, kwargs['lmbda_nm'],
+                                                         [kwargs['psize_cm'] * 1e7] * 3, sign_convention)
+    if rescale_intensity:
+        # util.py:254-281 (including its `len(probe_real) == 3` test for the per-mode normalisation)
+        dat = np.asarray(data_first_angle, dtype=np.float64)
+        if kwargs['raw_data_type'] == 'magnitude':
+            dat = dat ** 2
+        npix = np.prod(np.shape(probe_real)[-2:])
+        intensity_target = np.sum(np.mean(np.abs(dat), axis=(0, 1)))
+        if not kwargs['normalize_fft']:
+            intensity_target = intensity_target / npix if sign_convention == 1 else intensity_target * npix
+        intensity_current = np.sum(probe_real ** 2 + probe_imag ** 2)
+        if len(probe_real) == 3:
+            intensity_current /= probe_real.shape[0]
+        s_ = np.sqrt(intensity_target / intensity_current)
+        probe_real = probe_real * s_
+        probe_imag = probe_imag * s_
     return probe_real, probe_imag
 
 

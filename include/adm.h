@@ -152,6 +152,28 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
                            const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                            float grad_scale, void* workspace, size_t workspace_bytes);
 
+/* Same as adm_multislice_fwd_adj with ONE PROBE SET PER POSITION (sub-pixel probe positions, adorym/forward_model.py:
+ * 296-311 + 337-375): probes device [batch][n_modes][Py][Px][2]; grad_probes device [batch][n_modes][Py][Px][2] or NULL,
+ * OVERWRITTEN with the per-position probe gradients (input of adm_probe_shift_adj). */
+int adm_multislice_fwd_adj_pp(adm_plan* plan, const float* obj_rot, const float* probes, const int32_t* pos, int batch,
+                              const float* target, int want_grad, float* grad_probes, float* pred, float* loss_sum,
+                              float grad_scale, void* workspace, size_t workspace_bytes);
+
+/* ---- f2  sub-pixel probe positions -----------------------------------------------------
+ * realign_image_fourier (adorym/util.py:380-397) applied to every probe mode for every position of a minibatch:
+ *   probes_out[b][m] = IFFT2( exp(-2 PI i (fx*sx_b + fy*sy_b)) * FFT2(probe[m]) ),  PI = 3.14159265359, f = fftfreq.
+ * shifts  device float [n_entries][2] = (sy, sx), the reference's probe_pos_correction flattened over (theta, position)
+ * index   device int32 [batch]: entry used by position b; NULL = entry b
+ * adm_probe_shift_adj is the adjoint (what torch.autograd.grad returns through that op for probe_real/imag and
+ * probe_pos_correction): grad_probe [n_modes][Py][Px][2] += sum_b shift_{-s_b}(grad_probes[b]) (may be NULL);
+ * grad_shifts[index[b]][0..1] += dL/d(sy, sx) (float [n_entries][2], NOT zeroed by the call). */
+int adm_probe_shift(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch, float* probes_out);
+int adm_probe_shift_adj(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,
+                        const float* grad_probes, float* grad_probe, float* grad_shifts);
+/* x[r][c] -= mean_r x[r][c]: the drift guard applied to probe_pos_correction after its update
+ * (adorym/optimizers.py:1046-1048).  Single workgroup; meant for small parameter arrays. */
+int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols);
+
 /* Adjoint of the tile gather (adorym/forward_model.py:313-331 under autograd): overlap-adds the tile
  * gradients left in `workspace` by adm_multislice_fwd_adj(want_grad=1) for the same pos/batch and WRITES
  * (not accumulates) them into every padded row of grad_rot [Z][Yp][Xp][2] touched by the batch; pixels of
@@ -166,7 +188,9 @@ int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes
 /* ---- R9  regulariser gradients --------------------------------------------------------
  * L1Regularizer / TVRegularizer (adorym/regularizers.py:30-46, 95-110; adorym/util.py:1427-1440):
  * grad_obj += d/dobj [ alpha_d*mean|delta| + alpha_b*mean|beta| + gamma*(TV(delta)+TV(beta)) ];
- * reg_value (device float[1], may be NULL) += the regulariser value. */
+ * reg_value (device float[1], may be NULL) += the regulariser value.
+ * Plans with unknown_type 'real_imag' evaluate the reference's real_imag branches instead (regularizers.py:38-45,
+ * 105-110): alpha_d*mean| |o| - mean|o| | + alpha_b*mean|arg o| + gamma*(TV(re^2+im^2) + TV(atan2(im, re))). */
 int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
                  float* reg_value);
 

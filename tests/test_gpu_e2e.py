@@ -77,8 +77,8 @@ def test_probe_optimisation_runs_and_reduces_loss(tmp_path):
 
 
 def test_unsupported_options_raise(tmp_path):
-    for bad in (dict(distribution_mode='shared_file'), dict(unknown_type='real_imag', gamma=1e-6), dict(optimizer='cg'),
-                dict(optimize_all_probe_pos=True), dict(optimize_probe_defocusing=True), dict(cpu_only=True)):
+    for bad in (dict(distribution_mode='shared_file'), dict(unknown_type='real_imag', reweighted_l1=True, alpha_d=1e-3), dict(optimizer='cg'),
+                dict(optimize_probe_pos_offset=True), dict(optimize_probe_defocusing=True), dict(cpu_only=True)):
         with pytest.raises(NotImplementedError):
             run(tmp_path, n_epochs=1, **bad)
 

@@ -212,3 +212,116 @@ def test_two_d_real_imag_driver_vs_oracle(A, ctx, tmp_path):
     upd = np.linalg.norm(ref - np.stack([g0.real, g0.imag], -1))
     assert np.linalg.norm(x - ref) < 5e-3 * upd
     assert sorted(f for f in os.listdir(st['output_folder']) if f.startswith('obj_')) == ['obj_mag_ds_1.tiff', 'obj_phase_ds_1.tiff']
+
+
+# ------------------------------------------------------------------------------------ f2 row: sub-pixel probe positions
+@pytest.mark.parametrize('name,kind,fp', [('db_s5_far', 'delta_beta', 'inf'), ('ri_s1_far', 'real_imag', 'inf'),
+                                          ('ri_s3_near', 'real_imag', 0)])
+def test_position_gradients_vs_reference(A, ctx, name, kind, fp):
+    """Fourier-shifted probes per position + gradients w.r.t. shifts, probe modes and tiles against the reference's
+    autograd (golden F11; fp64 values, compared with the 3x rule against the reference's own fp32 run)."""
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F11_c1.npz'))
+    tiles, probe, shifts, meas = f[name + '_tiles'], f[name + '_probe'], f[name + '_shifts'], f[name + '_meas']
+    B, P, _, S, _ = tiles.shape
+    M = probe.shape[0]
+    # lay the tiles side by side in a [P, B*P, S] object
+    obj = np.concatenate(list(tiles), axis=1)
+    pos = np.array([[0, b * P] for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (P, B * P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=fp, n_probe_modes=M,
+                             max_batch=B, unknown_type=kind)
+    eng.set_batch(pos, meas.astype(np.float32))
+    obj_d = ctx.array(obj.astype(np.float32))
+    eng.rotate(obj_d, None, None)
+    probe_d = ctx.array(np.stack([probe.real, probe.imag], -1).astype(np.float32))
+    sh_d = ctx.array(shifts.astype(np.float32))
+    gp = ctx.zeros(probe_d.shape)
+    gs = ctx.zeros(sh_d.shape)
+    eng.multislice(probe_d, grad_probe=gp, want_pred=True, shifts=sh_d, grad_shifts=gs)
+    g_obj = ctx.zeros(obj_d.shape)
+    eng.rotate_adjoint(g_obj, None, None)
+    loss = eng.loss()
+    t64, t32 = name + '_64', name + '_32'
+    assert abs(loss - f[t64 + '_loss']) < 2e-5 * abs(f[t64 + '_loss'])
+    pred = eng.pred()
+    assert np.linalg.norm(pred - f[t64 + '_pred']) < 2e-6 * np.linalg.norm(f[t64 + '_pred'])
+    gt = np.stack(np.split(g_obj.get(), B, axis=1))
+    gph = gp.get()
+    for mine, key in ((gt, '_grad_tiles'), (gph[..., 0] + 1j * gph[..., 1], '_grad_probe'), (gs.get(), '_grad_shifts')):
+        ref64, ref32 = f[t64 + key], f[t32 + key]
+        err = np.linalg.norm(mine - ref64) / np.linalg.norm(ref64)
+        err_ref = np.linalg.norm(ref32 - ref64) / np.linalg.norm(ref64)
+        assert err < max(1e-4, 3 * err_ref), (key, err, err_ref)
+
+
+def test_probe_shift_kernel_vs_reference(A, ctx):
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F11_c1.npz'))
+    probe = f['shift_probe']
+    M, P = probe.shape[:2]
+    eng = A.MultisliceEngine(ctx, (P, P, 1), (P, P), np.zeros((1, 2)), cases.ENERGY_EV, cases.PSIZE_CM, n_probe_modes=M, max_batch=3)
+    shifts = np.stack([f['shift%d_s' % k] for k in range(3)]).astype(np.float32)
+    out = ctx.empty((3, M, P, P, 2))
+    from adorym_amd._lib import check
+    probe_d = ctx.array(np.stack([probe.real, probe.imag], -1).astype(np.float32))
+    shifts_d = ctx.array(shifts)
+    check(ctx.lib.adm_probe_shift(eng.plan.handle, probe_d.ptr, shifts_d.ptr, None, 3, out.ptr))
+    o = out.get()
+    for k in range(3):
+        ref = f['shift%d_64' % k]
+        assert np.abs(o[k, ..., 0] + 1j * o[k, ..., 1] - ref).max() < 3e-6 * np.abs(ref).max()
+
+
+def test_real_imag_regularisers_vs_reference(A, ctx):
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F11_c1.npz'))
+    obj = f['reg_obj']
+    Y, X, Z = obj.shape[:3]
+    eng = A.MultisliceEngine(ctx, (Y, X, Z), (8, 8), np.zeros((1, 2)), cases.ENERGY_EV, cases.PSIZE_CM, max_batch=1, unknown_type='real_imag')
+    from adorym_amd._lib import check
+    x = ctx.array(obj.astype(np.float32))
+    for (ad, ab, gm), key in (((0., 0., 0.7), 'tv'), ((0.8, 0.3, 0.), 'l1')):
+        g = ctx.zeros(x.shape)
+        val = ctx.zeros((1,))
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, x.ptr, ad, ab, gm, g.ptr, val.ptr))
+        assert abs(val.get()[0] - f['reg_%s_val' % key]) < 2e-6 * abs(f['reg_%s_val' % key])
+        ref = f['reg_%s_grad' % key]
+        assert np.abs(g.get() - ref).max() < 1e-5 * np.abs(ref).max()
+
+
+def test_center_rows(A, ctx):
+    from adorym_amd._lib import check
+    r = cases.rng(5)
+    x = r.standard_normal((1000, 2)).astype(np.float32) + 3
+    d = ctx.array(x)
+    check(ctx.lib.adm_center_rows(ctx.handle, d.ptr, 1000, 2))
+    assert np.abs(d.get() - (x - x.mean(0))).max() < 1e-5
+
+
+def test_config1_shape_driver_vs_reference(A, ctx, tmp_path):
+    """The whole config-1 feature set through reconstruct_ptychography on the GPU against the REFERENCE driver's own run
+    (golden F11): 2-D, real_imag unknowns, two probe modes, intensity data, probe rescaling, Adam on object + probe +
+    sub-pixel position corrections, TV regulariser on |o|^2 and arg o."""
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F11_c1.npz'))
+    Cc = cases.C1MINI
+    inp = cases.c1mini_inputs()
+    st = A.reconstruct_ptychography(
+        fname=f['e2e_prj'], obj_size=(Cc['Y'], Cc['X'], 1), probe_pos=inp['pos_nominal'], theta_st=0, theta_end=0, n_theta=1,
+        two_d_mode=True, energy_ev=Cc['energy_ev'], psize_cm=Cc['psize_cm'], free_prop_cm='inf', minibatch_size=Cc['minibatch_size'],
+        n_epochs=2, initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='supplied',
+        probe_initial=[inp['probe_guess'][0], inp['probe_guess'][1]], n_probe_modes=Cc['M'], rescale_probe_intensity=True,
+        raw_data_type='intensity', optimize_probe=True, probe_learning_rate=1e-3, optimize_all_probe_pos=True,
+        all_probe_pos_learning_rate=1e-2, unknown_type='real_imag', gamma=1e-6, optimizer='adam', learning_rate=1e-3,
+        n_dp_batch=Cc['n_dp_batch'], save_path=str(tmp_path), output_folder='c1', store_checkpoint=False, use_checkpoint=False,
+        return_state=True)
+    assert np.allclose(st['losses'], f['e2e_losses_64'], rtol=5e-4)
+    x = np.stack([st['delta'], st['beta']], -1)
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    upd = np.linalg.norm(f['e2e_obj_64'] - np.stack([g0.real, g0.imag], -1))
+
+    def rel(a, b, scale):
+        return np.linalg.norm(a - b) / scale
+    e_obj, e_obj_ref = rel(x, f['e2e_obj_64'], upd), rel(f['e2e_obj_32'], f['e2e_obj_64'], upd)
+    assert e_obj < max(5e-3, 3 * e_obj_ref), (e_obj, e_obj_ref)
+    p = st['probe_real'] + 1j * st['probe_imag']
+    pn = np.linalg.norm(f['e2e_probe_64'])
+    assert rel(p, f['e2e_probe_64'], pn) < max(1e-4, 3 * rel(f['e2e_probe_32'], f['e2e_probe_64'], pn))
+    cn = np.linalg.norm(f['e2e_pos_corr_64'])
+    assert rel(st['probe_pos_correction'], f['e2e_pos_corr_64'], cn) < max(2e-2, 3 * rel(f['e2e_pos_corr_32'], f['e2e_pos_corr_64'], cn))
