@@ -320,6 +320,7 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
     p.poisson_mult = d.poisson_multiplier;
     p.real_imag = d.unknown_type;
     if (per_position) {
+        if (d.binning != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: binning > 1 is not implemented with per-position probes");
         p.probe_bstride = p.gprobe_bstride = (size_t)d.n_modes * d.probe_y * d.probe_x;
         if (grad_probe && want_grad)
             ADM_HIP(hipMemsetAsync(grad_probe, 0, (size_t)batch * p.gprobe_bstride * sizeof(float2), plan->ctx->stream));

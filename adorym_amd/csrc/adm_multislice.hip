@@ -526,7 +526,9 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
     }
 }
 
-template <int N, int R1, int R2, bool BIN1, bool MULTI, bool RI>
+// PP: one probe set per position (sub-pixel probe positions); a template parameter because even the two extra address
+// computations measurably perturb the schedule of the tuned default kernel (+3 %).
+template <int N, int R1, int R2, bool BIN1, bool MULTI, bool RI, bool PP>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
@@ -611,7 +613,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     float lsum = 0.f;
     if (!MULTI) {
         // ================= single probe mode: everything stays in registers =================
-        load_probe<N, R1, R2>(c, a, p.probe + (size_t)b * p.probe_bstride);
+        load_probe<N, R1, R2>(c, a, PP ? p.probe + (size_t)b * p.probe_bstride : p.probe);
         fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
         detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
         if (p.det_mode == ADM_DET_FARFIELD_) {
@@ -644,7 +646,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
         rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
-        add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr);
+        add_probe_grad<N, R1, R2>(c, a, (PP && p.grad_probe) ? p.grad_probe + (size_t)b * p.gprobe_bstride : p.grad_probe);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
         // pred = sqrt(sum_m |Psi_m|^2): the detector-plane fields of all modes are parked in HBM (thread-native
@@ -656,7 +658,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 #pragma unroll
         for (int k = 0; k < GE::G; ++k) inten[k] = 0.f;
         for (int m = 0; m < M; ++m) {
-            load_probe<N, R1, R2>(c, a, p.probe + (size_t)b * p.probe_bstride + (size_t)m * N * N);
+            load_probe<N, R1, R2>(c, a, p.probe + (PP ? (size_t)b * p.probe_bstride : 0) + (size_t)m * N * N);
             fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
             detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
             float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
@@ -716,7 +718,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
             if (m == 0) rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
             else rev_sweep<N, R1, R2, BIN1, true, RI>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
-            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride + (size_t)m * N * N : nullptr);
+            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (PP ? (size_t)b * p.gprobe_bstride : 0) + (size_t)m * N * N : nullptr);
         }
     }
 }
@@ -724,19 +726,21 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
     const dim3 g(batch), t(GE::NT);
-    if (p.real_imag) {          // binning == 1 is enforced at plan creation
-        if (p.n_modes > 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true, true>), g, t, 0, st, p);
-        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, true>), g, t, 0, st, p);
-    } else if (p.n_modes > 1) {
-        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, true, false>), g, t, 0, st, p);
-        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, true, false>), g, t, 0, st, p);
+#define ADM_LAUNCH(B1, MU, RI_, PP_) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, B1, MU, RI_, PP_>), g, t, 0, st, p)
+    const bool multi = p.n_modes > 1;
+    if (p.probe_bstride) {          // per-position probes: binning == 1 only (checked by the caller)
+        if (p.real_imag) { if (multi) ADM_LAUNCH(true, true, true, true); else ADM_LAUNCH(true, false, true, true); }
+        else { if (multi) ADM_LAUNCH(true, true, false, true); else ADM_LAUNCH(true, false, false, true); }
+    } else if (p.real_imag) {       // binning == 1 is enforced at plan creation
+        if (multi) ADM_LAUNCH(true, true, true, false); else ADM_LAUNCH(true, false, true, false);
+    } else if (multi) {
+        if (p.binning == 1) ADM_LAUNCH(true, true, false, false); else ADM_LAUNCH(false, true, false, false);
     } else {
-        if (p.binning == 1) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, false>), g, t, 0, st, p);
-        else hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, false, false, false>), g, t, 0, st, p);
+        if (p.binning == 1) ADM_LAUNCH(true, false, false, false); else ADM_LAUNCH(false, false, false, false);
     }
+#undef ADM_LAUNCH
     return hipGetLastError();
 }
-
 
 // =====================================================================================================================
 // Sub-pixel probe positions: position b sees every probe mode Fourier-shifted by its correction (sy, sx)
