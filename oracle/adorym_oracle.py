@@ -913,3 +913,127 @@ def reconstruct_2d(prj, obj_init, probes, probe_pos, phys, n_epochs=1, minibatch
                 i_opt_batch += 1
     out = dict(obj=obj, probes=pst[..., 0] + 1j * pst[..., 1], pos_corr=corr, losses=losses, first_grad=first_grad)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# f1  multi-distance holography (MultiDistModel, forward_model.py:809-1092), one undivided tile, S = 1
+# --------------------------------------------------------------------------------------
+def affine_sample(img, theta, want_grad_theta=False, cot=None):
+    """w.affine_transform (wrappers.py:1158-1174) = F.affine_grid (align_corners=False) + F.grid_sample (bilinear,
+    padding_mode='border', align_corners=False) for one image [H,W] and one 2x3 matrix.  With ``cot`` (cotangent of the
+    output) also returns d<cot, out>/dtheta [2,3] as torch's grid_sampler backward does (zero through clamped coordinates)."""
+    H, W = img.shape
+
+    def base(n):
+        # torch: linspace(-1, 1, n) * (n - 1) / n; the linspace is evaluated from both ends with a FUSED multiply-add
+        # (fma(step, i, -1) below the middle, fma(-step, n-1-i, 1) above).  Reproduced to the rounding because at the
+        # identity transform the sampling points sit ON pixel centres, where floor() decides which one-sided
+        # derivative the backward pass sees.  The fma is emulated in the next wider type.
+        dt_ = img.dtype.type
+        wide = np.longdouble if img.dtype == np.float64 else np.float64
+        step = wide(dt_(2) / dt_(n - 1))
+        i = np.arange(n)
+        lo = (wide(-1) + step * i.astype(wide)).astype(img.dtype)
+        hi = (wide(1) - step * (n - 1 - i).astype(wide)).astype(img.dtype)
+        r = np.where(i < n // 2, lo, hi)
+        return (r * dt_(n - 1)) / dt_(n)
+    X, Y = np.meshgrid(base(W), base(H))
+    gx = theta[0, 0] * X + theta[0, 1] * Y + theta[0, 2]
+    gy = theta[1, 0] * X + theta[1, 1] * Y + theta[1, 2]
+    ix = ((gx + 1) * W - 1) / 2
+    iy = ((gy + 1) * H - 1) / 2
+    mx = ((ix > 0) & (ix < W - 1)).astype(img.dtype)          # clip_coordinates_set_grad: 0 at and beyond the borders
+    my = ((iy > 0) & (iy < H - 1)).astype(img.dtype)
+    ix = np.clip(ix, 0, W - 1)
+    iy = np.clip(iy, 0, H - 1)
+    x0 = np.floor(ix).astype(int); y0 = np.floor(iy).astype(int)
+    wx = ix - x0; wy = iy - y0
+    x1 = np.minimum(x0 + 1, W - 1); y1 = np.minimum(y0 + 1, H - 1)
+    # corners outside the image get weight 0 in torch (within_bounds test): x0+1 == W only happens with wx == 0
+    v00, v01, v10, v11 = img[y0, x0], img[y0, x1], img[y1, x0], img[y1, x1]
+    out = v00 * (1 - wx) * (1 - wy) + v01 * wx * (1 - wy) + v10 * (1 - wx) * wy + v11 * wx * wy
+    if cot is None:
+        return out
+    dix = ((v01 - v00) * (1 - wy) + (v11 - v10) * wy) * mx * (W / 2) * cot
+    diy = ((v10 - v00) * (1 - wx) + (v11 - v01) * wx) * my * (H / 2) * cot
+    g = np.array([[np.sum(dix * X), np.sum(dix * Y), np.sum(dix)], [np.sum(diy * X), np.sum(diy * Y), np.sum(diy)]])
+    return out, g
+
+
+def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm, raw_data_type='intensity',
+                         sign_convention=1, dtype='float64'):
+    """Loss and gradients of the multi-distance chain for a real_imag object [N,N,1,2] under a complex probe [N,N]:
+    psi = probe*o;  Psi_d = IFFT2(FFT2(psi) * exp(-i sigma PI lambda d (u^2+v^2)))  (propagate.py:84-103, 556-568);
+    loss = mean_d,pixels (|Psi_d| - sqrt|affine(data_d, A_d)|)^2.  Returns loss, pred, target, grad_obj [N,N,1,2],
+    grad_probe (complex), grad_dists_cm [n_d], grad_affine [n_d,2,3]."""
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    N0, N1 = obj.shape[:2]
+    lm = 1240. / energy_ev
+    u, v = gen_freq_mesh(np.array([psize_cm * 1e7] * 3), [N0, N1])
+    uv2 = (u ** 2 + v ** 2).astype(dt)
+    o = (obj[:, :, 0, 0] + 1j * obj[:, :, 0, 1]).astype(cdt)
+    psi = (probe.astype(cdt) * o).astype(cdt)
+    F = np.fft.fft2(psi).astype(cdt)
+    nd = len(dists_cm)
+    n_tot = nd * N0 * N1
+    loss = 0.
+    preds, tgts = [], []
+    g_dists = np.zeros(nd, dtype=dt)
+    g_aff = np.zeros((nd, 2, 3), dtype=dt)
+    GF = np.zeros_like(F)
+    for i in range(nd):
+        d_nm = dt.type(dists_cm[i]) * dt.type(1e7)
+        arg = (dt.type(-sign_convention * PI * lm) * d_nm * uv2).astype(dt)
+        Hd = (np.cos(arg) + 1j * np.sin(arg)).astype(cdt)
+        Psi = np.fft.ifft2(F * Hd).astype(cdt)
+        pred = np.abs(Psi)
+        samp = affine_sample(np.asarray(data[i], dtype=dt), np.asarray(affine[i], dtype=dt))
+        tgt = np.sqrt(np.abs(samp)) if raw_data_type == 'intensity' else np.abs(samp)
+        diff = pred - tgt
+        loss += np.sum(diff ** 2) / n_tot
+        with np.errstate(divide='ignore', invalid='ignore'):
+            G = np.where(pred > 0, (2 / n_tot) * diff * Psi / pred, 0).astype(cdt)
+            dtgt = -(2 / n_tot) * diff
+            cot = dtgt * (np.sign(samp) / (2 * np.sqrt(np.abs(samp))) if raw_data_type == 'intensity' else np.sign(samp))
+        cot = np.where(np.isfinite(cot), cot, 0)
+        _, g_aff[i] = affine_sample(np.asarray(data[i], dtype=dt), np.asarray(affine[i], dtype=dt), cot=cot)
+        Gh = np.fft.fft2(G) / (N0 * N1)
+        dH = (-1j * sign_convention * PI * lm) * uv2 * Hd
+        g_dists[i] = np.real(np.sum(np.conj(Gh) * dH * F)) * 1e7
+        GF += np.conj(Hd) * Gh
+        preds.append(pred); tgts.append(tgt)
+    g_psi = np.fft.ifft2(GF) * (N0 * N1)
+    g_o = g_psi * np.conj(probe)
+    g_obj = np.zeros_like(obj, dtype=dt)
+    g_obj[:, :, 0, 0] = g_o.real
+    g_obj[:, :, 0, 1] = g_o.imag
+    return loss, np.stack(preds), np.stack(tgts), g_obj, g_psi * np.conj(o), g_dists, g_aff
+
+
+def reconstruct_multidist(data, obj_init, probe, dists_cm, energy_ev, psize_cm, n_epochs=1, learning_rate=1e-2,
+                          optimize_free_prop=False, free_prop_learning_rate=1e-1, optimize_prj_affine=False,
+                          prj_affine_learning_rate=1e-3, raw_data_type='intensity', dtype='float64'):
+    """reconstruct_ptychography for multi-distance data of one undivided tile (two_d_mode, minibatch 1, one minibatch per
+    epoch => the Adam step counter is 0 in every epoch, ptychography.py:848): Adam on the object, optionally on the
+    distances and the affine matrices (matrix 0 is pinned to the identity after every update, optimizers.py:1062-1075)."""
+    dt = np.dtype(dtype)
+    obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
+    m, v = np.zeros_like(obj), np.zeros_like(obj)
+    dists = np.asarray(dists_cm, dtype=dt).copy()
+    dm, dv = np.zeros_like(dists), np.zeros_like(dists)
+    aff = np.tile(np.array([[1., 0, 0], [0, 1., 0]], dtype=dt), [len(dists), 1, 1])
+    am, av = np.zeros_like(aff), np.zeros_like(aff)
+    losses, first_grad = [], None
+    for i_epoch in range(n_epochs):
+        loss, _, _, g, _, gd, ga = holo_forward_adjoint(obj, probe, dists, aff, data, energy_ev, psize_cm, raw_data_type, 1, dt)
+        if first_grad is None:
+            first_grad = g.copy()
+        obj, m, v = adam_step(obj, g, m, v, 0, step_size=learning_rate)
+        if optimize_free_prop:
+            dists, dm, dv = adam_step(dists, gd, dm, dv, 0, step_size=free_prop_learning_rate)
+        if optimize_prj_affine:
+            aff, am, av = adam_step(aff, ga, am, av, 0, step_size=prj_affine_learning_rate)
+            aff[0] = np.array([[1., 0, 0], [0, 1., 0]], dtype=dt)
+        losses.append(float(loss))
+    return dict(obj=obj, dists=dists, affine=aff, losses=losses, first_grad=first_grad)

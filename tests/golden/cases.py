@@ -150,3 +150,21 @@ def c1mini_inputs():
     guess_pp = pp + 0.1 * r.uniform(-1, 1, pp.shape)
     return dict(truth=(mag_t, ph_t), guess=(guess_mag, guess_ph), pos_true=pos_true, pos_nominal=pos_nominal,
                 probe_true=(pm, pp), probe_guess=(guess_pm, guess_pp))
+
+
+# ---------------------------------------------------------------- F12: multi-distance holography (f1 row, config-5 shape)
+C5MINI = dict(N=32, energy_ev=17050., psize_cm=1e-4, dists_cm=(40., 60., 90.), )
+
+
+def c5mini_inputs():
+    """2-D complex-transmission object seen by a plane wave at three propagation distances; the holograms of
+    distances 1 and 2 are recorded with a small affine misregistration."""
+    c = C5MINI
+    N = c['N']
+    mag_t = 1 - 0.25 * smooth_field((N, N, 1), 121)
+    ph_t = 0.6 * smooth_field((N, N, 1), 122) - 0.3
+    guess_mag = np.full((N, N, 1), 0.9) + 0.02 * smooth_field((N, N, 1), 123)
+    guess_ph = 0.05 * smooth_field((N, N, 1), 124)
+    affine_true = np.array([[[1., 0, 0], [0, 1., 0]], [[1.02, 0.01, 0.03], [-0.01, 0.99, -0.02]], [[0.98, 0.0, -0.04], [0.015, 1.01, 0.02]]])
+    dists_guess = np.array(c['dists_cm']) * np.array([1.0, 1.03, 0.97])
+    return dict(truth=(mag_t, ph_t), guess=(guess_mag, guess_ph), affine_true=affine_true, dists_guess=dists_guess)

@@ -614,9 +614,113 @@ def gen_f11():
     gs.run_fp64 = False
     save('F11_c1', **out)
 
+# ----------------------------------------------------------------------------- F12 (f1 row: multi-distance holography)
+def _multidist_chain(o, pr, pi, dists_cm, affine, data, energy, psize_cm, raw='intensity'):
+    """MultiDistModel.predict + get_loss_function (forward_model.py:819-1092) for one undivided tile (n_blocks = 1):
+    S = 1 modulation, fresnel_propagate_wrapped to every distance, loss against the affine-registered data."""
+    N = o.shape[0]
+    lm = 1240. / energy
+    vox = np.array([psize_cm * 1e7] * 3)
+    from adorym.propagate import gen_freq_mesh, fresnel_propagate_wrapped
+    u, v = gen_freq_mesh(vox, [N, N])
+    u = torch.tensor(u, dtype=o.dtype); v = torch.tensor(v, dtype=o.dtype)
+    preds = []
+    for i in range(len(dists_cm)):
+        er, ei = multislice_propagate_batch(o[None], pr, pi, energy, psize_cm, kernel=None, free_prop_cm=dists_cm[i],
+                                            obj_batch_shape=[1, N, N, 1], type='real_imag', optimize_free_prop=True, u_free=u, v_free=v)
+        preds.append(w.sqrt(er ** 2 + ei ** 2))
+    pred = w.concatenate(preds, 0)
+    tgt = w.concatenate([w.affine_transform(data[i:i + 1], affine[i]) for i in range(len(dists_cm))])
+    fm = adorym.ForwardModel(loss_function_type='lsq', raw_data_type=raw)
+    return fm.get_mismatch_loss(pred, tgt), pred, tgt
+
+
+def gen_f12():
+    out = {}
+    C = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = C['N']
+    gs.run_fp64 = True
+    truth = np.stack([inp['truth'][0] * np.cos(inp['truth'][1]), inp['truth'][0] * np.sin(inp['truth'][1])], -1)
+    ident = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [3, 1, 1])
+    one = torch.ones((N, N), dtype=torch.float64); zero = torch.zeros((N, N), dtype=torch.float64)
+    # data: |forward(truth)|^2 at the true distances, then de-registered with the inverse of affine_true
+    _, pred_t, _ = _multidist_chain(torch.tensor(truth), one, zero, torch.tensor(C['dists_cm'], dtype=torch.float64),
+                                    torch.tensor(ident), torch.zeros((3, N, N), dtype=torch.float64), C['energy_ev'], C['psize_cm'])
+    inten = pred_t.detach() ** 2
+    inv = []
+    for a in inp['affine_true']:
+        m = np.vstack([a, [0, 0, 1]]); inv.append(np.linalg.inv(m)[:2])
+    data = torch.cat([w.affine_transform(inten[i:i + 1], torch.tensor(inv[i])) for i in range(3)]).numpy()
+    out['data'] = data.astype(np.float32)
+    data = out['data'].astype(np.float64)
+    # (a) affine_transform (wrappers.py:1158-1174) forward
+    out['affine_in'] = data[1]
+    out['affine_theta'] = inp['affine_true'][1]
+    out['affine_out'] = w.affine_transform(torch.tensor(data[1:2]), torch.tensor(inp['affine_true'][1])).numpy()[0]
+    # (b) loss + gradients w.r.t. object, probe, distances, affine matrices
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    guess = np.stack([g0.real, g0.imag], -1)
+    out['guess'] = guess
+    aff_guess = inp['affine_true'].copy(); aff_guess[1:] += 0.01 * cases.rng(1200).uniform(-1, 1, (2, 2, 3))
+    out['aff_guess'] = aff_guess
+    pr0 = 1 + 0.1 * cases.rng(1201).uniform(-1, 1, (N, N)); pi0 = 0.1 * cases.rng(1202).uniform(-1, 1, (N, N))
+    out['probe'] = pr0 + 1j * pi0
+    for fp64 in (True, False):
+        gs.run_fp64 = fp64
+        dt = torch.float64 if fp64 else torch.float32
+        o = torch.tensor(guess, dtype=dt, requires_grad=True)
+        pr = torch.tensor(pr0, dtype=dt, requires_grad=True); pi = torch.tensor(pi0, dtype=dt, requires_grad=True)
+        d = torch.tensor(inp['dists_guess'], dtype=dt, requires_grad=True)
+        a = torch.tensor(aff_guess, dtype=dt, requires_grad=True)
+        loss, pred, tgt = _multidist_chain(o, pr, pi, d, a, torch.tensor(data, dtype=dt), C['energy_ev'], C['psize_cm'])
+        g = torch.autograd.grad(loss, [o, pr, pi, d, a])
+        tag = '_64' if fp64 else '_32'
+        out['loss' + tag] = np.array(loss.item()); out['pred' + tag] = pred.detach().numpy(); out['target' + tag] = tgt.detach().numpy()
+        out['grad_obj' + tag] = g[0].numpy(); out['grad_probe' + tag] = g[1].numpy() + 1j * g[2].numpy()
+        out['grad_dists' + tag] = g[3].numpy(); out['grad_affine' + tag] = g[4].numpy()
+    gs.run_fp64 = False
+    # (c) the reference driver end to end (config-5 shape): distances and affine registration optimised with the object
+    import adorym.ptychography as PT
+    orig_up = PT.update_parameters
+    prj = out['data'][None].astype(np.float64)                 # [1, n_dists, N, N]
+
+    class MultiDistPlugin(adorym.MultiDistModel):
+        # the reference's 'auto' selection passes run_bfloat16/run_float64 to MultiDistModel.__init__, which does not accept
+        # them (TypeError at ptychography.py:535); a forward_model= plugin that drops the two keywords is the way to run it
+        def __init__(self, *a, run_bfloat16=False, run_float64=False, **k):
+            super().__init__(*a, **k)
+
+    for fp64 in (True, False):
+        rec = {}
+        def rec_up(opt_ls, optimizable_params, kw, _rec=rec):
+            res = orig_up(opt_ls, optimizable_params, kw)
+            _rec['dists'] = res['free_prop_cm'].detach().numpy().copy()
+            _rec['affine'] = res['prj_affine_ls'].detach().numpy().copy()
+            return res
+        PT.update_parameters = rec_up
+        try:
+            run_driver(prj, [N, N, 1], np.array([[0., 0.]]), 0, 1,
+                       dict(minibatch_size=1, n_epochs=4, two_d_mode=True, energy_ev=C['energy_ev'], psize_cm=C['psize_cm'],
+                            free_prop_cm=np.array(inp['dists_guess']), initial_guess=[inp['guess'][0], inp['guess'][1]],
+                            probe_type='plane', raw_data_type='intensity', unknown_type='real_imag', gamma=0, alpha_d=0, alpha_b=0,
+                            optimizer='adam', learning_rate=1e-2, optimize_free_prop=True, free_prop_learning_rate=1e-1,
+                            optimize_prj_affine=True, prj_affine_learning_rate=1e-3, n_dp_batch=1, run_float64=fp64,
+                            randomize_probe_pos=True, safe_zone_width=0, forward_model=MultiDistPlugin), rec, ri=True)
+        finally:
+            PT.update_parameters = orig_up
+        tag = '_64' if fp64 else '_32'
+        out['e2e_obj' + tag] = np.stack([rec['mag'] * np.cos(rec['phase']), rec['mag'] * np.sin(rec['phase'])], -1)
+        out['e2e_losses' + tag] = rec['losses']
+        out['e2e_dists' + tag] = rec['dists']
+        out['e2e_affine' + tag] = rec['affine']
+        out['e2e_first_grad' + tag] = rec['first_grad']
+    gs.run_fp64 = False
+    save('F12_multidist', **out)
+
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11']
+    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -627,3 +731,4 @@ if __name__ == '__main__':
     if 'f9' in which: gen_f9()
     if 'f10' in which: gen_f10()
     if 'f11' in which: gen_f11()
+    if 'f12' in which: gen_f12()

@@ -389,3 +389,38 @@ def test_f11_end_to_end_config1_shape():
     assert np.abs(out['obj'] - f['e2e_obj_64']).max() < 2e-6          # the golden object went through mag/phase fp32 TIFFs
     assert np.abs(out['probes'] - f['e2e_probe_64']).max() < 1e-9 * np.abs(f['e2e_probe_64']).max()
     assert np.abs(out['pos_corr'] - f['e2e_pos_corr_64']).max() < 1e-8
+
+
+# ------------------------------------------------------------------------------------ F12 (f1 row)
+def test_f12_affine_transform():
+    f = load('F12_multidist')
+    out = O.affine_sample(f['affine_in'], f['affine_theta'])
+    assert np.abs(out - f['affine_out']).max() < 1e-10 * np.abs(f['affine_out']).max()
+
+
+def test_f12_multidistance_gradients():
+    f = load('F12_multidist')
+    C = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    res = O.holo_forward_adjoint(f['guess'], f['probe'], inp['dists_guess'], f['aff_guess'], f['data'].astype(np.float64),
+                                 C['energy_ev'], C['psize_cm'])
+    loss, pred, tgt, g_obj, g_probe, g_d, g_a = res
+    assert abs(loss - f['loss_64']) < 1e-10 * abs(f['loss_64'])
+    assert np.abs(pred - f['pred_64']).max() < 1e-10 and np.abs(tgt ** 2 - f['target_64']).max() < 1e-10   # golden = registered intensity
+    for a, b in ((g_obj, f['grad_obj_64']), (g_probe, f['grad_probe_64']), (g_d, f['grad_dists_64']), (g_a, f['grad_affine_64'])):
+        assert np.linalg.norm(a - b) < 1e-8 * np.linalg.norm(b), (np.linalg.norm(a - b), np.linalg.norm(b))
+
+
+def test_f12_end_to_end_config5_shape():
+    f = load('F12_multidist')
+    C = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = C['N']
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    out = O.reconstruct_multidist(f['data'].astype(np.float64), [g0.real, g0.imag], np.ones((N, N), complex), inp['dists_guess'],
+                                  C['energy_ev'], C['psize_cm'], n_epochs=4, learning_rate=1e-2, optimize_free_prop=True,
+                                  free_prop_learning_rate=1e-1, optimize_prj_affine=True, prj_affine_learning_rate=1e-3)
+    assert np.allclose(out['losses'], f['e2e_losses_64'], rtol=1e-8)
+    assert np.abs(out['dists'] - f['e2e_dists_64']).max() < 1e-8
+    assert np.abs(out['affine'] - f['e2e_affine_64']).max() < 1e-8
+    assert np.abs(out['obj'] - f['e2e_obj_64']).max() < 2e-6
