@@ -23,6 +23,12 @@ class PlanDesc(C.Structure):
                 ('loss_type', C.c_int32), ('poisson_multiplier', C.c_float), ('unknown_type', C.c_int32)]
 
 
+class HoloDesc(C.Structure):
+    _fields_ = [('ny', C.c_int32), ('nx', C.c_int32), ('n_dists', C.c_int32), ('lambda_nm', C.c_double),
+                ('voxel_nm_y', C.c_double), ('voxel_nm_x', C.c_double), ('sign_convention', C.c_int32),
+                ('unknown_type', C.c_int32), ('raw_intensity', C.c_int32), ('k1', C.c_float)]
+
+
 _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol include/adm.h declares
@@ -68,6 +74,9 @@ SIGNATURES = {
     'adm_rwl1_update': (_I, [_VP, _VP, _VP, _VP]),
     'adm_reg_grad_weighted': (_I, [_VP, _VP, _VP, _F, _F, _VP, _VP]),
     'adm_axpy': (_I, [_VP, _VP, _VP, _F, _SZ]),
+    'adm_holo_create': (_I, [_VP, C.POINTER(HoloDesc), C.POINTER(_VP)]),
+    'adm_holo_destroy': (_I, [_VP]),
+    'adm_holo_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

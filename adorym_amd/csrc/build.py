@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libadm.so')
-SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip']
+SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip', 'adm_holo.hip']
 HDRS = ['adm_common.h', 'adm_fft.h', os.path.join('..', '..', 'include', 'adm.h')]
 
 
@@ -30,12 +30,15 @@ def build(force=False, extra=(), out=None, tag=''):
     if not force and out == OUT and not needs_build():
         return OUT
     objs = []
+    hdr_t = max(os.path.getmtime(os.path.join(HERE, f)) for f in HDRS + ['build.py'])
     for s in SRCS:
         o = os.path.join(HERE, s.replace('.hip', tag + '.o'))
+        objs.append(o)
+        if not force and not extra and os.path.exists(o) and os.path.getmtime(o) > max(hdr_t, os.path.getmtime(os.path.join(HERE, s))):
+            continue          # object is newer than its source and every header
         cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
                '-Wno-unused-result', '-fno-slp-vectorize', '-c', os.path.join(HERE, s), '-o', o] + list(extra)
         subprocess.check_call(cmd)
-        objs.append(o)
     subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
     return out
 

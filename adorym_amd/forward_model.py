@@ -280,6 +280,125 @@ class SparseMultisliceModel(ForwardModel):
         raise NotImplementedError('SparseMultisliceModel is outside the accelerated path (not in BASELINE configs)')
 
 
-class MultiDistModel(ForwardModel):
-    def __init__(self, *a, **k):
-        raise NotImplementedError('MultiDistModel is a "next" row (SURVEY section 8 f1), not implemented yet')
+class MultiDistModel(PtychographyModel):
+    """
+    adorym/forward_model.py:809-1092 for one undivided field of view (the reference's n_blocks == 1 branch, config 5):
+    the S = 1 object is illuminated by the (plane) probe and Fresnel-propagated to every distance of ``free_prop_cm``
+    (fresnel_propagate_wrapped); the loss compares with the measured holograms, optionally registered by the affine
+    matrices ``prj_affine_ls`` (w.affine_transform).  Gradients w.r.t. obj, probe, free_prop_cm and prj_affine_ls come from
+    the hand-derived adjoint in adm_holo_fwd_adj.  ``common_vars_dict['holo_engine']`` is an adorym_amd.HolographyEngine.
+    """
+
+    def __init__(self, loss_function_type='lsq', distribution_mode=None, device=None, common_vars_dict=None,
+                 raw_data_type='magnitude', simulation_mode=False, run_bfloat16=False, run_float64=False):
+        super(MultiDistModel, self).__init__(loss_function_type, distribution_mode, device, common_vars_dict, raw_data_type,
+                                             simulation_mode=simulation_mode, run_bfloat16=run_bfloat16, run_float64=run_float64)
+        if loss_function_type != 'lsq':
+            raise NotImplementedError('MultiDistModel: only the LSQ loss is on the accelerated path')
+        self.holo = common_vars_dict['holo_engine'] if common_vars_dict else None
+        self._data_key = None
+        self._data_dev = None
+        self._small = {}
+
+    def _check(self, safe_zone_width, ctf_lg_kappa, probe_pos_correction):
+        cv = self.common_vars
+        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset', 'optimize_all_probe_pos',
+                     'optimize_ctf_lg_kappa'):
+            if cv.get(flag):
+                raise NotImplementedError('%s with MultiDistModel is outside the accelerated path' % flag)
+        if safe_zone_width not in (0, None):
+            raise NotImplementedError('safe_zone_width > 0 is outside the accelerated path')
+        if not cv.get('two_d_mode'):
+            raise NotImplementedError('MultiDistModel is accelerated for two_d_mode (one object slice) only')
+
+    def _dev(self, name, value, shape):
+        """Small parameter arrays: pass DeviceArrays through, upload (and cache) host values."""
+        if isinstance(value, DeviceArray):
+            return value
+        host = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(shape))
+        cur = self._small.get(name)
+        if cur is None or cur[0].tobytes() != host.tobytes():
+            self._small[name] = (host, self.device.array(host))
+        return self._small[name][1]
+
+    def _data(self, this_i_theta):
+        """All holograms of this angle, raw (the sqrt for intensity data happens after the affine registration)."""
+        td = self.common_vars.get('theta_downsample') or 1
+        key = int(this_i_theta) * td
+        if self._data_key != key:
+            t = np.ascontiguousarray(np.abs(np.asarray(self.prj[key])), dtype=np.float32)
+            self._data_dev = self.device.array(t)
+            self._data_key = key
+        return self._data_dev
+
+    def _run(self, obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad, grad_obj=None, grads=None,
+             want_pred=False):
+        nd = self.holo.n_dists
+        probe = self._probe(probe_real, probe_imag)          # [1, ny, nx, 2]
+        dists = self._dev('free_prop_cm', free_prop_cm, (nd,))
+        aff = None
+        if self.common_vars.get('optimize_prj_affine'):      # forward_model.py:1063-1070
+            aff = self._dev('prj_affine_ls', prj_affine_ls, (nd, 2, 3))
+        g = grads or {}
+        self.holo.forward_adjoint(obj, probe, dists, self._data(this_i_theta), affine=aff, want_grad=want_grad, grad_obj=grad_obj,
+                                  grad_probe=g.get('probe'), grad_dists=g.get('dists'), grad_affine=g.get('affine') if aff is not None else None,
+                                  want_pred=want_pred)
+
+    def predict(self, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
+                probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa, prj_pos_offset):
+        """Detected magnitudes [n_dists, ny, nx] (host float32), adorym/forward_model.py:819-1034."""
+        self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
+        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True)
+        self.i_call += 1
+        return self.holo.pred()
+
+    def get_loss_function(self):
+        def calculate_loss(obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
+                           probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa,
+                           prj_pos_offset):
+            self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
+            self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False)
+            self.current_loss = float(self.holo.loss() + self._regularize(obj, None))
+            return self.current_loss
+        calculate_loss.forward_model = self
+        return calculate_loss
+
+    def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
+                           this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width,
+                           prj_affine_ls, ctf_lg_kappa, prj_pos_offset):
+        """Replacement of torch.autograd.grad over MultiDistModel's loss: gradients ordered like opt_args_ls; index 0 ->
+        grad_obj (accumulated in place), probe_real/probe_imag -> one interleaved DeviceArray, free_prop_cm -> DeviceArray
+        [n_dists], prj_affine_ls -> DeviceArray [n_dists,2,3]."""
+        self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
+        nd = self.holo.n_dists
+        idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls')}
+        grads = {}
+        if idx['probe_real'] in opt_args_ls or idx['probe_imag'] in opt_args_ls:
+            probe = self._probe(probe_real, probe_imag)
+            if self._grad_probe_dev is None or self._grad_probe_dev.shape != probe.shape:
+                self._grad_probe_dev = self.device.empty(probe.shape)
+            grads['probe'] = self._grad_probe_dev
+        if idx['free_prop_cm'] in opt_args_ls:
+            if getattr(self, '_gd', None) is None:
+                self._gd = self.device.empty((nd,))
+            grads['dists'] = self._gd.zero_()
+        if idx['prj_affine_ls'] in opt_args_ls:
+            if getattr(self, '_ga', None) is None:
+                self._ga = self.device.empty((nd, 2, 3))
+            grads['affine'] = self._ga.zero_()
+        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=True, grad_obj=grad_obj, grads=grads)
+        reg = self._regularize(obj, grad_obj)
+        self.current_loss = float(self.holo.loss() + reg)
+        out = []
+        for i in opt_args_ls:
+            if i == 0:
+                out.append(grad_obj)
+            elif i in (idx['probe_real'], idx['probe_imag']):
+                out.append(grads['probe'])
+            elif i == idx['free_prop_cm']:
+                out.append(grads['dists'])
+            elif i == idx['prj_affine_ls']:
+                out.append(grads['affine'])
+            else:
+                raise NotImplementedError("gradient w.r.t. '%s' is outside the accelerated path" % self.argument_ls[i])
+        return tuple(out)

@@ -1,0 +1,56 @@
+"""
+Multi-distance near-field holography on the GPU: the engine behind MultiDistModel
+(adorym/forward_model.py:809-1092) for one undivided field of view and one object slice.  See include/adm.h
+(adm_holo_*) and csrc/adm_holo.hip.
+"""
+import ctypes as C
+import numpy as np
+
+from ._lib import HoloDesc, check
+from .constants import PI
+from .device import DeviceArray
+
+
+class HolographyEngine(object):
+    def __init__(self, ctx, field_size, n_dists, energy_ev, psize_cm, sign_convention=1, unknown_type='real_imag',
+                 raw_data_type='intensity', scale_ri_by_k=True):
+        self.ctx = ctx
+        self.ny, self.nx = int(field_size[0]), int(field_size[1])
+        self.n_dists = int(n_dists)
+        lmbda_nm = 1240. / energy_ev
+        voxel_nm = psize_cm * 1e7
+        k1 = 2. * PI * voxel_nm / lmbda_nm if scale_ri_by_k else 1.
+        desc = HoloDesc(ny=self.ny, nx=self.nx, n_dists=self.n_dists, lambda_nm=lmbda_nm, voxel_nm_y=voxel_nm, voxel_nm_x=voxel_nm,
+                        sign_convention=int(sign_convention), unknown_type=1 if unknown_type == 'real_imag' else 0,
+                        raw_intensity=1 if raw_data_type == 'intensity' else 0, k1=float(k1))
+        h = C.c_void_p()
+        check(ctx.lib.adm_holo_create(ctx.handle, C.byref(desc), C.byref(h)))
+        self.handle = h
+        self._loss = DeviceArray(ctx, (self.n_dists,), np.float32)
+        self._pred = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.ctx.lib.adm_holo_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward_adjoint(self, obj, probe, dists_cm, data, affine=None, want_grad=True, grad_obj=None, grad_probe=None,
+                        grad_dists=None, grad_affine=None, want_pred=False):
+        """All arguments are DeviceArrays: obj [ny,nx,(1,)2], probe [ny,nx,2], dists_cm [n_dists], data [n_dists,ny,nx] (raw),
+        affine [n_dists,2,3] or None.  Gradients are accumulated (+=) except grad_probe (overwritten)."""
+        if want_pred and self._pred is None:
+            self._pred = DeviceArray(self.ctx, (self.n_dists, self.ny, self.nx), np.float32)
+        p = lambda a: a.ptr if a is not None else None
+        check(self.ctx.lib.adm_holo_fwd_adj(self.handle, obj.ptr, probe.ptr, dists_cm.ptr, p(affine), data.ptr, 1 if want_grad else 0,
+                                            p(grad_obj), p(grad_probe), p(grad_dists), p(grad_affine),
+                                            self._pred.ptr if want_pred else None, self._loss.ptr))
+
+    def loss(self):
+        """mean over (distance, pixel) of the squared residual -- blocks."""
+        return float(self._loss.get().astype(np.float64).sum() / (self.n_dists * self.ny * self.nx))
+
+    def pred(self):
+        return self._pred.get()

@@ -30,7 +30,7 @@ from .constants import PI
 from .device import Context
 from .differentiator import Differentiator
 from .dp import DataParallelObject, HipOps, constraint_flags
-from .forward_model import ForwardModel, PtychographyModel
+from .forward_model import ForwardModel, PtychographyModel, MultiDistModel
 from .optimizers import Optimizer, AdamOptimizer, GDOptimizer, MomentumOptimizer
 from .propagate import MultisliceEngine, RotationTable, get_kernel
 from .regularizers import L1Regularizer, TVRegularizer, ReweightedL1Regularizer
@@ -185,8 +185,7 @@ def reconstruct_ptychography(
     _not_implemented(interpolation != 'bilinear', "interpolation='%s'" % interpolation)
     for nm, flag in (('optimize_probe_defocusing', optimize_probe_defocusing), ('optimize_probe_pos_offset', optimize_probe_pos_offset),
                      ('optimize_prj_pos_offset', optimize_prj_pos_offset),
-                     ('optimize_slice_pos', optimize_slice_pos), ('optimize_free_prop', optimize_free_prop),
-                     ('optimize_prj_affine', optimize_prj_affine), ('optimize_tilt', optimize_tilt),
+                     ('optimize_slice_pos', optimize_slice_pos), ('optimize_tilt', optimize_tilt),
                      ('optimize_ctf_lg_kappa', optimize_ctf_lg_kappa)):
         _not_implemented(flag, nm)
     if update_scheme not in ('immediate', 'per angle'):
@@ -242,12 +241,25 @@ def reconstruct_ptychography(
     _not_implemented(slice_pos_cm_ls is not None and len(slice_pos_cm_ls) > 1, 'sparse multislice (slice_pos_cm_ls)')
     if free_prop_cm is None:
         free_prop_cm = f.get('metadata/free_prop_cm')
-    if np.array(free_prop_cm).size != 1:
-        _not_implemented(True, 'multi-distance holography (MultiDistModel)')
-    if isinstance(free_prop_cm, np.ndarray):
-        free_prop_cm = free_prop_cm.reshape(-1)[0]
-        free_prop_cm = free_prop_cm if isinstance(free_prop_cm, str) else float(free_prop_cm)
-    probe_size = [int(v) for v in prj.shape[-2:]]
+    is_multi_dist = np.array(free_prop_cm).size != 1          # ptychography.py:296-305
+    if is_multi_dist:
+        # one undivided field of view (n_blocks == 1), one object slice
+        free_prop_cm = np.asarray(free_prop_cm, dtype=float).reshape(-1)
+        n_dists = len(free_prop_cm)
+        _not_implemented(prj.shape[1] != n_dists or len(probe_pos) != 1, 'multi-distance data divided into sub-tiles (n_blocks > 1)')
+        _not_implemented(not two_d_mode, 'multi-distance holography of a 3-D object')
+        _not_implemented(safe_zone_width != 0, 'safe_zone_width > 0')
+        _not_implemented(n_probe_modes != 1, 'several probe modes with multi-distance data')
+        _not_implemented(loss_function_type != 'lsq', 'Poisson loss with multi-distance data')
+        _not_implemented(optimize_all_probe_pos, 'optimize_all_probe_pos with multi-distance data')
+        _not_implemented(list(prj.shape[-2:]) != list(obj_size[:2]), 'holograms whose size differs from the object size')
+        probe_size = [int(v) for v in obj_size[:2]]          # subdiv_probe (ptychography.py:312-314)
+    else:
+        _not_implemented(optimize_free_prop or optimize_prj_affine, 'optimize_free_prop / optimize_prj_affine without multi-distance data')
+        if isinstance(free_prop_cm, np.ndarray):
+            free_prop_cm = free_prop_cm.reshape(-1)[0]
+            free_prop_cm = free_prop_cm if isinstance(free_prop_cm, str) else float(free_prop_cm)
+        probe_size = [int(v) for v in prj.shape[-2:]]
     print_flush('Data reading: {} s'.format(time.time() - t0), sto_rank, rank, **stdout_options)
     print_flush('Data shape: {}'.format([n_theta, *prj.shape[1:]]), sto_rank, rank, **stdout_options)
     kwargs.pop('probe_size', None)
@@ -268,13 +280,23 @@ def reconstruct_ptychography(
     voxel_nm = np.array([psize_cm] * 3) * 1.e7 * ds_level
     lmbda_nm = 1240. / energy_ev
     delta_nm = voxel_nm[-1]
-    h = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, probe_size, fresnel_approx=fresnel_approx, sign_convention=sign_convention)
+    h = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, probe_size, fresnel_approx=fresnel_approx, sign_convention=sign_convention) \
+        if not is_multi_dist else None
     probe_pos_int = np.round(probe_pos).astype(int)
-    engine = MultisliceEngine(ctx, this_obj_size, probe_size, probe_pos_int, energy_ev, psize_cm, free_prop_cm=free_prop_cm,
-                              binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
-                              normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
-                              max_batch=minibatch_size, loss_function_type=loss_function_type, poisson_multiplier=poisson_multiplier,
-                              unknown_type=unknown_type)
+    holo_engine = None
+    if is_multi_dist:
+        from .holography import HolographyEngine
+        holo_engine = HolographyEngine(ctx, probe_size, n_dists, energy_ev, psize_cm, sign_convention=sign_convention,
+                                       unknown_type=unknown_type, raw_data_type=raw_data_type, scale_ri_by_k=scale_ri_by_k)
+        # a minimal multislice plan is still created: it carries the object geometry for the regulariser kernels
+        engine = MultisliceEngine(ctx, this_obj_size, (8, 8), np.zeros((1, 2), int), energy_ev, psize_cm, free_prop_cm=0,
+                                  max_batch=1, unknown_type=unknown_type)
+    else:
+        engine = MultisliceEngine(ctx, this_obj_size, probe_size, probe_pos_int, energy_ev, psize_cm, free_prop_cm=free_prop_cm,
+                                  binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
+                                  normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
+                                  max_batch=minibatch_size, loss_function_type=loss_function_type,
+                                  poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
 
     # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
     # (the reference caches them as .npy files in ./arrsize_*; no files are written here)
@@ -351,7 +373,8 @@ def reconstruct_ptychography(
     common_vars = dict(unknown_type=unknown_type, normalize_fft=normalize_fft, sign_convention=sign_convention,
                        rotate_out_of_loop=rotate_out_of_loop, scale_ri_by_k=scale_ri_by_k, is_minus_logged=is_minus_logged,
                        forward_algorithm=forward_algorithm, stdout_options=stdout_options, poisson_multiplier=poisson_multiplier,
-                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine,
+                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine, holo_engine=holo_engine,
+                       optimize_prj_affine=optimize_prj_affine, optimize_free_prop=optimize_free_prop, optimize_ctf_lg_kappa=optimize_ctf_lg_kappa,
                        rotation_tables=rotation_tables, two_d_mode=two_d_mode, theta_downsample=theta_downsample,
                        ds_level=ds_level, probe_size=probe_size, this_obj_size=this_obj_size, n_theta=n_theta,
                        theta_ls=theta_ls, energy_ev=energy_ev, psize_cm=psize_cm, h=h, free_prop_cm=free_prop_cm,
@@ -362,7 +385,7 @@ def reconstruct_ptychography(
     fm_args = dict(loss_function_type=loss_function_type, distribution_mode=distribution_mode, device=ctx,
                    common_vars_dict=common_vars, raw_data_type=raw_data_type, run_bfloat16=run_bfloat16, run_float64=run_float64)
     if forward_model == 'auto':
-        forward_model = PtychographyModel(**fm_args)
+        forward_model = MultiDistModel(**fm_args) if is_multi_dist else PtychographyModel(**fm_args)
     else:
         forward_model = forward_model(**fm_args)
     print_flush('Forward model: {}.'.format(type(forward_model).__name__), sto_rank, rank, **stdout_options)
@@ -442,6 +465,37 @@ def reconstruct_ptychography(
         opt_args_ls = opt_args_ls + [forward_model.get_argument_index('probe_real'), forward_model.get_argument_index('probe_imag')]
         opt_ls.append(opt_probe)
         probe_grad_dev = ctx.zeros(probe_dev.shape)
+
+    opt_free_prop = opt_prj_affine = None
+    if is_multi_dist:
+        # ptychography.py:685-727, optimizers.py:905-943
+        optimizable_params['probe_pos_correction'] = np.zeros([n_dists, 2])
+        optimizable_params['free_prop_cm'] = ctx.array(free_prop_cm, np.float32) if optimize_free_prop else free_prop_cm
+        optimizable_params['safe_zone_width'] = safe_zone_width
+        optimizable_params['ctf_lg_kappa'] = ctf_lg_kappa
+        aff0 = np.tile(np.array([[1., 0, 0], [0, 1., 0]]).reshape([1, 2, 3]), [n_dists, 1, 1])
+        optimizable_params['prj_affine_ls'] = ctx.array(aff0, np.float32) if optimize_prj_affine else aff0
+        if optimize_free_prop:
+            opt_free_prop = optimizer_free_prop if optimizer_free_prop is not None else \
+                AdamOptimizer('free_prop_cm', output_folder=output_folder, options_dict={'step_size': free_prop_learning_rate},
+                              forward_model=forward_model)
+            opt_free_prop.name = 'free_prop_cm'
+            opt_free_prop.create_param_arrays([n_dists], device=ctx)
+            opt_free_prop.set_index_in_grad_return(len(opt_args_ls))
+            opt_args_ls = opt_args_ls + [forward_model.get_argument_index('free_prop_cm')]
+            opt_ls.append(opt_free_prop)
+            free_prop_grad_dev = ctx.zeros([n_dists])
+        if optimize_prj_affine:
+            opt_prj_affine = optimizer_prj_affine if optimizer_prj_affine is not None else \
+                AdamOptimizer('prj_affine_ls', output_folder=output_folder, options_dict={'step_size': prj_affine_learning_rate},
+                              forward_model=forward_model)
+            opt_prj_affine.name = 'prj_affine_ls'
+            opt_prj_affine.create_param_arrays([n_dists, 2, 3], device=ctx)
+            opt_prj_affine.set_index_in_grad_return(len(opt_args_ls))
+            opt_args_ls = opt_args_ls + [forward_model.get_argument_index('prj_affine_ls')]
+            opt_ls.append(opt_prj_affine)
+            affine_grad_dev = ctx.zeros([n_dists, 2, 3])
+            affine_identity_dev = ctx.array(np.array([[1., 0, 0], [0, 1., 0]]), np.float32)
 
     opt_probe_pos = None
     if optimize_all_probe_pos:
@@ -567,6 +621,10 @@ def reconstruct_ptychography(
                     probe_grad_dev.zero_()
                 if optimize_all_probe_pos:
                     pos_grad_dev.zero_()
+                if opt_free_prop is not None:
+                    free_prop_grad_dev.zero_()
+                if opt_prj_affine is not None:
+                    affine_grad_dev.zero_()
             grad_func_args = {}
             for arg in forward_model.argument_ls:
                 if arg == 'obj':
@@ -592,6 +650,12 @@ def reconstruct_ptychography(
             if optimize_all_probe_pos:
                 gcd = grads[opt_args_ls.index(forward_model.get_argument_index('probe_pos_correction'))]
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, pos_grad_dev.ptr, gcd.ptr, 1.0, gcd.size))
+            if opt_free_prop is not None:
+                gfd = grads[opt_free_prop.index_in_grad_returns]
+                _lib.check(ctx.lib.adm_axpy(ctx.handle, free_prop_grad_dev.ptr, gfd.ptr, 1.0, gfd.size))
+            if opt_prj_affine is not None:
+                gad = grads[opt_prj_affine.index_in_grad_returns]
+                _lib.check(ctx.lib.adm_axpy(ctx.handle, affine_grad_dev.ptr, gad.ptr, 1.0, gad.size))
 
             if update_scheme == 'per angle' and not is_last_batch_of_this_theta:
                 continue
@@ -631,6 +695,21 @@ def reconstruct_ptychography(
                 opt_probe_pos.apply_gradient(corr_dev, pos_grad_dev, i_opt_batch, **opt_probe_pos.options_dict)
                 # prevent position drifting: subtract the mean over (theta, position)
                 _lib.check(ctx.lib.adm_center_rows(ctx.handle, corr_dev.ptr, corr_dev.size // 2, 2))
+
+            # ---- propagation distances and affine registration (optimizers.py:1062-1083) ----
+            if (opt_free_prop is not None or opt_prj_affine is not None) and i_batch + i_epoch * n_batch >= other_params_update_delay:
+                for o_, g_, name_ in ((opt_free_prop, 'free_prop_grad_dev', 'free_prop_cm'), (opt_prj_affine, 'affine_grad_dev', 'prj_affine_ls')):
+                    if o_ is None:
+                        continue
+                    gdev = free_prop_grad_dev if name_ == 'free_prop_cm' else affine_grad_dev
+                    if n_ranks > 1:
+                        g = comm.torch.from_numpy(gdev.get()).to(comm.device)
+                        comm.all_reduce_sum(g)
+                        gdev.set(g.cpu().numpy())
+                    o_.apply_gradient(optimizable_params[name_], gdev, i_opt_batch, **o_.options_dict)
+                if opt_prj_affine is not None:
+                    # "regularize transformation of image 0": matrix 0 is pinned to the identity
+                    _lib.check(ctx.lib.adm_d2d(ctx.handle, optimizable_params['prj_affine_ls'].ptr, affine_identity_dev.ptr, 6 * 4))
 
             # ---- finishing a batch (ptychography.py:1231-1271) ----
             current_loss = forward_model.current_loss
@@ -677,5 +756,7 @@ def reconstruct_ptychography(
         pc = optimizable_params['probe_pos_correction']
         return {'delta': arr[..., 0], 'beta': arr[..., 1], 'probe_real': pa[..., 0], 'probe_imag': pa[..., 1],
                 'probe_pos_correction': pc.get() if hasattr(pc, 'get') else np.asarray(pc),
+                'free_prop_cm': (lambda v: v.get() if hasattr(v, 'get') else v)(optimizable_params.get('free_prop_cm', free_prop_cm)),
+                'prj_affine_ls': (lambda v: v.get() if hasattr(v, 'get') else v)(optimizable_params.get('prj_affine_ls')),
                 'losses': loss_history, 'output_folder': output_folder}
     return None

@@ -218,6 +218,35 @@ int adm_momentum_step(adm_ctx* ctx, float* x, const float* g, float* v, size_t l
 int adm_rwl1_update(adm_plan* plan, const float* obj, float* weight, float* scratch);
 int adm_reg_grad_weighted(adm_plan* plan, const float* obj, const float* weight, float alpha_d, float alpha_b, float* grad_obj,
                           float* reg_value);
+/* ---- f1  multi-distance near-field holography ------------------------------------------
+ * MultiDistModel (adorym/forward_model.py:809-1092) for one undivided field of view (n_blocks == 1, config 5) and one
+ * object slice:  psi = probe * c(obj);  Psi_d = IFFT2(FFT2(psi) * exp(-i sigma PI lambda d (u^2+v^2)))
+ * (fresnel_propagate_wrapped, adorym/propagate.py:84-103, 556-568);  loss = mean_{d,pixels}(|Psi_d| - t_d)^2 with
+ * t_d = sqrt|A_d(data_d)| for intensity data (|A_d(data_d)| for magnitudes) and A_d = w.affine_transform
+ * (adorym/wrappers.py:1158-1174: F.affine_grid + F.grid_sample, bilinear, border padding, align_corners=False). */
+typedef struct adm_holo adm_holo;
+typedef struct adm_holo_desc {
+    int32_t ny, nx;                   /* field size = object size (powers of two, 16 ... 2048)         */
+    int32_t n_dists;                  /* number of holograms / propagation distances                   */
+    double  lambda_nm;                /* 1240 / energy_ev                                              */
+    double  voxel_nm_y, voxel_nm_x;   /* psize_cm * 1e7                                                */
+    int32_t sign_convention;          /* +1 / -1                                                       */
+    int32_t unknown_type;             /* 0 delta_beta (uses k1), 1 real_imag                           */
+    int32_t raw_intensity;            /* raw_data_type: 0 'magnitude', 1 'intensity'                   */
+    float   k1;                       /* 2 PI delta_nm / lambda_nm (delta_beta only)                   */
+} adm_holo_desc;
+int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo** out);
+int adm_holo_destroy(adm_holo* holo);
+/* obj [ny][nx][2], probe [ny][nx][2], dists_cm [n_dists] (the reference's free_prop_cm), affine [n_dists][2][3]
+ * (prj_affine_ls; NULL = identity), data [n_dists][ny][nx] raw measurements: all device pointers.
+ * loss_sum [n_dists] (overwritten) = per-distance sum of squared residuals; loss = sum / (n_dists*ny*nx).
+ * want_grad: grad_obj [ny][nx][2] += dL/dobj; grad_probe [ny][nx][2] = dL/dprobe (NULL ok);
+ * grad_dists [n_dists] += dL/dfree_prop_cm (NULL ok); grad_affine [n_dists][2][3] += dL/dprj_affine_ls (NULL ok);
+ * pred [n_dists][ny][nx] = |Psi_d| (NULL ok). */
+int adm_holo_fwd_adj(adm_holo* holo, const float* obj, const float* probe, const float* dists_cm, const float* affine,
+                     const float* data, int want_grad, float* grad_obj, float* grad_probe, float* grad_dists,
+                     float* grad_affine, float* pred, float* loss_sum);
+
 /* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
 int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);
 

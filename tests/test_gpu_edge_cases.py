@@ -325,3 +325,78 @@ def test_config1_shape_driver_vs_reference(A, ctx, tmp_path):
     assert rel(p, f['e2e_probe_64'], pn) < max(1e-4, 3 * rel(f['e2e_probe_32'], f['e2e_probe_64'], pn))
     cn = np.linalg.norm(f['e2e_pos_corr_64'])
     assert rel(st['probe_pos_correction'], f['e2e_pos_corr_64'], cn) < max(2e-2, 3 * rel(f['e2e_pos_corr_32'], f['e2e_pos_corr_64'], cn))
+
+
+# ------------------------------------------------------------------------------------ f1 row: multi-distance holography
+def test_multidistance_gradients_vs_reference(A, ctx):
+    """adm_holo_fwd_adj against the reference's autograd through MultiDistModel's chain (golden F12): loss, prediction,
+    gradients w.r.t. object, probe, the propagation distances and the affine registration matrices."""
+    from adorym_amd.holography import HolographyEngine
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F12_multidist.npz'))
+    Cc = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = Cc['N']
+    eng = HolographyEngine(ctx, (N, N), 3, Cc['energy_ev'], Cc['psize_cm'])
+    obj = ctx.array(f['guess'].astype(np.float32))
+    probe = ctx.array(np.stack([f['probe'].real, f['probe'].imag], -1).astype(np.float32))
+    dists = ctx.array(inp['dists_guess'].astype(np.float32))
+    aff = ctx.array(f['aff_guess'].astype(np.float32))
+    data = ctx.array(f['data'].astype(np.float32))
+    g_obj, g_probe = ctx.zeros(obj.shape), ctx.zeros(probe.shape)
+    g_d, g_a = ctx.zeros((3,)), ctx.zeros((3, 2, 3))
+    eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g_obj, grad_probe=g_probe, grad_dists=g_d, grad_affine=g_a,
+                        want_pred=True)
+    assert abs(eng.loss() - f['loss_64']) < 2e-5 * abs(f['loss_64'])
+    assert np.linalg.norm(eng.pred() - f['pred_64']) < 2e-6 * np.linalg.norm(f['pred_64'])
+    gp = g_probe.get()
+    for mine, key in ((g_obj.get(), 'grad_obj'), (gp[..., 0] + 1j * gp[..., 1], 'grad_probe'), (g_d.get(), 'grad_dists'),
+                      (g_a.get(), 'grad_affine')):
+        r64, r32 = f[key + '_64'], f[key + '_32']
+        err = np.linalg.norm(mine - r64) / np.linalg.norm(r64)
+        err_ref = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        assert err < max(1e-4, 3 * err_ref), (key, err, err_ref)
+
+
+@pytest.mark.parametrize('N', [16, 64, 128, 512, 1024])
+def test_large_field_transforms_vs_oracle(A, ctx, N):
+    """The batched row-FFT (Stockham radix 8/4/2) behind the holography path at every pass structure, through the
+    public entry point: plane probe, object = random complex field, one distance, data = 0 => pred = |propagated field|."""
+    from adorym_amd.holography import HolographyEngine
+    r = cases.rng(700 + N)
+    o = (1 + 0.3 * r.standard_normal((N, N))) * np.exp(1j * r.uniform(-1, 1, (N, N)))
+    eng = HolographyEngine(ctx, (N, N), 2, 8000., 5e-5)
+    obj = ctx.array(np.stack([o.real, o.imag], -1).astype(np.float32))
+    probe = ctx.array(np.stack([np.ones((N, N)), np.zeros((N, N))], -1).astype(np.float32))
+    dists = np.array([3.0, 7.5])
+    data = ctx.zeros((2, N, N))
+    eng.forward_adjoint(obj, probe, ctx.array(dists.astype(np.float32)), data, want_grad=False, want_pred=True)
+    _, pred, _, _, _, _, _ = O.holo_forward_adjoint(np.stack([o.real, o.imag], -1)[:, :, None, :], np.ones((N, N), complex), dists,
+                                                    np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [2, 1, 1]), np.zeros((2, N, N)), 8000., 5e-5)
+    assert np.linalg.norm(eng.pred() - pred) < 3e-6 * np.linalg.norm(pred)
+
+
+def test_config5_shape_driver_vs_reference(A, ctx, tmp_path):
+    """Multi-distance holography through reconstruct_ptychography against the REFERENCE driver's own run (golden F12):
+    object + propagation distances + affine registration matrices optimised together (config-5 feature set)."""
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F12_multidist.npz'))
+    Cc = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = Cc['N']
+    st = A.reconstruct_ptychography(
+        fname=f['data'][None], obj_size=(N, N, 1), probe_pos=np.array([[0., 0.]]), theta_st=0, theta_end=0, n_theta=1, two_d_mode=True,
+        energy_ev=Cc['energy_ev'], psize_cm=Cc['psize_cm'], free_prop_cm=np.array(inp['dists_guess']), minibatch_size=1, n_epochs=4,
+        initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='plane', raw_data_type='intensity', unknown_type='real_imag',
+        gamma=0, alpha_d=0, alpha_b=0, optimizer='adam', learning_rate=1e-2, optimize_free_prop=True, free_prop_learning_rate=1e-1,
+        optimize_prj_affine=True, prj_affine_learning_rate=1e-3, n_dp_batch=1, randomize_probe_pos=True, save_path=str(tmp_path),
+        output_folder='c5', store_checkpoint=False, use_checkpoint=False, return_state=True)
+    assert np.allclose(st['losses'], f['e2e_losses_64'], rtol=2e-3)
+    d64, d32 = f['e2e_dists_64'], f['e2e_dists_32']
+    assert np.abs(st['free_prop_cm'] - d64).max() < max(2e-3, 3 * np.abs(d32 - d64).max())
+    a64, a32 = f['e2e_affine_64'], f['e2e_affine_32']
+    assert np.abs(st['prj_affine_ls'] - a64).max() < max(2e-4, 3 * np.abs(a32 - a64).max())
+    assert np.array_equal(st['prj_affine_ls'][0], np.array([[1., 0, 0], [0, 1., 0]], np.float32))
+    x = np.stack([st['delta'], st['beta']], -1)
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    upd = np.linalg.norm(f['e2e_obj_64'] - np.stack([g0.real, g0.imag], -1))
+    e, e_ref = np.linalg.norm(x - f['e2e_obj_64']) / upd, np.linalg.norm(f['e2e_obj_32'] - f['e2e_obj_64']) / upd
+    assert e < max(5e-3, 3 * e_ref), (e, e_ref)
