@@ -24,6 +24,7 @@ struct adm_holo {
     float2 *tw_y, *tw_x;      // exp(-2 pi i j / N) for N = ny, nx
     float* uv2;               // [ny][nx] u^2 + v^2 (nm^-2), fp32 like the reference's tensors
     float2 *psi, *F, *W, *T;  // psi [ny][nx]; F = FFT2(psi); W, T: [n_dists][ny][nx] work fields
+    float* partial;           // [n_dists][256 blocks][8] per-block partial sums
 };
 
 namespace adm {
@@ -175,8 +176,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // grid = (blocks, n_dists): one distance per blockIdx.y so that the reductions are per distance.
 __global__ __launch_bounds__(256) void holo_loss_kernel(float2* __restrict__ Psi, const float* __restrict__ data,
                                                         const float* __restrict__ affine, int ny, int nx, int intensity, float gscale,
-                                                        float* __restrict__ pred_out, float* __restrict__ loss_sum,
-                                                        float* __restrict__ grad_affine) {
+                                                        float* __restrict__ pred_out, float* __restrict__ partial,
+                                                        int want_affine) {
     __shared__ float red[4];
     const int d = blockIdx.y;
     const size_t n = (size_t)ny * nx;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void holo_loss_kernel(float2* __restrict__ Psi
         if (pred_out) pred_out[(size_t)d * n + i] = mag;
         const float g = (mag > 0.f) ? gscale * diff / mag : 0.f;
         Psi[(size_t)d * n + i] = cscale(ps, g);
-        if (grad_affine) {
+        if (want_affine) {
             const float sg = (float)((samp > 0.f) - (samp < 0.f));
             float cot = -gscale * diff * (intensity ? sg / (2.f * sqrtf(as)) : sg);
             if (!(fabsf(cot) <= 3.0e38f)) cot = 0.f;               // 0/0 at an exactly zero sample
@@ -223,13 +224,32 @@ __global__ __launch_bounds__(256) void holo_loss_kernel(float2* __restrict__ Psi
             ga[3] += diy * X; ga[4] += diy * Y; ga[5] += diy;
         }
     }
+    // per-block partial sums (slot 0: loss, 1..6: affine gradient); summed by holo_reduce_kernel -- hundreds of float
+    // atomics on one address serialise in L2 and made this kernel 10x slower than its arithmetic
+    float* out = partial + ((size_t)d * gridDim.x + blockIdx.x) * 8;
     const float ls = block_sum(lsum, red);
-    if (threadIdx.x == 0) atomicAdd(loss_sum + d, ls);
-    if (grad_affine) {
+    if (threadIdx.x == 0) out[0] = ls;
+    if (want_affine) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             const float s = block_sum(ga[q], red);
-            if (threadIdx.x == 0) atomicAdd(grad_affine + d * 6 + q, s);
+            if (threadIdx.x == 0) out[1 + q] = s;
+        }
+    }
+}
+
+// dst[d*stride + q] (=|+=) scale * sum_b partial[(d*nb + b)*8 + off + q]   for q < nq;  one wave per distance
+__global__ __launch_bounds__(64) void holo_reduce_kernel(const float* __restrict__ partial, int nb, int off, int nq, float scale,
+                                                         float* __restrict__ dst, int stride, int accumulate) {
+    const int d = blockIdx.x;
+    for (int q = 0; q < nq; ++q) {
+        float acc = 0.f;
+        for (int b = threadIdx.x; b < nb; b += 64) acc += partial[((size_t)d * nb + b) * 8 + off + q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (threadIdx.x == 0) {
+            if (accumulate) dst[d * stride + q] += scale * acc;
+            else dst[d * stride + q] = scale * acc;
         }
     }
 }
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(256) void holo_loss_kernel(float2* __restrict__ Psi
 // dL/dd_cm = 1e7 * Re sum_k conj(Gh_d) (-i sigma PI lambda uv2) H_d F     (one distance per blockIdx.y)
 __global__ __launch_bounds__(256) void holo_adjoint_kernel(const float2* __restrict__ Gh, const float2* __restrict__ F,
                                                            const float* __restrict__ uv2, const float* __restrict__ dists, size_t n, int nd,
-                                                           float c1, float* __restrict__ grad_dists) {
+                                                           float c1, float* __restrict__ partial) {
     __shared__ float red[4];
     const int d = blockIdx.y;
     float acc = 0.f;
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(256) void holo_adjoint_kernel(const float2* __restr
         acc += -c1 * u2 * (g.x * hf.y - g.y * hf.x);
     }
     const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(grad_dists + d, s * 1e7f);
+    if (threadIdx.x == 0) partial[((size_t)d * gridDim.x + blockIdx.x) * 8] = s;
 }
 
 __global__ __launch_bounds__(256) void holo_sum_conj_h_kernel(const float2* __restrict__ Gh, const float* __restrict__ uv2,
@@ -341,6 +361,7 @@ extern "C" int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo
     if (!rc) rc = adm_malloc(ctx, n * sizeof(float2), (void**)&h->F);
     if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->W);
     if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->T);
+    if (!rc) rc = adm_malloc(ctx, (size_t)d.n_dists * 256 * 8 * sizeof(float), (void**)&h->partial);
     if (rc) {
         adm_holo_destroy(h);
         return rc;
@@ -351,7 +372,7 @@ extern "C" int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo
 
 extern "C" int adm_holo_destroy(adm_holo* h) {
     if (!h) return ADM_OK;
-    void* bufs[] = {h->tw_y, h->tw_x, h->uv2, h->psi, h->F, h->W, h->T};
+    void* bufs[] = {h->tw_y, h->tw_x, h->uv2, h->psi, h->F, h->W, h->T, h->partial};
     for (void* b : bufs)
         if (b) adm_free(h->ctx, b);
     delete h;
@@ -376,18 +397,23 @@ extern "C" int adm_holo_fwd_adj(adm_holo* h, const float* obj, const float* prob
     hipLaunchKernelGGL(holo_apply_h_kernel, dim3(grid_for(n * nd)), dim3(256), 0, st, (const float2*)h->F, (const float*)h->uv2, dists_cm,
                        h->W, n, nd, c1);
     ADM_HIP(fft2<true>(h, h->W, h->W, h->T, nd, inv_n));            // Psi_d (normalised inverse), in place via T
-    ADM_HIP(hipMemsetAsync(loss_sum, 0, nd * sizeof(float), st));
     const float gscale = want_grad ? (float)(2.0 / ((double)n * nd)) : 0.f;
     int nb = grid_for(n);
     if (nb > 256) nb = 256;
+    const int want_affine = (want_grad && grad_affine) ? 1 : 0;
     hipLaunchKernelGGL(holo_loss_kernel, dim3(nb, nd), dim3(256), 0, st, h->W, data, affine, d.ny, d.nx, d.raw_intensity, gscale, pred,
-                       loss_sum, want_grad ? grad_affine : (float*)nullptr);
+                       h->partial, want_affine);
+    hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 0, 1, 1.0f, loss_sum, 1, 0);
+    if (want_affine)
+        hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 1, 6, 1.0f, grad_affine, 6, 1);
     ADM_HIP(hipGetLastError());
     if (!want_grad) return ADM_OK;
     ADM_HIP(fft2<false>(h, h->W, h->W, h->T, nd, inv_n));           // Gh_d = FFT2(dL/dPsi_d) / N
-    if (grad_dists)
+    if (grad_dists) {
         hipLaunchKernelGGL(holo_adjoint_kernel, dim3(nb, nd), dim3(256), 0, st, (const float2*)h->W, (const float2*)h->F,
-                           (const float*)h->uv2, dists_cm, n, nd, c1, grad_dists);
+                           (const float*)h->uv2, dists_cm, n, nd, c1, h->partial);
+        hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 0, 1, 1e7f, grad_dists, 1, 1);
+    }
     hipLaunchKernelGGL(holo_sum_conj_h_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)h->W, (const float*)h->uv2, dists_cm,
                        h->psi, n, nd, c1);
     ADM_HIP(fft2<true>(h, h->psi, h->psi, h->T, 1, 1.0f));          // dL/dpsi = unnormalised inverse of GF

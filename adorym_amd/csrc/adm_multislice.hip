@@ -827,7 +827,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
     Ctx<N, R1, R2> c;
     int tc2, kx;
     init_ctx<N, R1, R2>(c, fld, q.twid, tc2, kx);
-    const int b = blockIdx.x;
+    const int b = blockIdx.x / q.n_modes, m = blockIdx.x % q.n_modes;     // one workgroup per (position, mode)
     const int e = q.index ? q.index[b] : b;
     const float2 s = q.shifts[e];
     cf ph[R2];
@@ -836,7 +836,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
     shift_phases<N, R1, R2>(ph, fy, fx, s, tc2);
     const float inv = (float)(1.0 / ((double)N * N));
     float gy = 0.f, gx = 0.f;
-    for (int m = 0; m < q.n_modes; ++m) {
+    {
         cf a[R1], bf[R2], bg[R2];
         load_probe<N, R1, R2>(c, a, q.probe + (size_t)m * N * N);
         fft2_to_regs<N, R1, R2>(c, a, bf);
@@ -856,7 +856,6 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
         }
         ifft2_from_regs<N, R1, R2>(c, bg, a);
         add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr);
-        __syncthreads();
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -877,7 +876,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
 
 template <int N, int R1, int R2> static hipError_t launch_shift(const ShiftParams& q, int batch, bool adjoint, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
-    if (adjoint) hipLaunchKernelGGL((probe_shift_adj_kernel<N, R1, R2>), dim3(batch), dim3(GE::NT), 0, st, q);
+    if (adjoint) hipLaunchKernelGGL((probe_shift_adj_kernel<N, R1, R2>), dim3(batch * q.n_modes), dim3(GE::NT), 0, st, q);
     else hipLaunchKernelGGL((probe_shift_kernel<N, R1, R2>), dim3(batch * q.n_modes), dim3(GE::NT), 0, st, q);
     return hipGetLastError();
 }

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""
+Measurement of the "next" rows at the shapes BASELINE.json names for them, beside the
+pinned NumPy oracle on the host.  Not the headline metric (bench.py is); prints one JSON object per row.
+
+    python tools/bench_rows.py            # on a GPU box
+C1 shape: 2-D ptychography, 618 x 606 x 1 real_imag object, 5 incoherent probe modes (P = 64), minibatch 35, intensity
+          data, Adam on object + probe + sub-pixel probe positions, TV regulariser  (demos/2d_ptychography_experimental_data.py)
+C5 shape: multi-distance holography, 512 x 512 x 1 real_imag object, plane probe, 4 distances, Adam on object +
+          distances + affine registration  (demos/2d_multidist_holography_w_affine.py)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import adorym_amd as A                      # noqa: E402
+from adorym_amd._lib import check           # noqa: E402
+from oracle import adorym_oracle as O       # noqa: E402  (CPU baseline leg only)
+
+
+def bench_c1(ctx, steps=50):
+    Y, X, P, M, B = 618, 606, 64, 5, 35
+    r = np.random.default_rng(0)
+    energy, psize = 8801.121930115722, 1.32789376566526e-06
+    pos = np.array([(y, x) for y in range(-20, Y - 40, 16) for x in range(-20, X - 40, 16)], dtype=float)
+    pos += r.uniform(-0.4, 0.4, pos.shape)
+    pos_int = np.round(pos).astype(int)
+    eng = A.MultisliceEngine(ctx, (Y, X, 1), (P, P), pos_int, energy, psize, free_prop_cm='inf', n_probe_modes=M, max_batch=B,
+                             unknown_type='real_imag')
+    obj_h = np.stack([r.normal(1, 1e-3, (Y, X, 1)), r.normal(0, 2e-3, (Y, X, 1))], -1).astype(np.float32)
+    obj = ctx.array(obj_h)
+    m, v, g = ctx.zeros(obj.shape), ctx.zeros(obj.shape), ctx.zeros(obj.shape)
+    probe_h = (r.standard_normal((M, P, P)) + 1j * r.standard_normal((M, P, P)))
+    probe = ctx.array(np.stack([probe_h.real, probe_h.imag], -1).astype(np.float32))
+    pm, pv, gp = ctx.zeros(probe.shape), ctx.zeros(probe.shape), ctx.zeros(probe.shape)
+    corr = ctx.array((pos - pos_int)[None].astype(np.float32))
+    cm, cv, gc = ctx.zeros(corr.shape), ctx.zeros(corr.shape), ctx.zeros(corr.shape)
+    meas = ctx.array((np.abs(r.standard_normal((B, P, P))) * 50).astype(np.float32))
+    idx = ctx.array(np.arange(B, dtype=np.int32))
+    lib = ctx.lib
+
+    def step(k):
+        s = (k * B) % (len(pos_int) - B)
+        eng.set_batch(pos_int[s:s + B], meas)
+        idx.set(np.arange(s, s + B, dtype=np.int32))
+        eng.rotate(obj, None, None)
+        g.zero_(); gp.zero_(); gc.zero_()
+        eng.multislice(probe, grad_probe=gp, shifts=corr, shift_index=idx, grad_shifts=gc)
+        eng.rotate_adjoint(g, None, None)
+        check(lib.adm_reg_grad(eng.plan.handle, obj.ptr, 0., 0., 1e-6, g.ptr, None))
+        check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_adam_step(ctx.handle, probe.ptr, gp.ptr, pm.ptr, pv.ptr, 0, probe.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_adam_step(ctx.handle, corr.ptr, gc.ptr, cm.ptr, cv.ptr, 0, corr.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_center_rows(ctx.handle, corr.ptr, corr.size // 2, 2))
+        return eng.loss()
+
+    for k in range(3):
+        step(k)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(3 + k)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    # CPU: the oracle's forward + adjoint of the same minibatch (fp32), one core
+    phys = O.Physics((P, P), energy, psize, free_prop_cm='inf', unknown_type='real_imag')
+    tiles, _ = O.extract_tiles(obj_h, pos_int[:B], (P, P), 'real_imag')
+    t1 = time.perf_counter()
+    O.forward_adjoint_tiles(tiles, probe_h, np.abs(r.standard_normal((B, P, P))), phys, 'float32', shifts=(pos - pos_int)[:B])
+    tc = time.perf_counter() - t1
+    return {'row': 'f2 / config-1 shape', 'workload': '2-D ptychography 618x606x1 real_imag, P=64, 5 modes, minibatch 35, object+probe+position Adam, TV',
+            'value': B / dt, 'unit': 'probe-positions/s', 'ms_per_step': 1e3 * dt,
+            'cpu_baseline': {'value': B / tc, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
+                             'sample': 'one minibatch fwd+adjoint incl. probe shifts, oracle fp32 (optimiser and regulariser excluded)'}}
+
+
+def bench_c5(ctx, steps=50):
+    N, nd = 512, 4
+    r = np.random.default_rng(1)
+    energy, psize = 17050., 1e-4
+    eng = A.HolographyEngine(ctx, (N, N), nd, energy, psize)
+    obj_h = np.stack([r.normal(1, 0., (N, N, 1)), r.normal(0, 0.01, (N, N, 1))], -1).astype(np.float32)
+    obj = ctx.array(obj_h)
+    m, v, g = ctx.zeros(obj.shape), ctx.zeros(obj.shape), ctx.zeros(obj.shape)
+    probe = ctx.array(np.stack([np.ones((1, N, N)), np.zeros((1, N, N))], -1).astype(np.float32))
+    d_h = np.array([40., 60., 90., 140.])
+    dists = ctx.array(d_h.astype(np.float32))
+    dm, dv, gd = ctx.zeros((nd,)), ctx.zeros((nd,)), ctx.zeros((nd,))
+    a_h = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1])
+    aff = ctx.array(a_h.astype(np.float32))
+    am, av, ga = ctx.zeros(aff.shape), ctx.zeros(aff.shape), ctx.zeros(aff.shape)
+    data_h = (1 + 0.1 * r.standard_normal((nd, N, N))) ** 2
+    data = ctx.array(data_h.astype(np.float32))
+    ident = ctx.array(np.array([[1., 0, 0], [0, 1., 0]], np.float32))
+    lib = ctx.lib
+
+    def step():
+        g.zero_(); gd.zero_(); ga.zero_()
+        eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd, grad_affine=ga)
+        check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_adam_step(ctx.handle, dists.ptr, gd.ptr, dm.ptr, dv.ptr, 0, nd, 0, 1e-1, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_adam_step(ctx.handle, aff.ptr, ga.ptr, am.ptr, av.ptr, 0, aff.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
+        check(lib.adm_d2d(ctx.handle, aff.ptr, ident.ptr, 24))
+        return eng.loss()
+
+    for _ in range(3):
+        step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    t1 = time.perf_counter()
+    O.holo_forward_adjoint(obj_h.astype(np.float64), np.ones((N, N), complex), d_h, a_h, data_h, energy, psize, dtype='float32')
+    tc = time.perf_counter() - t1
+    # algorithmic bytes of one step: read obj+probe, read 4 holograms, write grad (fields stay on chip in principle)
+    return {'row': 'f1 / config-5 shape', 'workload': 'multi-distance holography 512x512x1 real_imag, 4 distances, object+distance+affine Adam',
+            'value': 1.0 / dt, 'unit': 'minibatches/s (4 holograms each)', 'ms_per_step': 1e3 * dt,
+            'cpu_baseline': {'value': 1.0 / tc, 'unit': 'minibatches/s', 'cores': 1, 'kind': 'port',
+                             'sample': 'one fwd+adjoint of the 4-distance chain, oracle fp32 (optimiser excluded)'}}
+
+
+if __name__ == '__main__':
+    ctx = A.Context(0)
+    for fn in (bench_c1, bench_c5):
+        print(json.dumps(fn(ctx)))
