@@ -49,6 +49,10 @@ SIGNATURES = {
     'adm_h2d': (_I, [_VP, _VP, _VP, _SZ]),
     'adm_d2h': (_I, [_VP, _VP, _VP, _SZ]),
     'adm_d2d': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_host_alloc': (_I, [_VP, _SZ, C.POINTER(_VP)]),
+    'adm_host_free': (_I, [_VP, _VP]),
+    'adm_d2h_async': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_event_sync': (_I, [_VP, _VP]),
     'adm_event_create': (_I, [_VP, C.POINTER(_VP)]),
     'adm_event_destroy': (_I, [_VP, _VP]),
     'adm_event_record': (_I, [_VP, _VP]),

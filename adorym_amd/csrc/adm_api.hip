@@ -147,6 +147,26 @@ extern "C" int adm_d2d(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return ADM_OK;
 }
 
+extern "C" int adm_host_alloc(adm_ctx* ctx, size_t bytes, void** hptr) {
+    if (!ctx || !hptr) return fail(ADM_ERR_INVALID, "adm_host_alloc: null argument");
+    if (hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return fail(ADM_ERR_NOMEM, "adm_host_alloc: hipHostMalloc failed");
+    return ADM_OK;
+}
+extern "C" int adm_host_free(adm_ctx* ctx, void* hptr) {
+    if (hptr) ADM_HIP(hipHostFree(hptr));
+    return ADM_OK;
+}
+extern "C" int adm_d2h_async(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(ADM_ERR_INVALID, "adm_d2h_async: null argument");
+    if (bytes) ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return ADM_OK;
+}
+extern "C" int adm_event_sync(adm_ctx* ctx, void* ev) {
+    if (!ev) return fail(ADM_ERR_INVALID, "adm_event_sync: null argument");
+    ADM_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return ADM_OK;
+}
+
 extern "C" int adm_event_create(adm_ctx* ctx, void** ev) {
     if (!ctx || !ev) return fail(ADM_ERR_INVALID, "adm_event_create: null argument");
     hipEvent_t e;

@@ -127,10 +127,42 @@ class Event(object):
         check(self.ctx.lib.adm_event_record(self.ctx.handle, self.handle))
         return self
 
+    def synchronize(self):
+        check(self.ctx.lib.adm_event_sync(self.ctx.handle, self.handle))
+        return self
+
     def elapsed_ms(self, end):
         ms = C.c_float()
         check(self.ctx.lib.adm_event_elapsed_ms(self.ctx.handle, self.handle, end.handle, C.byref(ms)))
         return ms.value
+
+
+class PinnedArray(object):
+    """Page-locked host array (NumPy view) for asynchronous device-to-host copies."""
+
+    def __init__(self, ctx, shape, dtype=np.float32):
+        self.ctx = ctx
+        self.shape = tuple(int(v) for v in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        h = C.c_void_p()
+        check(ctx.lib.adm_host_alloc(ctx.handle, self.nbytes, C.byref(h)))
+        self.handle = h
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(h.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def copy_from_async(self, dev, nbytes=None):
+        check(self.ctx.lib.adm_d2h_async(self.ctx.handle, self.handle, dev.ptr, int(nbytes if nbytes is not None else min(self.nbytes, dev.nbytes))))
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.array = None
+                self.ctx.lib.adm_host_free(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def _fptr(a):

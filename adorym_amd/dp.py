@@ -91,29 +91,54 @@ class DataParallelObject(object):
         self.moments = [ops.alloc(self.per) for _ in range(n_moments)]   # ZeRO-1: only the owned shard
 
     # gradient exchange + update ------------------------------------------------------------
-    def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None):
-        """optimizer: 'adam' | 'gd' | 'momentum'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict."""
-        R = self.comm.size
+    def _apply(self, optimizer, i_batch, options, flags, mask, g, g_base, lo, hi):
+        if hi <= lo:
+            return
+        if optimizer == 'adam':
+            self.ops.adam(self.obj, g, g_base, self.moments[0], self.moments[1], self.lo, lo, hi, i_batch,
+                          options.get('step_size', 0.001), options.get('b1', 0.9), options.get('b2', 0.999),
+                          options.get('eps', 1e-7), flags, mask)
+        elif optimizer == 'gd':
+            self.ops.gd(self.obj, g, g_base, lo, hi, options['step_size'], flags, mask)
+        elif optimizer == 'momentum':
+            self.ops.momentum(self.obj, g, g_base, self.moments[0], self.lo, lo, hi, options.get('step_size', 0.001),
+                              options.get('gamma', 0.9), flags, mask)
+        else:
+            raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
+
+    def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None, first=None):
+        """optimizer: 'adam' | 'gd' | 'momentum'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict.
+
+        ``first=(lo, hi)`` (flat element range, single-rank runs): the part of the object the NEXT minibatch reads (its
+        y-planes).  Only that range is updated now; the rest of the (element-wise, order-independent) update is DEFERRED
+        until finish_update() -- which zero_grad() calls -- so that the caller can queue it on the context's side stream
+        after the next rotation, where it overlaps the next multislice kernel (which keeps only `minibatch` of the 256
+        CUs busy).  Same arithmetic, same result; nothing outside ``first`` may be read before finish_update()."""
+        self.finish_update()
         if self.dist:
             self.comm.reduce_scatter_sum(self.t_grad, self.t_gshard)
             g, g_base = self.gshard, self.lo
         else:
             g, g_base = self.grad, 0
-        if self.hi > self.lo:
-            if optimizer == 'adam':
-                self.ops.adam(self.obj, g, g_base, self.moments[0], self.moments[1], self.lo, self.lo, self.hi, i_batch,
-                              options.get('step_size', 0.001), options.get('b1', 0.9), options.get('b2', 0.999),
-                              options.get('eps', 1e-7), flags, mask)
-            elif optimizer == 'gd':
-                self.ops.gd(self.obj, g, g_base, self.lo, self.hi, options['step_size'], flags, mask)
-            elif optimizer == 'momentum':
-                self.ops.momentum(self.obj, g, g_base, self.moments[0], self.lo, self.lo, self.hi, options.get('step_size', 0.001),
-                                  options.get('gamma', 0.9), flags, mask)
-            else:
-                raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
+        if first is not None and not self.dist and self.hi > self.lo:
+            f_lo, f_hi = max(self.lo, int(first[0])), min(self.hi, int(first[1]))
+            self._apply(optimizer, i_batch, options, flags, mask, g, g_base, f_lo, f_hi)
+            self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, f_lo, f_hi)
+        else:
+            self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, self.hi)
         if self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
 
+    def finish_update(self):
+        """Apply the part of the last update that exchange_and_update(first=...) deferred (on the current stream)."""
+        d = getattr(self, '_deferred', None)
+        if d is not None:
+            self._deferred = None
+            optimizer, i_batch, options, flags, mask, g, g_base, f_lo, f_hi = d
+            self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, f_lo)
+            self._apply(optimizer, i_batch, options, flags, mask, g, g_base, f_hi, self.hi)
+
     def zero_grad(self):
+        self.finish_update()        # the deferred update still reads the gradient
         self.ops.zero(self.grad)

@@ -258,6 +258,29 @@ class MultisliceEngine(object):
             sums = sums[B - last:]
         return float(sums.sum() / (len(sums) * self.probe_size[0] * self.probe_size[1]))
 
+    def loss_async(self, last=None):
+        """Queue the read-back of the per-position loss sums of the batch just launched and return a token for
+        loss_result(); the host is not blocked, so the next minibatch can be queued first."""
+        from .device import PinnedArray, Event
+        if getattr(self, '_loss_pinned', None) is None or self._loss_pinned[0].shape[0] < self.max_batch:
+            self._loss_pinned = [PinnedArray(self.ctx, (self.max_batch,)) for _ in range(2)]
+            self._loss_events = [Event(self.ctx) for _ in range(2)]
+            self._loss_slot = 0
+        self._loss_slot ^= 1
+        k = self._loss_slot
+        B = self._B
+        self._loss_pinned[k].copy_from_async(self._loss, 4 * B)
+        self._loss_events[k].record()
+        return (k, B, last)
+
+    def loss_result(self, token):
+        k, B, last = token
+        self._loss_events[k].synchronize()
+        sums = self._loss_pinned[k].array[:B].astype(np.float64)
+        if last is not None:
+            sums = sums[B - last:]
+        return float(sums.sum() / (len(sums) * self.probe_size[0] * self.probe_size[1]))
+
     def pred(self):
         return self._pred.view(0, (self._B,) + self.probe_size).get()
 

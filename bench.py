@@ -206,9 +206,20 @@ def main():
     ctx.sync()
 
     opt_options = {'step_size': cfg['learning_rate']}
-    ev_ms = [ctx.event(), ctx.event()]
+    # two sets of timing events / loss read-backs: step k's results are looked at after step k+1 has been queued, so the
+    # GPU never waits for the host (the loss still comes back for EVERY minibatch, as in the reference's log)
+    ev_ms = [(ctx.event(), ctx.event()) for _ in range(2)]
     ms_kernel_total = [0.0]
     loss_box = [0.0]
+    pending = [None]
+
+    def resolve():
+        if pending[0] is not None:
+            token, evs = pending[0]
+            if evs is not None:
+                ms_kernel_total[0] += evs[0].elapsed_ms(evs[1])
+            loss_box[0] = eng.loss_result(token)
+            pending[0] = None
 
     def step(k, timed):
         it, ind = plan_batches[k]
@@ -223,26 +234,34 @@ def main():
         check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
                                    state.grad.ptr, None))
         ctx.end_fork()
+        evs = ev_ms[k & 1] if timed else None
         if timed:
-            ev_ms[0].record()
+            evs[0].record()
         eng.multislice(probe, accumulate=False)
         if timed:
-            ev_ms[1].record()
+            evs[1].record()
         eng.accumulate_tiles()
         ctx.join()
         eng.rotate_adjoint(state.grad, tables[it], yr)
-        state.exchange_and_update('adam', k, opt_options)
-        if timed:
-            ms_kernel_total[0] += ev_ms[0].elapsed_ms(ev_ms[1])   # blocks on the kernel only; the rest stays queued
-        loss_box[0] = eng.loss()
+        # update the y-planes the next minibatch reads first; the rest of the Adam pass overlaps the next kernel
+        first = None
+        if k + 1 < len(plan_batches):
+            ny0, ny1 = eng.y_footprint(pos_all[plan_batches[k + 1][1]])
+            first = (ny0 * X * Z * 2, ny1 * X * Z * 2)
+        state.exchange_and_update('adam', k, opt_options, first=first)
+        token = eng.loss_async()
+        resolve()                       # the PREVIOUS step's kernel time and loss
+        pending[0] = (token, evs)
 
     for k in range(args.warmup):
         step(k, False)
+    resolve()
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.warmup, total):
         step(k, True)
+    resolve()
     comm.barrier()
     torch.cuda.synchronize()
     dt = comm.max_over_ranks(time.perf_counter() - t0)

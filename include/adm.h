@@ -66,12 +66,19 @@ int adm_memset(adm_ctx* ctx, void* dptr, int byte_value, size_t bytes);       /*
 int adm_h2d(adm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* blocking */
 int adm_d2h(adm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* blocking */
 int adm_d2d(adm_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /* async */
+/* Pinned host memory + asynchronous read-back: lets the caller queue the next minibatch before it looks at the loss of
+ * the previous one (the reference blocks on w.to_numpy(loss) every minibatch, adorym/forward_model.py:140).
+ * adm_d2h_async: dst must come from adm_host_alloc; complete once an event recorded after it has been synchronised. */
+int adm_host_alloc(adm_ctx* ctx, size_t bytes, void** hptr);
+int adm_host_free(adm_ctx* ctx, void* hptr);
+int adm_d2h_async(adm_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes);
 
 /* ---- events: kernel timing on the context's stream --------------------------------- */
 int adm_event_create(adm_ctx* ctx, void** ev);
 int adm_event_destroy(adm_ctx* ctx, void* ev);
 int adm_event_record(adm_ctx* ctx, void* ev);
 int adm_event_elapsed_ms(adm_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* blocks on ev_stop */
+int adm_event_sync(adm_ctx* ctx, void* ev);                                        /* blocks until ev has happened */
 
 /* ---- plan: static geometry + physics of one reconstruction ------------------------- */
 typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;
