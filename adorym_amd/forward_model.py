@@ -32,7 +32,8 @@ class ForwardModel(object):
         self.distribution_mode = distribution_mode
         self.device = device                      # adorym_amd.Context
         self.simulation_mode = simulation_mode
-        self.current_loss = 0
+        self._current_loss = 0
+        self._loss_thunk = None
         self.raw_data_type = raw_data_type
         self.i_call = 0
         self.common_vars = common_vars_dict
@@ -43,6 +44,29 @@ class ForwardModel(object):
                 setattr(self, k, common_vars_dict.get(k))
         self.loss_args = {}
         self.reg_list = []
+
+    @property
+    def current_loss(self):
+        """Loss of the last evaluation (adorym/forward_model.py:141-146).  The GPU path queues its read-back without
+        blocking; the value is fetched the first time it is looked at."""
+        if self._loss_thunk is not None:
+            t, self._loss_thunk = self._loss_thunk, None
+            self._current_loss = float(t())
+        return self._current_loss
+
+    @current_loss.setter
+    def current_loss(self, v):
+        self._loss_thunk = None
+        self._current_loss = v
+
+    def take_loss_thunk(self):
+        """Detach the pending loss read-back (a callable returning the float) so that the caller can resolve it later,
+        after more work has been queued; returns None if the loss is already on the host."""
+        t, self._loss_thunk = self._loss_thunk, None
+        if t is None:
+            v = self._current_loss
+            return lambda: v
+        return t
 
     def update_loss_args(self, kwargs):
         self.loss_args = kwargs
@@ -159,13 +183,24 @@ class PtychographyModel(ForwardModel):
         return self._probe_dev
 
     def _run(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad, grad_obj=None,
-             want_probe_grad=False, want_pred=False, probe_pos_correction=None, this_ind_batch=None, want_shift_grad=False):
+             want_probe_grad=False, want_pred=False, probe_pos_correction=None, this_ind_batch=None, want_shift_grad=False,
+             side_hook=None, regularize=True):
+        """One evaluation.  Stream plan (same as bench.py): rotation on the main stream; then, on the context's side
+        stream, ``side_hook()`` (the driver zeroes the gradient buffer / finishes the previous update there) and the
+        regulariser gradient -- they only need the object -- while the multislice chain, which occupies `minibatch` of
+        the 256 CUs, runs on the main stream; joined before the back-rotation adds into ``grad_obj``."""
         eng = self.engine
+        ctx = self.device
         probe = self._probe(probe_real, probe_imag)
         coords = self._coords(this_i_theta)
         eng.set_batch(this_pos_batch, target)
         yr = eng.y_footprint(this_pos_batch)
         eng.rotate(obj, coords, yr)
+        ctx.fork()
+        if side_hook is not None:
+            side_hook()
+        self._reg_pending = self._regularize_launch(obj, grad_obj if want_grad else None) if regularize else False
+        ctx.end_fork()
         gp = None
         if want_probe_grad:
             if self._grad_probe_dev is None or self._grad_probe_dev.shape != probe.shape:
@@ -183,19 +218,23 @@ class PtychographyModel(ForwardModel):
         mb = B // self.batch_group
         gs = 2.0 / (mb * eng.probe_size[0] * eng.probe_size[1])     # each reference minibatch is a mean over ITS positions
         eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
-                       shift_index=idx, grad_shifts=gsh)
+                       shift_index=idx, grad_shifts=gsh, accumulate=False)
+        if want_grad:
+            eng.accumulate_tiles()
+        ctx.join()
         self._last_mb = mb
         if want_grad:
             eng.rotate_adjoint(grad_obj, coords, yr)
         return gp, gsh
 
-    def _regularize(self, obj, grad_obj):
-        """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value."""
+    def _regularize_launch(self, obj, grad_obj):
+        """Queue the regulariser kernels (value into a device scalar, gradient added to grad_obj if given) on the
+        current stream.  Returns True if a value is pending."""
         from .regularizers import ReweightedL1Regularizer
         ad, ab, gm = combined_weights(self.reg_list)
         rw = [r for r in self.reg_list if isinstance(r, ReweightedL1Regularizer)]
         if ad == 0 and ab == 0 and gm == 0 and not rw:
-            return 0.0
+            return False
         if self._reg_val is None:
             self._reg_val = self.device.zeros((1,))
         self._reg_val.zero_()
@@ -211,7 +250,38 @@ class PtychographyModel(ForwardModel):
                 raise RuntimeError('ReweightedL1Regularizer: update_l1_weight() has not been called')
             check(self.device.lib.adm_reg_grad_weighted(self.engine.plan.handle, obj.ptr, r.weight_l1.ptr, float(r.alpha_d or 0.) * k,
                                                         float(r.alpha_b or 0.) * k, grad_obj.ptr, self._reg_val.ptr))
-        return float(self._reg_val.get()[0]) / k
+        return True
+
+    def _reg_value_async(self, pending):
+        """Queue the read-back of the regulariser value (after the join); returns a callable giving the float."""
+        if not pending:
+            return lambda: 0.0
+        from .device import PinnedArray, Event
+        if getattr(self, '_reg_pinned', None) is None:
+            self._reg_pinned = [PinnedArray(self.device, (1,)) for _ in range(2)]
+            self._reg_events = [Event(self.device) for _ in range(2)]
+            self._reg_slot = 0
+        self._reg_slot ^= 1
+        k = self._reg_slot
+        self._reg_pinned[k].copy_from_async(self._reg_val, 4)
+        self._reg_events[k].record()
+        g = float(self.batch_group)
+
+        def value():
+            self._reg_events[k].synchronize()
+            return float(self._reg_pinned[k].array[0]) / g
+        return value
+
+    def _regularize(self, obj, grad_obj):
+        """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value (blocking)."""
+        return self._reg_value_async(self._regularize_launch(obj, grad_obj))()
+
+    def _queue_loss(self, data_loss_fn=None):
+        """current_loss <- data term + regulariser, both read back lazily."""
+        tok = self.engine.loss_async(last=self._last_mb) if data_loss_fn is None else None
+        regv = self._reg_value_async(getattr(self, '_reg_pending', False))
+        eng = self.engine
+        self._loss_thunk = (lambda: eng.loss_result(tok) + regv()) if data_loss_fn is None else (lambda: data_loss_fn() + regv())
 
     # ------------------------------------------------------------------ reference interface
     def predict(self, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
@@ -221,7 +291,7 @@ class PtychographyModel(ForwardModel):
         B = len(this_pos_batch)
         zeros = np.zeros((B,) + tuple(self.engine.probe_size), np.float32)
         self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, zeros, want_grad=False, want_pred=True,
-                  probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch)
+                  probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch, regularize=False)
         self.i_call += 1
         return self.engine.pred()
 
@@ -233,14 +303,14 @@ class PtychographyModel(ForwardModel):
                                    ds_level=self.common_vars.get('ds_level', 1))
             self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=False,
                       probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch)
-            loss = self.engine.loss(last=self._last_mb) + self._regularize(obj, None)
-            self.current_loss = float(loss)
+            self._queue_loss()
             return self.current_loss
         calculate_loss.forward_model = self
         return calculate_loss
 
     def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
-                           this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset):
+                           this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset,
+                           _side_hook=None):
         """
         The hand-derived replacement of ``torch.autograd.grad(loss, [args in opt_args_ls])``
         (adorym/wrappers.py:300-331): accumulates d loss/d obj into ``grad_obj`` (DeviceArray) and returns
@@ -254,9 +324,8 @@ class PtychographyModel(ForwardModel):
         want_probe = (i_pr in opt_args_ls) or (i_pi in opt_args_ls)
         gp, gsh = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
                             want_probe_grad=want_probe, probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch,
-                            want_shift_grad=i_pc in opt_args_ls)
-        reg = self._regularize(obj, grad_obj)
-        self.current_loss = float(self.engine.loss(last=self._last_mb) + reg)
+                            want_shift_grad=i_pc in opt_args_ls, side_hook=_side_hook)
+        self._queue_loss()          # self.current_loss fetches it on first access
         out = []
         for i in opt_args_ls:
             if i == 0:
@@ -365,11 +434,13 @@ class MultiDistModel(PtychographyModel):
 
     def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
                            this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width,
-                           prj_affine_ls, ctf_lg_kappa, prj_pos_offset):
+                           prj_affine_ls, ctf_lg_kappa, prj_pos_offset, _side_hook=None):
         """Replacement of torch.autograd.grad over MultiDistModel's loss: gradients ordered like opt_args_ls; index 0 ->
         grad_obj (accumulated in place), probe_real/probe_imag -> one interleaved DeviceArray, free_prop_cm -> DeviceArray
         [n_dists], prj_affine_ls -> DeviceArray [n_dists,2,3]."""
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
+        if _side_hook is not None:
+            _side_hook()
         nd = self.holo.n_dists
         idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls')}
         grads = {}

@@ -388,6 +388,7 @@ def reconstruct_ptychography(
         forward_model = MultiDistModel(**fm_args) if is_multi_dist else PtychographyModel(**fm_args)
     else:
         forward_model = forward_model(**fm_args)
+    builtin_model = type(forward_model) in (PtychographyModel, MultiDistModel)
     print_flush('Forward model: {}.'.format(type(forward_model).__name__), sto_rank, rank, **stdout_options)
 
     if regularizers is None:
@@ -534,6 +535,21 @@ def reconstruct_ptychography(
     cont = True
     i_epoch = starting_epoch
     _ckpt_thread = [None]
+    pending_log = [None]
+
+    def flush_log():
+        if pending_log[0] is None:
+            return
+        e_, b_, thunk, t_start = pending_log[0]
+        pending_log[0] = None
+        current_loss = thunk()
+        loss_history.append(current_loss)
+        print_flush('Minibatch/angle done in {} s; loss (rank 0) is {}.'.format(time.time() - t_start, current_loss), sto_rank,
+                    rank, **stdout_options)
+        print_flush('Throughput: {} angles/sec'.format(minibatch_size / (time.time() - t_start)), sto_rank, rank, **stdout_options)
+        f_conv.write('{},{},{},{}\n'.format(e_, b_, current_loss, time.time() - t_zero))
+        f_conv.flush()
+
     while cont:
         t0 = time.time()
         n_tot_per_batch = minibatch_size * n_ranks
@@ -573,6 +589,7 @@ def reconstruct_ptychography(
                 import threading
                 if _ckpt_thread[0] is not None:
                     _ckpt_thread[0].join()
+                state.finish_update()
                 host_obj = obj.arr.get() if rank == 0 else None
                 host_mom = [m_.get() for m_ in state.moments] if (rank == 0 or n_ranks > 1) else []
                 pk = {'probe': probe_dev.get()} if rank == 0 or True else None
@@ -610,13 +627,18 @@ def reconstruct_ptychography(
             # ---- reweighted-L1 weights, refreshed every 10 minibatches (ptychography.py:995-1000) ----
             if reg_rwl1 is not None:
                 if i_batch % 10 == 0:
+                    state.finish_update()
                     _lib.check(ctx.lib.adm_rwl1_update(engine.plan.handle, obj.arr.ptr, rwl1_weight.ptr, rwl1_scratch.ptr))
                 reg_rwl1.update_l1_weight(rwl1_weight)
 
             # ---- gradients (ptychography.py:1017-1066) ----
             t_grad_0 = time.time()
+            side_hook = None
             if initialize_gradients:
-                state.zero_grad()
+                if builtin_model:
+                    side_hook = state.zero_grad      # queued on the side stream, after the rotation (see PtychographyModel._run)
+                else:
+                    state.zero_grad()
                 if optimize_probe:
                     probe_grad_dev.zero_()
                 if optimize_all_probe_pos:
@@ -640,7 +662,7 @@ def reconstruct_ptychography(
                 else:
                     grad_func_args[arg] = optimizable_params[arg]
             forward_model.update_loss_args(grad_func_args)
-            grads = diff.get_gradients(_accumulate_into=gradient.arr, **grad_func_args)
+            grads = diff.get_gradients(_accumulate_into=gradient.arr, _side_hook=side_hook, **grad_func_args)
             print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
             if initialize_gradients:
                 initialize_gradients = False
@@ -658,6 +680,7 @@ def reconstruct_ptychography(
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, affine_grad_dev.ptr, gad.ptr, 1.0, gad.size))
 
             if update_scheme == 'per angle' and not is_last_batch_of_this_theta:
+                flush_log()     # keeps at most one evaluation between a loss read-back and its use (two pinned slots)
                 continue
             initialize_gradients = True
 
@@ -668,7 +691,18 @@ def reconstruct_ptychography(
                     if opt_kind == 'gd':
                         o['step_size'] = GDOptimizer.scheduled_step(i_opt_batch, o.get('step_size', 0.001), o.get('dynamic_rate', True),
                                                                     o.get('first_downrate_iteration', 92))
-                    state.exchange_and_update(opt_kind, i_opt_batch, o, flags=flags, mask=mask.mask if mask is not None else None)
+                    first = None
+                    if n_ranks == 1 and builtin_model and not is_multi_dist and i_batch + 1 < n_batch:
+                        # update the y-planes the next minibatch reads first; the rest of the element-wise update is queued
+                        # by that minibatch on the side stream (DataParallelObject.finish_update), beside its multislice kernel
+                        nxt = ind_list_rand[i_batch + 1]
+                        ny0, ny1 = engine.y_footprint(probe_pos_int[nxt[:minibatch_size, 1]])
+                        if update_scheme == 'per angle' and fuse_per_angle:
+                            ny0, ny1 = 0, this_obj_size[0]
+                        plane = this_obj_size[1] * this_obj_size[2] * 2
+                        first = (ny0 * plane, ny1 * plane)
+                    state.exchange_and_update(opt_kind, i_opt_batch, o, flags=flags, mask=mask.mask if mask is not None else None,
+                                              first=first)
                 else:
                     opt.apply_gradient(obj.arr, gradient, i_opt_batch, flags=flags, mask=mask.mask if mask is not None else None,
                                        **opt.options_dict)
@@ -712,19 +746,17 @@ def reconstruct_ptychography(
                     _lib.check(ctx.lib.adm_d2d(ctx.handle, optimizable_params['prj_affine_ls'].ptr, affine_identity_dev.ptr, 6 * 4))
 
             # ---- finishing a batch (ptychography.py:1231-1271) ----
-            current_loss = forward_model.current_loss
-            loss_history.append(current_loss)
-            print_flush('Minibatch/angle done in {} s; loss (rank 0) is {}.'.format(time.time() - t00, current_loss), sto_rank,
-                        rank, **stdout_options)
-            print_flush('Throughput: {} angles/sec'.format(minibatch_size / (time.time() - t00)), sto_rank, rank, **stdout_options)
-            f_conv.write('{},{},{},{}\n'.format(i_epoch, i_batch, current_loss, time.time() - t_zero))
-            f_conv.flush()
+            this_log = (i_epoch, i_batch, forward_model.take_loss_thunk() if builtin_model else (lambda v=forward_model.current_loss: v), t00)
+            flush_log()                     # the PREVIOUS minibatch: its loss is read after this one has been queued
+            pending_log[0] = this_log
             if optimizer_batch_number_increment == 'angle':
                 if is_last_batch_of_this_theta:
                     i_opt_batch += 1
             elif optimizer_batch_number_increment == 'batch':
                 i_opt_batch += 1
 
+        flush_log()
+        state.finish_update()
         if n_epochs != 'auto' and i_epoch == n_epochs - 1:
             cont = False
         print_flush('Epoch {} (rank {}); Delta-t = {} s; current time = {} s,'.format(i_epoch, rank, time.time() - t0,
