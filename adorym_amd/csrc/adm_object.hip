@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256) void rotate_adj_csr_kernel(const float2* __res
 struct TileGeom {
     int Yp, Xp, pad_y0, pad_x0, P, R1, R2, G, LPW, NT, n_steps, binning, Z;
     int row0, nrows;      // padded-row window touched by the batch
+    int add_lo, add_hi;   // padded rows [add_lo, add_hi) already hold an earlier part of the same batch: accumulate there
 };
 
 __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict__ pos, int B, TileGeom g,
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
 #endif
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
+    const bool add = (g.row0 + r >= g.add_lo) && (g.row0 + r < g.add_hi);
     const int st0 = blockIdx.z * TA_STEPS;
     const int nst = min(TA_STEPS, g.n_steps - st0);
     float2 acc[TA_STEPS];
@@ -249,7 +251,11 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
         if (i < nst) {
             const int st = st0 + i;
             const int s_lo = st * g.binning, s_hi = min(s_lo + g.binning, g.Z);
-            for (int sl = s_lo; sl < s_hi; ++sl) out[(size_t)sl * slice_stride] = acc[i];
+            for (int sl = s_lo; sl < s_hi; ++sl) {
+                float2 v = acc[i];
+                if (add) { const float2 o = out[(size_t)sl * slice_stride]; v.x += o.x; v.y += o.y; }
+                out[(size_t)sl * slice_stride] = v;
+            }
         }
     }
 }
@@ -575,6 +581,11 @@ extern "C" int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const i
 
 extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                                        const int32_t* pos_host, float* grad_rot) {
+    return adm_tile_grad_accumulate_part(plan, workspace, workspace_bytes, pos, batch, pos_host, grad_rot, 0, 0, 0);
+}
+
+extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                            const int32_t* pos_host, float* grad_rot, int win_y_lo, int win_y_hi, int add) {
     if (!plan || !workspace || !pos || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: batch must be positive");
     if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: workspace too small");
@@ -588,6 +599,16 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
     for (int b = 1; b < batch; ++b) { ymin = pos_host[2 * b] < ymin ? pos_host[2 * b] : ymin; ymax = pos_host[2 * b] > ymax ? pos_host[2 * b] : ymax; }
     g.row0 = ymin + d.pad_y0;
     g.nrows = ymax - ymin + N;
+    g.add_lo = g.add_hi = 0;
+    if (add) {                      // accumulate into this part's own rows (an earlier part wrote the whole batch window)
+        g.add_lo = g.row0;
+        g.add_hi = g.row0 + g.nrows;
+    } else if (win_y_hi > win_y_lo) {   // first part: write the whole batch window (zeros where no tile of this part reaches)
+        if (win_y_lo + d.pad_y0 > g.row0 || win_y_hi + d.pad_y0 < g.row0 + g.nrows)
+            return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_part: the window must contain the part's own rows");
+        g.row0 = win_y_lo + d.pad_y0;
+        g.nrows = win_y_hi - win_y_lo;
+    }
     if (g.row0 < 0 || g.row0 + g.nrows > g.Yp) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: a position lies outside the padded frame");
     const size_t per = (size_t)plan->n_steps * g.R1 * g.NT;
     if ((size_t)batch * per >= 0xFFFFFFFFull) return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate: batch too large for 32-bit tile offsets");

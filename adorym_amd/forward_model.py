@@ -217,11 +217,15 @@ class PtychographyModel(ForwardModel):
         B = len(np.asarray(this_pos_batch).reshape(-1, 2))
         mb = B // self.batch_group
         gs = 2.0 / (mb * eng.probe_size[0] * eng.probe_size[1])     # each reference minibatch is a mean over ITS positions
-        eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
-                       shift_index=idx, grad_shifts=gsh, accumulate=False)
-        if want_grad:
-            eng.accumulate_tiles()
-        ctx.join()
+        if want_grad and shifts is None and B > eng.N_CU:
+            ctx.join()              # the overlapped launch uses the side stream itself
+            eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)
+        else:
+            eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
+                           shift_index=idx, grad_shifts=gsh, accumulate=False)
+            if want_grad:
+                eng.accumulate_tiles()
+            ctx.join()
         self._last_mb = mb
         if want_grad:
             eng.rotate_adjoint(grad_obj, coords, yr)

@@ -241,18 +241,62 @@ class MultisliceEngine(object):
         check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
                                                     self._pos_host.ctypes.data, self.grad_rot.ptr))
         self._accumulated = True
+        self._acc_parts = [(self._ws, self._B)]
+
+    N_CU = 256        # MI355X compute units = multislice workgroups resident at once
+
+    def multislice_overlapped(self, probe, grad_probe=None, grad_scale=None, want_pred=False):
+        """multislice(want_grad=True) + accumulate_tiles() for batches larger than the chip.  A batch of B > 256 positions runs
+        in ceil(B/256) rounds of workgroups; here every round is its own launch (own workspace) and the overlap-add of round
+        i runs on the side stream BESIDE the launch of round i+1 -- in particular beside a short last round that leaves most
+        CUs idle.  Same sums as one launch + one overlap-add, up to the order of the additions per pixel."""
+        B = self._B
+        if B <= self.N_CU:
+            self.multislice(probe, grad_probe=grad_probe, want_grad=True, want_pred=want_pred, grad_scale=grad_scale)
+            return
+        Py, Px = self.probe_size
+        if grad_scale is None:
+            grad_scale = 2.0 / (B * Py * Px)
+        bounds = list(range(0, B, self.N_CU)) + [B]
+        parts = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1)]
+        if getattr(self, '_ws_parts', None) is None or len(self._ws_parts) < len(parts):
+            need = self.plan.workspace_bytes(self.N_CU)
+            self._ws_parts = [DeviceArray(self.ctx, (need,), np.uint8) for _ in parts]
+        lib, h = self.ctx.lib, self.plan.handle
+        gp = grad_probe.ptr if grad_probe is not None else None
+        pr = self._pred.ptr if want_pred else None
+        y_lo = int(self._pos_host[:, 0].min())
+        y_hi = int(self._pos_host[:, 0].max()) + Py
+        self._acc_parts = []
+        for i, (o, n) in enumerate(parts):
+            ws = self._ws_parts[i]
+            check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
+                                             self._cur_target.ptr + 4 * o * Py * Px, 1, gp, (pr + 4 * o * Py * Px) if pr else None,
+                                             self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes))
+            self.ctx.fork()                   # side stream: waits for this round, then runs beside the next one
+            check(lib.adm_tile_grad_accumulate_part(h, ws.ptr, ws.nbytes, self._cur_pos.ptr + 8 * o, n,
+                                                    self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
+            self.ctx.end_fork()
+            self._acc_parts.append((ws, n))
+        self.ctx.join()
+        self._accumulated = True
+
+    def _check_overflow(self):
+        if self._accumulated:
+            for ws, n in getattr(self, '_acc_parts', []):
+                if n > 64:                        # a pixel cannot be covered by more tiles than the part has
+                    ov = C.c_int(0)
+                    check(self.ctx.lib.adm_tile_grad_status(self.plan.handle, ws.ptr, ws.nbytes, n, C.byref(ov)))
+                    if ov.value:
+                        raise RuntimeError('tile overlap-add overflow: a pixel is covered by more than 64 tiles of this batch; '
+                                           'use a smaller batch')
+        self._accumulated = False
 
     def loss(self, last=None):
         """mean of the per-pixel loss terms over the batch (adorym/forward_model.py:88-103) -- blocks.
         ``last=n``: over the last n positions only (the final minibatch of a fused 'per angle' group)."""
         B = self._B
-        if self._accumulated and B > 64:      # a pixel cannot be covered by more than B <= 64 tiles
-            ov = C.c_int(0)
-            check(self.ctx.lib.adm_tile_grad_status(self.plan.handle, self._ws.ptr, self._ws.nbytes, B, C.byref(ov)))
-            if ov.value:
-                raise RuntimeError('tile overlap-add overflow: a pixel is covered by more than 64 tiles of this batch; '
-                                   'use a smaller batch')
-        self._accumulated = False
+        self._check_overflow()
         sums = self._loss.view(0, (B,)).get().astype(np.float64)
         if last is not None:
             sums = sums[B - last:]

@@ -188,6 +188,12 @@ int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols);
  * atomics).  pos_host = the same positions on the host (used for the row window). */
 int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                              const int32_t* pos_host, float* grad_rot);
+/* The same for a batch that was launched in several parts (each with its own workspace), so that the overlap-add of one
+ * part can run beside the multislice launch of the next.  First part: add = 0 and [win_y_lo, win_y_hi) = the y-window
+ * (object coordinates; may reach into the pads) of the WHOLE batch -- all of it is written (zeros where no tile of this part
+ * reaches).  Later parts: add = 1, their tiles are accumulated into what is there (win_* ignored). */
+int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                  const int32_t* pos_host, float* grad_rot, int win_y_lo, int win_y_hi, int add);
 /* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
  * (the overlap-add then dropped contributions; use smaller batches). */
 int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);

@@ -400,3 +400,33 @@ def test_config5_shape_driver_vs_reference(A, ctx, tmp_path):
     upd = np.linalg.norm(f['e2e_obj_64'] - np.stack([g0.real, g0.imag], -1))
     e, e_ref = np.linalg.norm(x - f['e2e_obj_64']) / upd, np.linalg.norm(f['e2e_obj_32'] - f['e2e_obj_64']) / upd
     assert e < max(5e-3, 3 * e_ref), (e, e_ref)
+
+
+def test_overlapped_split_launch_matches_single_launch(A, ctx):
+    """A batch larger than the chip (B = 300 > 256 workgroups) launched as full rounds + overlap-add beside the short last
+    round (multislice_overlapped) gives the same tile-gradient sums and losses as one launch + one overlap-add."""
+    r = cases.rng(314)
+    Y, X, S, P = 60, 64, 4, 16
+    pos = np.stack([r.integers(-6, Y - 8, 300), r.integers(-6, X - 8, 300)], 1)
+    pos[290:] = pos[:10]                                   # duplicates, like the padded minibatches of a fused angle
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=300)
+    obj = ctx.array(np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1).astype(np.float32))
+    probe = ctx.array((r.standard_normal((1, P, P, 2))).astype(np.float32))
+    meas = (np.abs(r.standard_normal((300, P, P))) * 10).astype(np.float32)
+    out = []
+    for overlapped in (False, True):
+        eng.set_batch(pos, meas)
+        eng.rotate(obj, None, None)
+        eng.grad_rot.zero_()
+        gp = ctx.zeros(probe.shape)
+        if overlapped:
+            eng.multislice_overlapped(probe, grad_probe=gp)
+        else:
+            eng.multislice(probe, grad_probe=gp)
+        g = ctx.zeros(obj.shape)
+        eng.rotate_adjoint(g, None, None)
+        out.append((eng.loss(), g.get(), eng._loss.get().copy(), gp.get()))
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][1] - out[1][1]).max() <= 2e-6 * np.abs(out[0][1]).max()
+    assert np.abs(out[0][3] - out[1][3]).max() <= 1e-5 * np.abs(out[0][3]).max()
