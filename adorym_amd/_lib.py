@@ -73,6 +73,7 @@ SIGNATURES = {
     'adm_tile_grad_accumulate_part': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP, _I, _I, _I]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
+    'adm_reg_grad_set': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
     'adm_momentum_step': (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _D, _D, _I, _VP]),

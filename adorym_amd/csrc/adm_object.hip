@@ -266,6 +266,8 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
+// SET: g = regulariser gradient (replaces a zero fill + accumulate when the gradient buffer is being initialised)
+template <bool SET>
 __global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__ x, float* __restrict__ g, int Y, int X, int Z,
                                                        float a_d, float a_b, float gamma, float* reg_value) {
     const size_t n = (size_t)Y * X * Z * 2;
@@ -293,7 +295,8 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__
             gr += gamma * invV * ((sgn(v - zp) - sgn(zm - v)) + (sgn(v - xp) - sgn(xm - v)) + (sgn(v - yp) - sgn(ym - v)));
             val += gamma * invV * (fabsf(zm - v) + fabsf(xm - v) + fabsf(ym - v));
         }
-        g[i] += gr;
+        if (SET) g[i] = gr;
+        else g[i] += gr;
     }
     if (reg_value) {
         __shared__ float red[4];
@@ -332,7 +335,7 @@ __device__ __forceinline__ void ri_up(const float2* __restrict__ x, size_t i, fl
 
 __global__ __launch_bounds__(256) void reg_grad_ri_kernel(const float2* __restrict__ x, float2* __restrict__ g, int Y, int X, int Z,
                                                           float a_d, float a_b, float gamma, const float* __restrict__ stats,
-                                                          float* reg_value) {
+                                                          float* reg_value, int set) {
     const size_t V = (size_t)Y * X * Z;
     const float invV = 1.0f / (float)V;
     float val = 0.f;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void reg_grad_ri_kernel(const float2* __restri
             gr += gamma * invV * (gu * 2.f * o.x - gp * o.y / u);
             gi += gamma * invV * (gu * 2.f * o.y + gp * o.x / u);
         }
-        float2 gv = g[i];
+        float2 gv = set ? make_float2(0.f, 0.f) : g[i];
         gv.x += gr;
         gv.y += gi;
         g[i] = gv;
@@ -636,8 +639,8 @@ extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t work
     return adm_d2h(plan->ctx, overflow_host, overflow, sizeof(int));
 }
 
-extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
-                            float* reg_value) {
+static int reg_grad_impl(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                         float* reg_value, bool set) {
     if (!plan || !obj || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad: null argument");
     const adm_plan_desc& d = plan->d;
     const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
@@ -653,14 +656,28 @@ extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, flo
             hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 1);
         }
         hipLaunchKernelGGL(reg_grad_ri_kernel, dim3(stream_grid(V)), dim3(256), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y,
-                           d.obj_x, d.obj_z, alpha_d, alpha_b, gamma, (const float*)plan->reg_stats, reg_value);
+                           d.obj_x, d.obj_z, alpha_d, alpha_b, gamma, (const float*)plan->reg_stats, reg_value, set ? 1 : 0);
         ADM_HIP(hipGetLastError());
         return ADM_OK;
     }
-    hipLaunchKernelGGL(reg_grad_kernel, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x,
-                       d.obj_z, alpha_d, alpha_b, gamma, reg_value);
+    if (set)
+        hipLaunchKernelGGL(reg_grad_kernel<true>, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x, d.obj_z,
+                           alpha_d, alpha_b, gamma, reg_value);
+    else
+        hipLaunchKernelGGL(reg_grad_kernel<false>, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x, d.obj_z,
+                           alpha_d, alpha_b, gamma, reg_value);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
+}
+
+extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                            float* reg_value) {
+    return reg_grad_impl(plan, obj, alpha_d, alpha_b, gamma, grad_obj, reg_value, false);
+}
+
+extern "C" int adm_reg_grad_set(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                                float* reg_value) {
+    return reg_grad_impl(plan, obj, alpha_d, alpha_b, gamma, grad_obj, reg_value, true);
 }
 
 extern "C" int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols) {

@@ -22,7 +22,7 @@ class Differentiator(object):
         self.loss_object = loss
         self.opt_args_ls = list(opt_args_ls) if opt_args_ls is not None else [0]
 
-    def get_gradients(self, _accumulate_into=None, _side_hook=None, **kwargs):
+    def get_gradients(self, _accumulate_into=None, _side_hook=None, _init_grad=False, **kwargs):
         """Returns (d loss/d obj, ...) like the reference.  The object gradient is a DeviceArray: by default a
         buffer owned by this Differentiator that is overwritten on every call; pass ``_accumulate_into`` to add
         the gradient straight into the caller's accumulation buffer (what ptychography.py:1063-1066 does next)."""
@@ -37,6 +37,8 @@ class Differentiator(object):
             target = _accumulate_into
         if _side_hook is not None:      # work the model may queue on the side stream next to the multislice chain
             kwargs['_side_hook'] = _side_hook
+        if _init_grad:                  # the accumulation buffer holds garbage: the model initialises it (no separate zero fill)
+            kwargs['_init_grad'] = True
         return fm.loss_and_gradients(self.opt_args_ls, target, **kwargs)
 
     def get_l_h_hessian_and_h_x_jacobian_mvps(self, *args, **kwargs):

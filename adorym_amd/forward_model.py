@@ -184,7 +184,7 @@ class PtychographyModel(ForwardModel):
 
     def _run(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad, grad_obj=None,
              want_probe_grad=False, want_pred=False, probe_pos_correction=None, this_ind_batch=None, want_shift_grad=False,
-             side_hook=None, regularize=True):
+             side_hook=None, regularize=True, init_grad=False):
         """One evaluation.  Stream plan (same as bench.py): rotation on the main stream; then, on the context's side
         stream, ``side_hook()`` (the driver zeroes the gradient buffer / finishes the previous update there) and the
         regulariser gradient -- they only need the object -- while the multislice chain, which occupies `minibatch` of
@@ -199,7 +199,10 @@ class PtychographyModel(ForwardModel):
         ctx.fork()
         if side_hook is not None:
             side_hook()
-        self._reg_pending = self._regularize_launch(obj, grad_obj if want_grad else None) if regularize else False
+        # init_grad: grad_obj is uninitialised -- the regulariser kernel writes it (one pass) or it is zero-filled
+        self._reg_pending = self._regularize_launch(obj, grad_obj if want_grad else None, init_grad and want_grad) if regularize else False
+        if init_grad and want_grad and not regularize:
+            grad_obj.zero_()
         ctx.end_fork()
         gp = None
         if want_probe_grad:
@@ -231,13 +234,17 @@ class PtychographyModel(ForwardModel):
             eng.rotate_adjoint(grad_obj, coords, yr)
         return gp, gsh
 
-    def _regularize_launch(self, obj, grad_obj):
+    def _regularize_launch(self, obj, grad_obj, init_grad=False):
         """Queue the regulariser kernels (value into a device scalar, gradient added to grad_obj if given) on the
-        current stream.  Returns True if a value is pending."""
+        current stream.  ``init_grad``: grad_obj holds garbage and is initialised here (regulariser kernel in 'set' mode,
+        or a zero fill).  Returns True if a value is pending."""
         from .regularizers import ReweightedL1Regularizer
         ad, ab, gm = combined_weights(self.reg_list)
         rw = [r for r in self.reg_list if isinstance(r, ReweightedL1Regularizer)]
-        if ad == 0 and ab == 0 and gm == 0 and not rw:
+        plain = ad != 0 or ab != 0 or gm != 0
+        if init_grad and not plain:
+            grad_obj.zero_()
+        if not plain and not rw:
             return False
         if self._reg_val is None:
             self._reg_val = self.device.zeros((1,))
@@ -247,8 +254,9 @@ class PtychographyModel(ForwardModel):
                 self._scratch_grad = self.device.empty((obj.size,))
             grad_obj = self._scratch_grad
         k = float(self.batch_group)     # every fused minibatch adds the regulariser once (forward_model.py:138-139)
-        if ad != 0 or ab != 0 or gm != 0:
-            check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, grad_obj.ptr, self._reg_val.ptr))
+        if plain:
+            fn = self.device.lib.adm_reg_grad_set if init_grad else self.device.lib.adm_reg_grad
+            check(fn(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, grad_obj.ptr, self._reg_val.ptr))
         for r in rw:
             if r.weight_l1 is None:
                 raise RuntimeError('ReweightedL1Regularizer: update_l1_weight() has not been called')
@@ -314,7 +322,7 @@ class PtychographyModel(ForwardModel):
 
     def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
                            this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, tilt_ls, prj_pos_offset,
-                           _side_hook=None):
+                           _side_hook=None, _init_grad=False):
         """
         The hand-derived replacement of ``torch.autograd.grad(loss, [args in opt_args_ls])``
         (adorym/wrappers.py:300-331): accumulates d loss/d obj into ``grad_obj`` (DeviceArray) and returns
@@ -328,7 +336,7 @@ class PtychographyModel(ForwardModel):
         want_probe = (i_pr in opt_args_ls) or (i_pi in opt_args_ls)
         gp, gsh = self._run(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, target, want_grad=True, grad_obj=grad_obj,
                             want_probe_grad=want_probe, probe_pos_correction=probe_pos_correction, this_ind_batch=this_ind_batch,
-                            want_shift_grad=i_pc in opt_args_ls, side_hook=_side_hook)
+                            want_shift_grad=i_pc in opt_args_ls, side_hook=_side_hook, init_grad=_init_grad)
         self._queue_loss()          # self.current_loss fetches it on first access
         out = []
         for i in opt_args_ls:
@@ -438,13 +446,15 @@ class MultiDistModel(PtychographyModel):
 
     def loss_and_gradients(self, opt_args_ls, grad_obj, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset,
                            this_i_theta, this_pos_batch, prj, probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width,
-                           prj_affine_ls, ctf_lg_kappa, prj_pos_offset, _side_hook=None):
+                           prj_affine_ls, ctf_lg_kappa, prj_pos_offset, _side_hook=None, _init_grad=False):
         """Replacement of torch.autograd.grad over MultiDistModel's loss: gradients ordered like opt_args_ls; index 0 ->
         grad_obj (accumulated in place), probe_real/probe_imag -> one interleaved DeviceArray, free_prop_cm -> DeviceArray
         [n_dists], prj_affine_ls -> DeviceArray [n_dists,2,3]."""
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         if _side_hook is not None:
             _side_hook()
+        if _init_grad:
+            grad_obj.zero_()
         nd = self.holo.n_dists
         idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls')}
         grads = {}

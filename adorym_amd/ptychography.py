@@ -633,10 +633,12 @@ def reconstruct_ptychography(
 
             # ---- gradients (ptychography.py:1017-1066) ----
             t_grad_0 = time.time()
-            side_hook = None
+            side_hook, init_grad = None, False
             if initialize_gradients:
                 if builtin_model:
-                    side_hook = state.zero_grad      # queued on the side stream, after the rotation (see PtychographyModel._run)
+                    # queued by the model on the side stream after the rotation: the deferred part of the previous update,
+                    # then the regulariser kernel in 'set' mode (or a zero fill) initialises the gradient buffer
+                    side_hook, init_grad = state.finish_update, True
                 else:
                     state.zero_grad()
                 if optimize_probe:
@@ -662,7 +664,7 @@ def reconstruct_ptychography(
                 else:
                     grad_func_args[arg] = optimizable_params[arg]
             forward_model.update_loss_args(grad_func_args)
-            grads = diff.get_gradients(_accumulate_into=gradient.arr, _side_hook=side_hook, **grad_func_args)
+            grads = diff.get_gradients(_accumulate_into=gradient.arr, _side_hook=side_hook, _init_grad=init_grad, **grad_func_args)
             print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
             if initialize_gradients:
                 initialize_gradients = False

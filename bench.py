@@ -115,9 +115,9 @@ def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=
         eng.set_batch(pos, tgt)
         eng.rotate(state.obj, tables[it], None)
         ctx.fork()
-        state.zero_grad()
-        check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * k, cfg['alpha_b'] * k, cfg['gamma'] * k,
-                                   state.grad.ptr, None))
+        state.finish_update()
+        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * k, cfg['alpha_b'] * k, cfg['gamma'] * k,
+                                       state.grad.ptr, None))
         ctx.end_fork()
         ctx.join()                  # (the side work is short; the overlapped launch below forks again)
         e0.record()
@@ -233,9 +233,9 @@ def main():
         yr = eng.y_footprint(pos)
         eng.rotate(state.obj, tables[it], yr)
         ctx.fork()
-        state.zero_grad()
-        check(ctx.lib.adm_reg_grad(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
-                                   state.grad.ptr, None))
+        state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
+        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
+                                       state.grad.ptr, None))      # initialises the gradient buffer: no separate zero fill
         ctx.end_fork()
         evs = ev_ms[k & 1] if timed else None
         if timed:

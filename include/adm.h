@@ -204,6 +204,10 @@ int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes
  * reg_value (device float[1], may be NULL) += the regulariser value.
  * Plans with unknown_type 'real_imag' evaluate the reference's real_imag branches instead (regularizers.py:38-45,
  * 105-110): alpha_d*mean| |o| - mean|o| | + alpha_b*mean|arg o| + gamma*(TV(re^2+im^2) + TV(atan2(im, re))). */
+/* adm_reg_grad_set: grad_obj = (instead of +=) the regulariser gradient -- initialises the gradient buffer of a new
+ * minibatch in one pass instead of a zero fill followed by an accumulate. */
+int adm_reg_grad_set(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                     float* reg_value);
 int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
                  float* reg_value);
 
