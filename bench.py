@@ -300,9 +300,13 @@ def main():
             out['cpu_baseline'] = cpu_baseline(cfg)
         if world == 1 and not args.no_per_angle:
             out['per_angle'] = per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check)
-        print(json.dumps(out))
+    else:
+        out = None
     if use_dist:
-        comm.close()
+        comm.close()            # RCCL may print its banner here; the JSON line goes last
+    if out is not None:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
