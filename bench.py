@@ -86,6 +86,25 @@ def cpu_baseline_torch(cfg, phys, probe, nb=2):
                       'reference op structure (oracle/torch_structured.py), %.1f s, torch %s' % (nb, dt, torch.__version__)}
 
 
+def cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize):
+    """CPU leg of tools/bench_rows.py (config-1 shape): seconds for the oracle's fwd + adjoint of one minibatch, fp32, 1 core."""
+    from oracle import adorym_oracle as O
+    phys = O.Physics((P, P), energy, psize, free_prop_cm='inf', unknown_type='real_imag')
+    tiles, _ = O.extract_tiles(obj_h, pos_int[:B], (P, P), 'real_imag')
+    meas = np.abs(np.random.default_rng(2).standard_normal((B, P, P)))
+    t1 = time.perf_counter()
+    O.forward_adjoint_tiles(tiles, probe_h, meas, phys, 'float32', shifts=(pos - pos_int)[:B])
+    return time.perf_counter() - t1
+
+
+def cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize):
+    """CPU leg of tools/bench_rows.py (config-5 shape): seconds for the oracle's fwd + adjoint of the 4-distance chain."""
+    from oracle import adorym_oracle as O
+    t1 = time.perf_counter()
+    O.holo_forward_adjoint(obj_h.astype(np.float64), np.ones((N, N), complex), d_h, a_h, data_h, energy, psize, dtype='float32')
+    return time.perf_counter() - t1
+
+
 def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=3):
     """Secondary figure (not `value`): the reference's update_scheme='per angle' -- the 17 minibatches of one angle
     (529 positions padded to 544, ptychography.py:820-823) see the same object, so adorym_amd fuses them into one

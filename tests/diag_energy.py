@@ -1,4 +1,5 @@
-"""GPU diagnostic: coherent energy drift of the propagation chain (object = 0 => c = 1 exactly)."""
+"""GPU diagnostic script (not collected by pytest; lives under tests/ because it uses the oracle): coherent energy drift of
+the propagation chain (object = 0 => c = 1 exactly).  python tests/diag_energy.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -115,3 +115,35 @@ def test_rank_slices_of_global_batch_match_reference_rule():
         for r in range(2):
             th, ind = O.rank_batch(b, k, r, 4, 2)
             assert th == full[r * 4, 0] and np.array_equal(ind, np.sort(full[r * 4:(r + 1) * 4, 1]))
+
+
+def test_deferred_update_equals_full_update():
+    """exchange_and_update(first=(lo, hi)) + finish_update() (the single-GPU stream plan: the next minibatch's planes are
+    updated first, the rest later on the side stream) is the same element-wise update as one full pass."""
+    sys.path.insert(0, ROOT)
+    from adorym_amd.comm import LocalComm
+    from adorym_amd.dp import DataParallelObject
+    shape = (6, 5, 4, 2)
+    r = np.random.default_rng(3)
+    ref = DataParallelObject(NumpyOps(), LocalComm(), shape)
+    sp = DataParallelObject(NumpyOps(), LocalComm(), shape)
+    n = ref.n
+    x0 = (r.standard_normal(n) * 1e-3).astype(np.float32)
+    ref.obj[:n] = x0
+    sp.obj[:n] = x0
+    plane = 5 * 4 * 2
+    for it in range(4):
+        g = r.standard_normal(n).astype(np.float32)
+        for st in (ref, sp):
+            st.zero_grad()                     # also flushes a deferred update
+            st.grad[:n] += g
+        ref.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+        lo, hi = (it % 3) * plane, ((it % 3) + 2) * plane
+        sp.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1, first=(lo, hi))
+        assert np.array_equal(sp.obj[lo:hi], ref.obj[lo:hi])           # the prioritised planes are final
+        if it == 1:
+            assert not np.array_equal(sp.obj[:n], ref.obj[:n])        # ... the rest is still pending
+    sp.finish_update()
+    assert np.array_equal(sp.obj[:n], ref.obj[:n])
+    for a, b in zip(sp.moments, ref.moments):
+        assert np.array_equal(a[:n], b[:n])

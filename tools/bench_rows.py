@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import adorym_amd as A                      # noqa: E402
 from adorym_amd._lib import check           # noqa: E402
-from oracle import adorym_oracle as O       # noqa: E402  (CPU baseline leg only)
+import bench                                # noqa: E402  (its cpu_baseline legs own the oracle timing)
 
 
 def bench_c1(ctx, steps=50):
@@ -67,12 +67,7 @@ def bench_c1(ctx, steps=50):
         step(3 + k)
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
-    # CPU: the oracle's forward + adjoint of the same minibatch (fp32), one core
-    phys = O.Physics((P, P), energy, psize, free_prop_cm='inf', unknown_type='real_imag')
-    tiles, _ = O.extract_tiles(obj_h, pos_int[:B], (P, P), 'real_imag')
-    t1 = time.perf_counter()
-    O.forward_adjoint_tiles(tiles, probe_h, np.abs(r.standard_normal((B, P, P))), phys, 'float32', shifts=(pos - pos_int)[:B])
-    tc = time.perf_counter() - t1
+    tc = bench.cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize)
     return {'row': 'f2 / config-1 shape', 'workload': '2-D ptychography 618x606x1 real_imag, P=64, 5 modes, minibatch 35, object+probe+position Adam, TV',
             'value': B / dt, 'unit': 'probe-positions/s', 'ms_per_step': 1e3 * dt,
             'cpu_baseline': {'value': B / tc, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
@@ -116,9 +111,7 @@ def bench_c5(ctx, steps=50):
         step()
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
-    t1 = time.perf_counter()
-    O.holo_forward_adjoint(obj_h.astype(np.float64), np.ones((N, N), complex), d_h, a_h, data_h, energy, psize, dtype='float32')
-    tc = time.perf_counter() - t1
+    tc = bench.cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize)
     # algorithmic bytes of one step: read obj+probe, read 4 holograms, write grad (fields stay on chip in principle)
     return {'row': 'f1 / config-5 shape', 'workload': 'multi-distance holography 512x512x1 real_imag, 4 distances, object+distance+affine Adam',
             'value': 1.0 / dt, 'unit': 'minibatches/s (4 holograms each)', 'ms_per_step': 1e3 * dt,
