@@ -64,6 +64,7 @@ SIGNATURES = {
     'adm_rotate_fwd': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
+    'adm_rotate_adj_staged': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_multislice_fwd_adj_pp': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_probe_shift': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),

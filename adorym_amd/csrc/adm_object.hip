@@ -156,6 +156,121 @@ __global__ __launch_bounds__(256) void rotate_adj_csr_kernel(const float2* __res
     }
 }
 
+// LDS-staged variant of the CSR rotation adjoint: the sources of a 16 x 16 patch of object-plane voxels lie in a
+// (x', z') bounding box of at most ~27 x 27 rotated-frame voxels (host-computed per patch and angle).  The box rows are
+// loaded contiguously along x' into LDS for four y planes, and the bilinear-transpose gather then runs out of LDS -- the
+// memory access pattern no longer depends on the angle (the direct gather is 10x slower at 45 degrees than at 0).
+// lsrc[j] = (z' - box.z0) * box.w + (x' - box.x0) of CSR entry j.
+#define ADM_STAGE_MAX 1024          // float2 elements per plane in LDS when four planes are staged at once
+__global__ __launch_bounds__(256) void rotate_adj_staged_kernel(const float2* __restrict__ grot, const int* __restrict__ ptr,
+                                                                const int* __restrict__ src, const unsigned short* __restrict__ lsrc,
+                                                                const float* __restrict__ wgt,
+                                                                const int4* __restrict__ boxes, float2* __restrict__ gobj, RotGeom g,
+                                                                int y_lo, int y_hi) {
+    __shared__ float2 stage[4 * ADM_STAGE_MAX];
+    const int4 box = boxes[blockIdx.y * gridDim.x + blockIdx.x];      // (x0, z0, w, h)
+    const int y0 = y_lo + blockIdx.z * 4;
+    const int ny = min(4, y_hi - y0);
+    const int bw = box.z, bh = box.w, per = bw * bh;
+    const size_t slice = (size_t)g.Yp * g.Xp;
+    const size_t plane = (size_t)g.X * g.Z;
+    const int lx = threadIdx.x >> 4, lz = threadIdx.x & 15;          // lanes along z, the fastest object axis
+    const int x = blockIdx.x * 16 + lx, z = blockIdx.y * 16 + lz;
+    const bool ok = (x < g.X) && (z < g.Z);
+    const int t = ok ? x * g.Z + z : 0;
+    const int beg = ok ? ptr[t] : 0, end = ok ? ptr[t + 1] : 0;
+    float2* o = gobj + (size_t)y0 * plane + (size_t)x * g.Z + z;
+    if (bw == 0) {
+        // no usable box (only for objects much larger than 256^3): gather from global memory
+        if (!ok) return;
+        const size_t row = (size_t)(g.pad_y0 + y0) * g.Xp;
+        float2 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = make_float2(0.f, 0.f);
+        for (int j = beg; j < end; ++j) {
+            const float w = wgt[j];
+            const float2* q = grot + (size_t)src[j] + row;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < ny) { const float2 v = q[(size_t)i * g.Xp]; a[i].x += w * v.x; a[i].y += w * v.y; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < ny) { float2 c = o[(size_t)i * plane]; c.x += a[i].x; c.y += a[i].y; o[(size_t)i * plane] = c; }
+        return;
+    }
+    if (per <= ADM_STAGE_MAX) {
+        // interior patch: the boxes of four y planes fit at once
+        for (int idx = threadIdx.x; idx < 4 * per; idx += 256) {
+            const int p = idx / per, rem = idx - p * per;
+            const int zz = rem / bw, xx = rem - zz * bw;
+            float2 v = make_float2(0.f, 0.f);
+            if (p < ny) v = grot[(size_t)(box.y + zz) * slice + (size_t)(g.pad_y0 + y0 + p) * g.Xp + g.pad_x0 + box.x + xx];
+            stage[p * ADM_STAGE_MAX + rem] = v;
+        }
+        __syncthreads();
+        if (!ok) return;
+        float2 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = make_float2(0.f, 0.f);
+        for (int j = beg; j < end; ++j) {
+            const float w = wgt[j];
+            const int q = lsrc[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float2 v = stage[i * ADM_STAGE_MAX + q]; a[i].x += w * v.x; a[i].y += w * v.y; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < ny) { float2 c = o[(size_t)i * plane]; c.x += a[i].x; c.y += a[i].y; o[(size_t)i * plane] = c; }
+        return;
+    }
+    // rim patch (border clamping folds a corner of the rotated frame onto it: box of up to 4096 voxels): one or two planes
+    // per pass over the CSR entries, whatever fits the 32 KB stage
+    const int npp = (2 * per <= 4 * ADM_STAGE_MAX) ? 2 : 1;
+    for (int p0 = 0; p0 < ny; p0 += npp) {
+        for (int idx = threadIdx.x; idx < npp * per; idx += 256) {
+            const int pp = idx / per, rem = idx - pp * per;
+            const int zz = rem / bw, xx = rem - zz * bw;
+            float2 v = make_float2(0.f, 0.f);
+            if (p0 + pp < ny) v = grot[(size_t)(box.y + zz) * slice + (size_t)(g.pad_y0 + y0 + p0 + pp) * g.Xp + g.pad_x0 + box.x + xx];
+            stage[idx] = v;
+        }
+        __syncthreads();
+        if (ok) {
+            float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+            const int second = (npp == 2) ? per : 0;
+            for (int j = beg; j < end; j += 8) {       // eight entries' weight/offset loads in flight, then the LDS gathers
+                float w[8];
+                int q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = min(j + u, end - 1);
+                    w[u] = (j + u < end) ? wgt[jj] : 0.f;
+                    q[u] = lsrc[jj];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float2 v0 = stage[q[u]];
+                    const float2 v1 = stage[q[u] + second];
+                    acc0.x += w[u] * v0.x; acc0.y += w[u] * v0.y;
+                    acc1.x += w[u] * v1.x; acc1.y += w[u] * v1.y;
+                }
+            }
+            float2 c = o[(size_t)p0 * plane];
+            c.x += acc0.x;
+            c.y += acc0.y;
+            o[(size_t)p0 * plane] = c;
+            if (npp == 2 && p0 + 1 < ny) {
+                float2 d = o[(size_t)(p0 + 1) * plane];
+                d.x += acc1.x;
+                d.y += acc1.y;
+                o[(size_t)(p0 + 1) * plane] = d;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Overlap-add of the per-position tile gradients written by the multislice kernel (adjoint of the
 // tile gather, adorym/forward_model.py:313-331).  Tiles overlap, so this is a gather per rotated-frame
@@ -578,6 +693,22 @@ extern "C" int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const i
     else
         hipLaunchKernelGGL(rotate_adj_csr_kernel<false>, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src,
                            csr_w, (float2*)grad_obj, g, y_lo, y_hi);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
+                                     const uint16_t* csr_lsrc, const float* csr_w, const int32_t* boxes, float* grad_obj, int y_lo,
+                                     int y_hi) {
+    if (!plan || !grad_rot || !csr_ptr || !csr_src || !csr_lsrc || !csr_w || !boxes || !grad_obj)
+        return fail(ADM_ERR_INVALID, "adm_rotate_adj_staged: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_adj_staged: bad y range");
+    if (y_lo == y_hi) return ADM_OK;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + 3) / 4);
+    hipLaunchKernelGGL(rotate_adj_staged_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src,
+                       (const unsigned short*)csr_lsrc, csr_w, (const int4*)boxes, (float2*)grad_obj, g, y_lo, y_hi);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

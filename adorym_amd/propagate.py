@@ -61,8 +61,8 @@ class RotationTable(object):
         key = (plan.rot_shape, plan.pads)
         if self._csr is None or self._csr_key != key:
             Zp, Yp, Xp, _ = plan.rot_shape
-            p, s, w = build_rotation_adjoint_csr(self.host, self.obj_size, Yp, Xp, plan.pads[1][0])
-            self._csr = (self.ctx.array(p), self.ctx.array(s), self.ctx.array(w))
+            parts = build_rotation_adjoint_csr(self.host, self.obj_size, Yp, Xp, plan.pads[1][0], staged=True)
+            self._csr = tuple(self.ctx.array(a) for a in parts)          # ptr, src, lsrc, w, boxes
             self._csr_key = key
         return self._csr
 
@@ -159,9 +159,9 @@ class MultisliceEngine(object):
         coordinate array (or None = identity) the scatter kernel with float atomics."""
         lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
         if isinstance(coords, RotationTable):
-            p, s, w = coords.csr(self.plan)
-            check(self.ctx.lib.adm_rotate_adj_csr(self.plan.handle, self.grad_rot.ptr, p.ptr, s.ptr, w.ptr, grad_obj.ptr, lo, hi,
-                                                  1 if coords.lanes_along_x else 0))
+            p, s, ls, w, b = coords.csr(self.plan)
+            check(self.ctx.lib.adm_rotate_adj_staged(self.plan.handle, self.grad_rot.ptr, p.ptr, s.ptr, ls.ptr, w.ptr, b.ptr,
+                                                     grad_obj.ptr, lo, hi))
         else:
             check(self.ctx.lib.adm_rotate_adj(self.plan.handle, self.grad_rot.ptr, coords.ptr if coords is not None else None,
                                               grad_obj.ptr, lo, hi))

@@ -132,7 +132,7 @@ def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=
     return probe_real, probe_imag
 
 
-def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0):
+def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0, staged=False):
     """
     Transpose of the bilinear sampling operator of one angle, as CSR over object-plane voxels t = x*Z + z
     (for adm_rotate_adj_csr).  The coordinate pipeline is w.grid_sample's (adorym/wrappers.py:1137-1141) followed by
@@ -168,4 +168,22 @@ def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0):
     tg, sr, ww = tg[order], sr[order], ww[order]
     ptr = np.zeros(X * Z + 1, dtype=np.int64)
     np.cumsum(np.bincount(tg, minlength=X * Z), out=ptr[1:])
-    return ptr.astype(np.int32), sr.astype(np.int32), ww.astype(np.float32)
+    if not staged:
+        return ptr.astype(np.int32), sr.astype(np.int32), ww.astype(np.float32)
+    # LDS-staged form (adm_rotate_adj_staged): per 16 x 16 patch of targets the bounding box of its sources
+    nbx, nbz = (X + 15) // 16, (Z + 15) // 16
+    blk = ((tg % Z) // 16) * nbx + (tg // Z) // 16
+    zs, xs = sr // (Yp * Xp), sr % (Yp * Xp) - pad_x0
+    big = np.iinfo(np.int64).max
+    x0 = np.full(nbx * nbz, big); z0 = np.full(nbx * nbz, big)
+    x1 = np.full(nbx * nbz, -1); z1 = np.full(nbx * nbz, -1)
+    np.minimum.at(x0, blk, xs); np.minimum.at(z0, blk, zs)
+    np.maximum.at(x1, blk, xs); np.maximum.at(z1, blk, zs)
+    empty = x1 < 0
+    x0[empty] = z0[empty] = 0
+    bw = np.where(empty, 1, x1 - x0 + 1); bh = np.where(empty, 1, z1 - z0 + 1)
+    too_big = bw * bh > 4096          # (rim patches, onto which border clamping folds a corner of the rotated frame, reach ~3000 at 256^3)
+    bw[too_big] = 0
+    lsrc = np.where(too_big[blk], 0, (zs - z0[blk]) * bw[blk] + (xs - x0[blk]))
+    boxes = np.stack([x0, z0, bw, bh], -1).astype(np.int32)
+    return ptr.astype(np.int32), sr.astype(np.int32), lsrc.astype(np.uint16), ww.astype(np.float32), boxes

@@ -133,6 +133,13 @@ int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords
  * gather neighbouring x' of grad_rot. */
 int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
                        const float* csr_w, float* grad_obj, int y_lo, int y_hi, int lanes_along_x);
+/* The same gather staged through LDS: boxes int32 [ceil(Z/16)][ceil(X/16)][4] = (x'0, z'0, width, height) is the
+ * rotated-frame bounding box (width*height <= 4096; four planes are staged at once up to 1024, else one at a time: rim patches
+ * collect the border-clamped samples of a whole corner of the rotated frame) of the sources of each 16 x 16 patch of
+ * object-plane voxels (x-patch index fastest) and csr_lsrc uint16 [nnz] = (z' - z'0) * width + (x' - x'0); width = 0 marks a
+ * patch without a usable box, which gathers through csr_src as adm_rotate_adj_csr does. */
+int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
+                          const uint16_t* csr_lsrc, const float* csr_w, const int32_t* boxes, float* grad_obj, int y_lo, int y_hi);
 
 /* ---- R3,R5-R8,R10  multislice forward + loss + adjoint ------------------------------
  * Replaces, for one minibatch of `batch` probe positions of one rotation angle:
