@@ -235,6 +235,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
     p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
     p->reg_stats = nullptr;
+    p->det_weight_dev = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
@@ -262,8 +263,25 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
     if (plan->twid_dev) adm_free(plan->ctx, plan->twid_dev);
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
+    if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
     delete plan;
     return ADM_OK;
+}
+
+extern "C" int adm_plan_set_detector_mask(adm_plan* plan, const float* mask_host) {
+    if (!plan) return fail(ADM_ERR_INVALID, "adm_plan_set_detector_mask: null plan");
+    const size_t n = (size_t)plan->d.probe_y * plan->d.probe_x;
+    if (!mask_host) {
+        if (plan->det_weight_dev) { adm_free(plan->ctx, plan->det_weight_dev); plan->det_weight_dev = nullptr; }
+        return ADM_OK;
+    }
+    std::vector<float> w(n);
+    for (size_t i = 0; i < n; ++i) w[i] = mask_host[i] >= 1e-5f ? 1.f : 0.f;      // forward_model.py:130-131
+    if (!plan->det_weight_dev) {
+        int rc = adm_malloc(plan->ctx, n * sizeof(float), (void**)&plan->det_weight_dev);
+        if (rc) return rc;
+    }
+    return adm_h2d(plan->ctx, plan->det_weight_dev, w.data(), n * sizeof(float));
 }
 
 extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
@@ -339,6 +357,7 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
     p.loss_type = d.loss_type;
     p.poisson_mult = d.poisson_multiplier;
     p.real_imag = d.unknown_type;
+    p.det_weight = plan->det_weight_dev;
     if (per_position) {
         if (d.binning != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: binning > 1 is not implemented with per-position probes");
         p.probe_bstride = p.gprobe_bstride = (size_t)d.n_modes * d.probe_y * d.probe_x;

@@ -27,6 +27,7 @@ struct adm_plan {
     float2* h_dev;         // [Py*Px] slice transfer function
     float2* hfree_dev;     // [Py*Px] or nullptr
     float2* twid_dev;      // [Px] exp(-2 pi i j / N)
+    float* det_weight_dev; // [Py*Px] beamstop weights or nullptr (adm_plan_set_detector_mask)
     float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
 };
 
@@ -60,6 +61,7 @@ struct MsParams {
     int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
     float poisson_mult;
     int real_imag;             // unknown_type == 'real_imag'
+    const float* det_weight;   // [P][P] 0/1 weights of the detector pixels in the loss (beamstop), reference layout; or nullptr
     size_t probe_bstride;      // float2 elements between the probes of consecutive positions (0 = one shared probe set)
     size_t gprobe_bstride;     // same for grad_probe (per-position gradients when the probes are per position)
 };

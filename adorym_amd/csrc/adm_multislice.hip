@@ -626,9 +626,10 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                     const cf psi = cscale(bb[k], p.det_scale);      // (conjugated when det_inverse; |.| unaffected)
                     const float mag = sqrtf(psi.x * psi.x + psi.y * psi.y);
                     float g;
-                    lsum += loss_term(mag, p.target[di], p, g);
+                    const float wq = p.det_weight ? p.det_weight[my * N + mx] : 1.f;     // beamstop mask (forward_model.py:128-136)
+                    lsum += wq * loss_term(mag, p.target[di], p, g);
                     if (p.pred) p.pred[di] = mag;
-                    bb[k] = cscale(psi, g * p.det_scale);            // adjoint of (scale * F) is scale * F^H
+                    bb[k] = cscale(psi, wq * g * p.det_scale);       // adjoint of (scale * F) is scale * F^H
                 }
             }
         } else if (c.act1) {
@@ -637,9 +638,10 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                 const size_t di = ((size_t)b * N + c.line) * N + k * R2 + c.t;
                 const float mag = sqrtf(a[k].x * a[k].x + a[k].y * a[k].y);
                 float g;
-                lsum += loss_term(mag, p.target[di], p, g);
+                const float wq = p.det_weight ? p.det_weight[c.line * N + k * R2 + c.t] : 1.f;
+                lsum += wq * loss_term(mag, p.target[di], p, g);
                 if (p.pred) p.pred[di] = mag;
-                a[k] = cscale(a[k], g);
+                a[k] = cscale(a[k], wq * g);
             }
         }
         block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
@@ -689,7 +691,9 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                     const int my = (c.t + R1 * k + N / 2) % N;
                     const size_t di = ((size_t)b * N + my) * N + mx;
                     const float mag = sqrtf(inten[k]);
-                    lsum += loss_term_nz(mag, p.target[di], p, gf[k]);
+                    const float wq = p.det_weight ? p.det_weight[my * N + mx] : 1.f;
+                    lsum += wq * loss_term_nz(mag, p.target[di], p, gf[k]);
+                    gf[k] *= wq;
                     if (p.pred) p.pred[di] = mag;
                 }
             }
@@ -698,7 +702,9 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             for (int k = 0; k < R1; ++k) {
                 const size_t di = ((size_t)b * N + c.line) * N + k * R2 + c.t;
                 const float mag = sqrtf(inten[k]);
-                lsum += loss_term_nz(mag, p.target[di], p, gf[k]);
+                const float wq = p.det_weight ? p.det_weight[c.line * N + k * R2 + c.t] : 1.f;
+                lsum += wq * loss_term_nz(mag, p.target[di], p, gf[k]);
+                gf[k] *= wq;
                 if (p.pred) p.pred[di] = mag;
             }
         }

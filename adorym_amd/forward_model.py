@@ -219,7 +219,7 @@ class PtychographyModel(ForwardModel):
             gsh = self._grad_shift_dev.zero_()
         B = len(np.asarray(this_pos_batch).reshape(-1, 2))
         mb = B // self.batch_group
-        gs = 2.0 / (mb * eng.probe_size[0] * eng.probe_size[1])     # each reference minibatch is a mean over ITS positions
+        gs = 2.0 / (mb * eng.n_det)     # each reference minibatch is a mean over ITS positions (and the kept detector pixels)
         if want_grad and shifts is None and B > eng.N_CU:
             ctx.join()              # the overlapped launch uses the side stream itself
             eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)

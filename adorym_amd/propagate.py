@@ -80,7 +80,8 @@ class MultisliceEngine(object):
 
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
-                 n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta'):
+                 n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta',
+                 beamstop=None):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -113,6 +114,12 @@ class MultisliceEngine(object):
         self.loss_function_type = loss_function_type
         self.pads = pads
         self.n_probe_modes = int(n_probe_modes)
+        # beamstop (adorym/forward_model.py:128-136): detector pixels with beamstop >= 1e-5 enter the loss
+        self.n_det = self.probe_size[0] * self.probe_size[1]
+        if beamstop is not None:
+            bs = np.ascontiguousarray(np.asarray(beamstop, dtype=np.float32).reshape(self.probe_size))
+            check(ctx.lib.adm_plan_set_detector_mask(self.plan.handle, bs.ctypes.data))
+            self.n_det = int((bs >= 1e-5).sum())
         self.obj_rot = ctx.zeros(self.plan.rot_shape)       # pads stay zero forever
         if unknown_type == 'real_imag':
             # pad_object pads a real_imag object with 1 + 0i (adorym/util.py:1338-1350): vacuum transmission
@@ -207,7 +214,7 @@ class MultisliceEngine(object):
         B = self._B
         Py, Px = self.probe_size
         if grad_scale is None:
-            grad_scale = 2.0 / (B * Py * Px)          # d mean((pred-target)^2) / d pred
+            grad_scale = 2.0 / (B * self.n_det)       # d mean((pred-target)^2) / d pred
         lib = self.ctx.lib
         if shifts is None:
             check(lib.adm_multislice_fwd_adj(
@@ -256,7 +263,7 @@ class MultisliceEngine(object):
             return
         Py, Px = self.probe_size
         if grad_scale is None:
-            grad_scale = 2.0 / (B * Py * Px)
+            grad_scale = 2.0 / (B * self.n_det)
         bounds = list(range(0, B, self.N_CU)) + [B]
         parts = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1)]
         if getattr(self, '_ws_parts', None) is None or len(self._ws_parts) < len(parts):
@@ -300,7 +307,7 @@ class MultisliceEngine(object):
         sums = self._loss.view(0, (B,)).get().astype(np.float64)
         if last is not None:
             sums = sums[B - last:]
-        return float(sums.sum() / (len(sums) * self.probe_size[0] * self.probe_size[1]))
+        return float(sums.sum() / (len(sums) * self.n_det))
 
     def loss_async(self, last=None):
         """Queue the read-back of the per-position loss sums of the batch just launched and return a token for
@@ -323,7 +330,7 @@ class MultisliceEngine(object):
         sums = self._loss_pinned[k].array[:B].astype(np.float64)
         if last is not None:
             sums = sums[B - last:]
-        return float(sums.sum() / (len(sums) * self.probe_size[0] * self.probe_size[1]))
+        return float(sums.sum() / (len(sums) * self.n_det))
 
     def pred(self):
         return self._pred.view(0, (self._B,) + self.probe_size).get()

@@ -176,7 +176,6 @@ def reconstruct_ptychography(
     _not_implemented(pure_projection or forward_algorithm != 'fresnel', 'pure_projection / CTF forward algorithm')
     _not_implemented(use_epie, 'ePIE')
     _not_implemented(is_minus_logged, 'is_minus_logged')
-    _not_implemented(beamstop is not None, 'beamstop')
     _not_implemented(not common_probe_pos, 'common_probe_pos=False')
     _not_implemented(not shared_probe_among_angles, 'shared_probe_among_angles=False')
     _not_implemented(update_using_external_algorithm is not None, 'update_using_external_algorithm')
@@ -296,7 +295,7 @@ def reconstruct_ptychography(
                                   binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
                                   normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
                                   max_batch=minibatch_size, loss_function_type=loss_function_type,
-                                  poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
+                                  poisson_multiplier=poisson_multiplier, unknown_type=unknown_type, beamstop=beamstop)
 
     # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
     # (the reference caches them as .npy files in ./arrsize_*; no files are written here)

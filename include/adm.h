@@ -108,6 +108,10 @@ typedef struct {
 
 int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out);
 int adm_plan_destroy(adm_plan* plan);
+/* Beamstop (adorym/forward_model.py:128-136): host float [Py][Px] in the detector layout of the data; pixels with
+ * mask >= 1e-5 take part in the loss, the others are dropped.  The per-position loss sums then run over the kept pixels only
+ * and the caller's grad_scale / mean use their count.  NULL removes the mask. */
+int adm_plan_set_detector_mask(adm_plan* plan, const float* mask_host);
 /* number of floats of one rotated-frame buffer: obj_z * (obj_y+pads) * (obj_x+pads) * 2.
  * Internal layout is slice-major [Z][Yp][Xp][2] so that a tile slice is Py contiguous rows. */
 size_t adm_plan_rot_elems(const adm_plan* plan);

@@ -407,7 +407,7 @@ def fourier_shift(probes, shift, dtype='float64'):
 
 
 def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_function_type='lsq',
-                          raw_data_type='magnitude', poisson_multiplier=1., shifts=None):
+                          raw_data_type='magnitude', poisson_multiplier=1., shifts=None, beamstop=None):
     """
     Loss + hand-derived gradient w.r.t. the tiles and the probe(s).  Replaces
     ``torch.autograd.grad`` (wrappers.py:322) over forward_model.py:337-375 +
@@ -415,6 +415,8 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
 
     Returns loss, pred [B,Py,Px], grad_tiles [B,Py,Px,S,2], grad_probes complex [M,Py,Px]
     (real part = dL/dprobe_real, imag part = dL/dprobe_imag).
+
+    ``beamstop`` [Py,Px] (optional): only detector pixels with beamstop >= 1e-5 enter the loss (forward_model.py:128-136).
 
     ``shifts`` [B,2] (optional): sub-pixel probe position corrections; position b sees every mode Fourier-shifted by
     shifts[b] (forward_model.py:296-311).  A fifth return value dL/dshifts [B,2] is appended and the probe gradient
@@ -444,8 +446,14 @@ def forward_adjoint_tiles(tiles, probes, meas, phys, dtype='float64', loss_funct
     else:
         pred = np.sqrt(sum((f.real ** 2 + f.imag ** 2) for f in fields))
     meas = np.asarray(meas).astype(dt, copy=False)
-    loss = mismatch_loss(pred, meas, loss_function_type, raw_data_type, poisson_multiplier)
-    dldp = _dloss_dpred(pred, meas, loss_function_type, raw_data_type, poisson_multiplier).astype(dt)
+    if beamstop is None:
+        loss = mismatch_loss(pred, meas, loss_function_type, raw_data_type, poisson_multiplier)
+        dldp = _dloss_dpred(pred, meas, loss_function_type, raw_data_type, poisson_multiplier).astype(dt)
+    else:
+        keep = np.asarray(beamstop) >= 1e-5
+        loss = mismatch_loss(pred[:, keep], meas[:, keep], loss_function_type, raw_data_type, poisson_multiplier)
+        dldp = np.zeros_like(pred)
+        dldp[:, keep] = _dloss_dpred(pred[:, keep], meas[:, keep], loss_function_type, raw_data_type, poisson_multiplier)
     grad_tiles = np.zeros_like(tiles)
     grad_probes = np.zeros(probes.shape, dtype=cdt)
     k1 = dt.type(phys.k1)

@@ -718,9 +718,34 @@ def gen_f12():
     gs.run_fp64 = False
     save('F12_multidist', **out)
 
+# ----------------------------------------------------------------------------- F13 (beamstop mask, forward_model.py:128-136)
+def gen_f13():
+    out = {}
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = np.load(os.path.join(HERE, 'F23_' + name + '.npz'))['meas']
+    P = meas.shape[-1]
+    r = cases.rng(1300)
+    bs = r.uniform(0, 1, (P, P))
+    bs[bs < 0.35] = 0.0                      # dropped pixels
+    bs[3, 4] = 5e-6                          # below the 1e-5 threshold: dropped as well
+    out['beamstop'] = bs
+    for fp64 in (True, False):
+        t, prs, pis, fields, pred = ref_case(c, c['guess'], fp64)
+        fm = adorym.ForwardModel(loss_function_type='lsq', raw_data_type='magnitude')
+        fm.common_vars = {'beamstop': torch.tensor(bs.copy(), dtype=pred.dtype)}
+        loss = fm.loss(pred, torch.tensor(meas, dtype=pred.dtype), t)
+        g = torch.autograd.grad(loss, [t] + prs + pis)
+        tag = '64' if fp64 else '32'
+        out['loss_' + tag] = np.array(loss.item())
+        out['grad_tiles_' + tag] = g[0].numpy()
+        out['grad_probe_' + tag] = g[1].numpy() + 1j * g[2].numpy()
+    gs.run_fp64 = False
+    save('F13_beamstop', **out)
+
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12']
+    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -732,3 +757,4 @@ if __name__ == '__main__':
     if 'f10' in which: gen_f10()
     if 'f11' in which: gen_f11()
     if 'f12' in which: gen_f12()
+    if 'f13' in which: gen_f13()

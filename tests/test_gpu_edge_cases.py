@@ -430,3 +430,34 @@ def test_overlapped_split_launch_matches_single_launch(A, ctx):
     assert np.array_equal(out[0][2], out[1][2])
     assert np.abs(out[0][1] - out[1][1]).max() <= 2e-6 * np.abs(out[0][1]).max()
     assert np.abs(out[0][3] - out[1][3]).max() <= 1e-5 * np.abs(out[0][3]).max()
+
+
+def test_beamstop_vs_reference(A, ctx):
+    """Beamstop mask (forward_model.py:128-136) through the kernel against the reference's autograd (golden F13)."""
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F13_beamstop.npz'))
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F23_' + name + '.npz'))['meas']
+    tiles = c['guess']
+    B, P, _, S, _ = tiles.shape
+    obj = np.concatenate(list(tiles), axis=1)
+    pos = np.array([[0, b * P] for b in range(B)])
+    eng = A.MultisliceEngine(ctx, (P, B * P, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=c['free_prop_cm'],
+                             binning=c['binning'], max_batch=B, beamstop=f['beamstop'])
+    eng.set_batch(pos, meas.astype(np.float32))
+    obj_d = ctx.array(obj.astype(np.float32))
+    eng.rotate(obj_d, None, None)
+    probe = c['probes']
+    probe_d = ctx.array(np.stack([probe.real, probe.imag], -1).astype(np.float32))
+    gp = ctx.zeros(probe_d.shape)
+    eng.multislice(probe_d, grad_probe=gp)
+    g_obj = ctx.zeros(obj_d.shape)
+    eng.rotate_adjoint(g_obj, None, None)
+    assert abs(eng.loss() - f['loss_64']) < 2e-5 * abs(f['loss_64'])
+    gt = np.stack(np.split(g_obj.get(), B, axis=1))
+    gph = gp.get()
+    for mine, key in ((gt, 'grad_tiles'), (gph[0, ..., 0] + 1j * gph[0, ..., 1], 'grad_probe')):
+        r64, r32 = f[key + '_64'], f[key + '_32']
+        err = np.linalg.norm(mine - r64) / np.linalg.norm(r64)
+        err_ref = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        assert err < max(1e-4, 3 * err_ref), (key, err, err_ref)

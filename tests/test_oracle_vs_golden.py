@@ -424,3 +424,16 @@ def test_f12_end_to_end_config5_shape():
     assert np.abs(out['dists'] - f['e2e_dists_64']).max() < 1e-8
     assert np.abs(out['affine'] - f['e2e_affine_64']).max() < 1e-8
     assert np.abs(out['obj'] - f['e2e_obj_64']).max() < 2e-6
+
+
+def test_f13_beamstop_loss_and_gradients():
+    """Beamstop mask of ForwardModel.loss (forward_model.py:128-136): pixels with beamstop >= 1e-5 are kept."""
+    f = load('F13_beamstop')
+    name = 'p12_s9_far_pos'
+    c = cases.tile_case_inputs(name)
+    meas = load('F23_' + name)['meas']
+    phys = O.Physics(c['probes'].shape[-2:], cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=c['free_prop_cm'], binning=c['binning'])
+    loss, pred, gt, gp = O.forward_adjoint_tiles(c['guess'], c['probes'], meas, phys, 'float64', beamstop=f['beamstop'])
+    assert abs(loss - f['loss_64']) < 1e-12 * abs(f['loss_64'])
+    assert np.linalg.norm(gt - f['grad_tiles_64']) < 1e-10 * np.linalg.norm(f['grad_tiles_64'])
+    assert np.linalg.norm(gp[0] - f['grad_probe_64']) < 1e-10 * np.linalg.norm(f['grad_probe_64'])
