@@ -39,3 +39,50 @@ def test_host_helpers_match_oracle():
     assert np.array_equal(calculate_pad_len([256] * 3, pos, [72, 72]), O.calculate_pad_len([256] * 3, pos, [72, 72]))
     a = get_kernel(1., 0.248, np.array([1., 1., 1.]), (72, 72))
     assert np.array_equal(a, O.get_kernel(1., 0.248, np.array([1., 1., 1.]), (72, 72)))
+
+
+def test_probe_initialisers_match_reference_goldens():
+    """Product host code adorym_amd.util.initialize_probe (aperture_defocus, intensity rescaling) against the values captured
+    from the reference (golden F11), and the CSR / staged form of the rotation adjoint against the oracle's scatter."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import cases
+    from adorym_amd.util import initialize_probe, build_rotation_adjoint_csr, rotation_lookup
+    from oracle import adorym_oracle as O
+    f = np.load(os.path.join(ROOT, 'tests', 'golden', 'F11_c1.npz'))
+    C = cases.C1MINI
+    lm = 1240. / C['energy_ev']
+    for k in range(3):
+        ar, br, dcm, sg = f['pinit_ad%d_args' % k]
+        pr, pi = initialize_probe([16, 16], 'aperture_defocus', aperture_radius=ar, beamstop_radius=br, probe_defocus_cm=dcm,
+                                  lmbda_nm=lm, psize_cm=C['psize_cm'], sign_convention=int(sg))
+        assert np.abs(pr + 1j * pi - f['pinit_ad%d' % k]).max() < 1e-12
+    pm, pp = f['pinit_sup_mag'], f['pinit_sup_phase']
+    for k, (rdt, nf, sg, nm) in enumerate((('intensity', False, 1, 3), ('magnitude', True, 1, 2), ('intensity', False, -1, 1))):
+        init = [pm[:nm], pp[:nm]] if nm > 1 else [pm[0], pp[0]]
+        pr, pi = initialize_probe([16, 16], 'supplied', probe_initial=init, rescale_intensity=True, data_first_angle=f['pinit_data'],
+                                  raw_data_type=rdt, normalize_fft=nf, sign_convention=sg, n_probe_modes=nm)
+        ref = f['pinit_rescale%d' % k]
+        assert np.abs(pr + 1j * pi - ref).max() < 1e-10 * np.abs(ref).max()
+    # rotation adjoint: CSR (+ staged boxes / local offsets) reproduces the oracle's adjoint
+    Y, X, Z = 3, 20, 24
+    coords = rotation_lookup((Y, X, Z), np.float32(0.7))
+    Yp, Xp, pad_x0 = Y + 4, X + 6, 2
+    ptr, src, lsrc, w, boxes = build_rotation_adjoint_csr(coords, (Y, X, Z), Yp, Xp, pad_x0, staged=True)
+    r = np.random.default_rng(0)
+    g_rot = r.standard_normal((Y, X, Z, 2))
+    ref = O.rotate_adj(g_rot, coords, np.float64)
+    flat = np.zeros((Z, Yp, Xp, 2))
+    flat[:, 1:1 + Y, pad_x0:pad_x0 + X] = np.transpose(g_rot, (2, 0, 1, 3))          # [Z][Yp][Xp] with pad_y0 = 1
+    out = np.zeros((Y, X * Z, 2))
+    nbx = (X + 15) // 16
+    for t in range(X * Z):
+        bx, bz = (t // Z) // 16, (t % Z) // 16
+        x0, z0, bw, bh = boxes[bz * nbx + bx]
+        for j in range(ptr[t], ptr[t + 1]):
+            zz, xx = src[j] // (Yp * Xp), src[j] % (Yp * Xp) - pad_x0
+            if bw > 0:
+                assert lsrc[j] == (zz - z0) * bw + (xx - x0) and 0 <= xx - x0 < bw and 0 <= zz - z0 < bh
+            out[:, t] += w[j] * flat[zz, 1:1 + Y, pad_x0 + xx]
+    assert np.abs(out.reshape(Y, X, Z, 2) - ref).max() < 1e-5
