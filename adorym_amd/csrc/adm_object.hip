@@ -381,37 +381,35 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
-// SET: g = regulariser gradient (replaces a zero fill + accumulate when the gradient buffer is being initialised)
+// SET: g = regulariser gradient (replaces a zero fill + accumulate when the gradient buffer is being initialised).
+// One thread per voxel (both channels, float2), threads along z (the fastest axis), blockIdx = (x, y): no integer divisions,
+// every load an 8-byte coalesced access (the y / x neighbours are whole rows one plane / one row away).
 template <bool SET>
-__global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__ x, float* __restrict__ g, int Y, int X, int Z,
+__global__ __launch_bounds__(256) void reg_grad_kernel(const float2* __restrict__ x, float2* __restrict__ g, int Y, int X, int Z,
                                                        float a_d, float a_b, float gamma, float* reg_value) {
-    const size_t n = (size_t)Y * X * Z * 2;
     const float invV = 1.0f / (float)((size_t)Y * X * Z);
     float val = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i & 1);
-        size_t vox = i >> 1;
-        const int z = (int)(vox % Z);
-        vox /= Z;
-        const int xx = (int)(vox % X);
-        const int y = (int)(vox / X);
-        const float v = x[i];
-        float gr = 0.f;
-        const float al = c ? a_b : a_d;
-        if (al != 0.f) { gr += al * sgn(v) * invV; val += al * fabsf(v) * invV; }
+    const int xx = blockIdx.x, y = blockIdx.y;
+    const size_t sx = (size_t)Z, sy = (size_t)Z * X;
+    const size_t row = (size_t)y * sy + (size_t)xx * sx;
+    const size_t row_xm = (size_t)y * sy + (size_t)((xx + X - 1) % X) * sx, row_xp = (size_t)y * sy + (size_t)((xx + 1) % X) * sx;
+    const size_t row_ym = (size_t)((y + Y - 1) % Y) * sy + (size_t)xx * sx, row_yp = (size_t)((y + 1) % Y) * sy + (size_t)xx * sx;
+    for (int z = threadIdx.x; z < Z; z += blockDim.x) {
+        const float2 v = x[row + z];
+        float2 gr = make_float2(0.f, 0.f);
+        if (a_d != 0.f) { gr.x += a_d * sgn(v.x) * invV; val += a_d * fabsf(v.x) * invV; }
+        if (a_b != 0.f) { gr.y += a_b * sgn(v.y) * invV; val += a_b * fabsf(v.y) * invV; }
         if (gamma != 0.f) {
-            const size_t sz = 2, sx = 2 * (size_t)Z, sy = 2 * (size_t)Z * X;
-            const float zm = x[i - (size_t)z * sz + (size_t)((z + Z - 1) % Z) * sz];
-            const float zp = x[i - (size_t)z * sz + (size_t)((z + 1) % Z) * sz];
-            const float xm = x[i - (size_t)xx * sx + (size_t)((xx + X - 1) % X) * sx];
-            const float xp = x[i - (size_t)xx * sx + (size_t)((xx + 1) % X) * sx];
-            const float ym = x[i - (size_t)y * sy + (size_t)((y + Y - 1) % Y) * sy];
-            const float yp = x[i - (size_t)y * sy + (size_t)((y + 1) % Y) * sy];
-            gr += gamma * invV * ((sgn(v - zp) - sgn(zm - v)) + (sgn(v - xp) - sgn(xm - v)) + (sgn(v - yp) - sgn(ym - v)));
-            val += gamma * invV * (fabsf(zm - v) + fabsf(xm - v) + fabsf(ym - v));
+            const float2 zm = x[row + (z + Z - 1) % Z], zp = x[row + (z + 1) % Z];
+            const float2 xm = x[row_xm + z], xp = x[row_xp + z];
+            const float2 ym = x[row_ym + z], yp = x[row_yp + z];
+            gr.x += gamma * invV * ((sgn(v.x - zp.x) - sgn(zm.x - v.x)) + (sgn(v.x - xp.x) - sgn(xm.x - v.x)) + (sgn(v.x - yp.x) - sgn(ym.x - v.x)));
+            gr.y += gamma * invV * ((sgn(v.y - zp.y) - sgn(zm.y - v.y)) + (sgn(v.y - xp.y) - sgn(xm.y - v.y)) + (sgn(v.y - yp.y) - sgn(ym.y - v.y)));
+            val += gamma * invV * (fabsf(zm.x - v.x) + fabsf(xm.x - v.x) + fabsf(ym.x - v.x));
+            val += gamma * invV * (fabsf(zm.y - v.y) + fabsf(xm.y - v.y) + fabsf(ym.y - v.y));
         }
-        if (SET) g[i] = gr;
-        else g[i] += gr;
+        if (SET) g[row + z] = gr;
+        else { float2 o = g[row + z]; o.x += gr.x; o.y += gr.y; g[row + z] = o; }
     }
     if (reg_value) {
         __shared__ float red[4];
@@ -419,7 +417,11 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float* __restrict__
         for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(reg_value, red[0] + red[1] + red[2] + red[3]);
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+            atomicAdd(reg_value, t);
+        }
     }
 }
 
@@ -791,11 +793,13 @@ static int reg_grad_impl(adm_plan* plan, const float* obj, float alpha_d, float 
         ADM_HIP(hipGetLastError());
         return ADM_OK;
     }
+    const int nt = d.obj_z >= 192 ? 256 : (d.obj_z >= 96 ? 128 : 64);
+    const dim3 grid(d.obj_x, d.obj_y);
     if (set)
-        hipLaunchKernelGGL(reg_grad_kernel<true>, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x, d.obj_z,
+        hipLaunchKernelGGL(reg_grad_kernel<true>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
                            alpha_d, alpha_b, gamma, reg_value);
     else
-        hipLaunchKernelGGL(reg_grad_kernel<false>, dim3(stream_grid(n)), dim3(256), 0, st, obj, grad_obj, d.obj_y, d.obj_x, d.obj_z,
+        hipLaunchKernelGGL(reg_grad_kernel<false>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
                            alpha_d, alpha_b, gamma, reg_value);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
