@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= g.Xp || r >= g.nrows) return;
     const int y = g.row0 + r;
-    unsigned* out = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
+    // structure-of-arrays: entry c of pixel (r, x) at cover[(c * nrows + r) * Xp + x], so that the lanes of a wave
+    // (consecutive x) read consecutive words
+    const size_t cplane = (size_t)g.nrows * g.Xp;
+    unsigned* out = cover + (size_t)r * g.Xp + x;
     int cnt = 0;
 #ifdef ADM_GTILE_PIXEL
     const unsigned per_pos = (unsigned)g.n_steps * g.P * g.P;
@@ -308,9 +311,9 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
             if (cnt < ADM_MAXCOVER) {
                 const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
 #ifdef ADM_GTILE_PIXEL
-                out[1 + cnt] = (unsigned)b * per_pos + (unsigned)(row * g.P + col);
+                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + (unsigned)(row * g.P + col);
 #else
-                out[1 + cnt] = (unsigned)b * per_pos + (unsigned)((col / g.R2) * g.NT + tid);
+                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + (unsigned)((col / g.R2) * g.NT + tid);
 #endif
             }
             ++cnt;
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
     if (x >= g.Xp || r >= g.nrows) return;
-    const unsigned* cv = cover + ((size_t)r * g.Xp + x) * (ADM_MAXCOVER + 1);
+    const size_t cplane = (size_t)g.nrows * g.Xp;
+    const unsigned* cv = cover + (size_t)r * g.Xp + x;
     const int cnt = (int)cv[0];
 #ifdef ADM_GTILE_PIXEL
     const size_t step_stride = (size_t)g.P * g.P;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     for (int i = 0; i < TA_STEPS; ++i) acc[i] = make_float2(0.f, 0.f);
     if (nst == TA_STEPS) {
         for (int c = 0; c < cnt; ++c) {
-            const float2* src = gtile + (size_t)cv[1 + c] + (size_t)st0 * step_stride;
+            const float2* src = gtile + (size_t)cv[(size_t)(1 + c) * cplane] + (size_t)st0 * step_stride;
             float2 v[TA_STEPS];
 #pragma unroll
             for (int i = 0; i < TA_STEPS; ++i) v[i] = src[(size_t)i * step_stride];
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
         }
     } else {
         for (int c = 0; c < cnt; ++c) {
-            const float2* src = gtile + (size_t)cv[1 + c] + (size_t)st0 * step_stride;
+            const float2* src = gtile + (size_t)cv[(size_t)(1 + c) * cplane] + (size_t)st0 * step_stride;
 #pragma unroll
             for (int i = 0; i < TA_STEPS; ++i)
                 if (i < nst) { const float2 v = src[(size_t)i * step_stride]; acc[i].x += v.x; acc[i].y += v.y; }
