@@ -323,10 +323,12 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     out[0] = (unsigned)cnt;
 }
 
-// One thread owns one padded pixel and TA_STEPS consecutive modulation steps: for every covering tile it issues
+// One thread owns one padded pixel and TA_STEPS consecutive modulation steps (4: measured best of 2/4/8/16): for every covering tile it issues
 // TA_STEPS independent 8-B loads (stride = one step of that tile) before touching the accumulators, so a wave keeps
 // TA_STEPS x 64 loads in flight instead of one dependent load per iteration.
-#define TA_STEPS 8
+#ifndef TA_STEPS
+#define TA_STEPS 4
+#endif
 __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
                                                               float2* __restrict__ grad_rot, TileGeom g) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
