@@ -461,3 +461,66 @@ def test_beamstop_vs_reference(A, ctx):
         err = np.linalg.norm(mine - r64) / np.linalg.norm(r64)
         err_ref = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
         assert err < max(1e-4, 3 * err_ref), (key, err, err_ref)
+
+
+def test_config1_full_size_minibatch_vs_oracle(A, ctx):
+    """BASELINE config 1 at its full size (618 x 606 x 1 real_imag object, 5 incoherent modes, minibatch 35; P = 64 as the
+    data file is absent): loss and gradients w.r.t. object, probe modes and sub-pixel positions against the fp64 oracle."""
+    r = cases.rng(6181)
+    Y, X, P, M, B = 618, 606, 64, 5, 35
+    energy, psize = 8801.121930115722, 1.32789376566526e-06
+    pos = np.stack([r.integers(-20, Y - 44, B), r.integers(-20, X - 44, B)], 1).astype(float) + r.uniform(-0.4, 0.4, (B, 2))
+    pos_int = np.round(pos).astype(int)
+    mag = 1 - 0.3 * r.uniform(size=(Y, X, 1)); ph = 0.6 * r.uniform(-1, 1, (Y, X, 1))
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    probe = (r.standard_normal((M, P, P)) + 1j * r.standard_normal((M, P, P))) * np.array([1, .5, .3, .2, .1])[:, None, None]
+    phys = O.Physics((P, P), energy, psize, free_prop_cm='inf', unknown_type='real_imag')
+    tiles, _ = O.extract_tiles(obj, pos_int, (P, P), 'real_imag')
+    shifts = pos - pos_int
+    meas = O.predict(tiles, probe, phys, 'float64')[0] * (1 + 0.2 * r.uniform(-1, 1, (B, P, P)))
+    loss, pred, gt, gp, gs = O.forward_adjoint_tiles(tiles, probe, meas, phys, 'float64', shifts=shifts)
+    g_ref = O.scatter_tiles_adj(gt, pos_int, obj.shape)
+    eng = A.MultisliceEngine(ctx, (Y, X, 1), (P, P), pos_int, energy, psize, free_prop_cm='inf', n_probe_modes=M, max_batch=B,
+                             unknown_type='real_imag')
+    eng.set_batch(pos_int, meas.astype(np.float32))
+    obj_d = ctx.array(obj.astype(np.float32))
+    eng.rotate(obj_d, None, None)
+    probe_d = ctx.array(np.stack([probe.real, probe.imag], -1).astype(np.float32))
+    sh_d = ctx.array(shifts.astype(np.float32))
+    gpd, gsd, g = ctx.zeros(probe_d.shape), ctx.zeros(sh_d.shape), ctx.zeros(obj_d.shape)
+    eng.multislice(probe_d, grad_probe=gpd, shifts=sh_d, grad_shifts=gsd)
+    eng.rotate_adjoint(g, None, None)
+    assert abs(eng.loss() - loss) < 2e-5 * abs(loss)
+    gph = gpd.get()
+    for mine, ref, tol in ((g.get(), g_ref, 1e-4), (gph[..., 0] + 1j * gph[..., 1], gp, 1e-4), (gsd.get(), gs, 2e-4)):
+        assert np.linalg.norm(mine - ref) < tol * np.linalg.norm(ref), np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+
+
+def test_config5_full_size_vs_oracle(A, ctx):
+    """BASELINE config 5 at its full size (512 x 512, 4 distances): loss, prediction and gradients w.r.t. the object, the
+    distances and the affine matrices against the fp64 oracle."""
+    from adorym_amd.holography import HolographyEngine
+    r = cases.rng(5125)
+    N, nd = 512, 4
+    energy, psize = 17050., 1e-4
+    mag = 1 - 0.2 * cases.smooth_field((N, N, 1), 5126); ph = 0.5 * cases.smooth_field((N, N, 1), 5127)
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    dists = np.array([40., 60., 90., 140.])
+    aff = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1]) + 0.01 * r.uniform(-1, 1, (nd, 2, 3))
+    data = (1 + 0.1 * cases.smooth_field((nd, N, N), 5128)) ** 2
+    loss, pred, _, g_obj, _, g_d, g_a = O.holo_forward_adjoint(obj, np.ones((N, N), complex), dists, aff, data, energy, psize)
+    # the affine-matrix gradient is ill-conditioned in fp32 at this size (sampling coordinates up to 512 carry 6e-5 px of
+    # rounding, and the sum over 262 144 pixels cancels): the oracle evaluated in fp32 sets the scale (3x rule)
+    g_a32 = O.holo_forward_adjoint(obj.astype(np.float32), np.ones((N, N), np.complex64), dists, aff, data, energy, psize,
+                                   dtype='float32')[6]
+    e_a32 = np.linalg.norm(g_a32 - g_a) / np.linalg.norm(g_a)
+    eng = HolographyEngine(ctx, (N, N), nd, energy, psize)
+    obj_d = ctx.array(obj.astype(np.float32))
+    probe_d = ctx.array(np.stack([np.ones((N, N)), np.zeros((N, N))], -1).astype(np.float32))
+    g, gd, ga = ctx.zeros(obj_d.shape), ctx.zeros((nd,)), ctx.zeros((nd, 2, 3))
+    eng.forward_adjoint(obj_d, probe_d, ctx.array(dists.astype(np.float32)), ctx.array(data.astype(np.float32)),
+                        affine=ctx.array(aff.astype(np.float32)), grad_obj=g, grad_dists=gd, grad_affine=ga, want_pred=True)
+    assert abs(eng.loss() - loss) < 5e-5 * abs(loss)
+    assert np.linalg.norm(eng.pred() - pred) < 3e-6 * np.linalg.norm(pred)
+    for mine, ref, tol in ((g.get(), g_obj, 2e-4), (gd.get(), g_d, 2e-3), (ga.get(), g_a, max(2e-3, 3 * e_a32))):
+        assert np.linalg.norm(mine - ref) < tol * np.linalg.norm(ref), np.linalg.norm(mine - ref) / np.linalg.norm(ref)
