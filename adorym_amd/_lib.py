@@ -67,6 +67,7 @@ SIGNATURES = {
     'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
     'adm_rotate_adj_staged': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
+    'adm_plan_set_lean_min_batch': (_I, [_VP, _I]),
     'adm_multislice_fwd_adj_pp': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_probe_shift': (_I, [_VP, _VP, _VP, _VP, _I, _VP]),
     'adm_probe_shift_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),

@@ -203,6 +203,10 @@ static int upload_c(adm_ctx* ctx, const float* re, const float* im, size_t n, fl
     return ADM_OK;
 }
 
+// default of adm_plan_set_lean_min_batch: 0 = the two-workgroups-per-CU kernel (adm_ms_lean.hip) is opt-in; as measured in
+// round 2 (profiles/README.md) it does not beat the latency-oriented kernel at any batch size yet
+#define ADM_LEAN_MIN_BATCH_DEFAULT 0
+
 extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out) {
     if (!ctx || !desc || !out) return fail(ADM_ERR_INVALID, "adm_plan_create: null argument");
     const adm_plan_desc& d = *desc;
@@ -237,6 +241,18 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->reg_stats = nullptr;
     p->det_weight_dev = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
+    {   // the throughput kernel reads H from a table folded along kx: exact mirror symmetry required
+        const int N = d.probe_x;
+        bool sym = true;
+        for (int ky = 0; ky < d.probe_y && sym; ++ky)
+            for (int kx = 1; kx < N; ++kx) {
+                const size_t i = (size_t)ky * N + kx, j = (size_t)ky * N + (N - kx);
+                if (d.h_re[i] != d.h_re[j] || d.h_im[i] != d.h_im[j]) { sym = false; break; }
+                if (d.det_mode == ADM_DET_FRESNEL && (d.hfree_re[i] != d.hfree_re[j] || d.hfree_im[i] != d.hfree_im[j])) { sym = false; break; }
+            }
+        p->h_sym = sym;
+        p->lean_min_batch = ADM_LEAN_MIN_BATCH_DEFAULT;
+    }
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
     if (!rc) {
@@ -364,7 +380,16 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
         if (grad_probe && want_grad)
             ADM_HIP(hipMemsetAsync(grad_probe, 0, (size_t)batch * p.gprobe_bstride * sizeof(float2), plan->ctx->stream));
     }
-    ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    const bool lean = plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
+                      d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
+    if (lean) ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
+    else ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch) {
+    if (!plan || min_batch < 0) return fail(ADM_ERR_INVALID, "adm_plan_set_lean_min_batch: bad argument");
+    plan->lean_min_batch = min_batch;
     return ADM_OK;
 }
 

@@ -29,6 +29,8 @@ struct adm_plan {
     float2* twid_dev;      // [Px] exp(-2 pi i j / N)
     float* det_weight_dev; // [Py*Px] beamstop weights or nullptr (adm_plan_set_detector_mask)
     float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
+    bool h_sym;            // H(ky, kx) == H(ky, N - kx) for the slice and detector kernels (every get_kernel() output)
+    int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
 };
 
 namespace adm {
@@ -85,6 +87,8 @@ size_t ws_off_cover(const adm_plan* plan, int batch);
 size_t ws_off_det(const adm_plan* plan, int batch);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
+bool ms_lean_supported(int n);
+hipError_t ms_lean_launch(int n, const MsParams& p, int batch, hipStream_t st);
 hipError_t shift_launch(int n, const ShiftParams& q, int batch, bool adjoint, hipStream_t st);
 }  // namespace adm
 

@@ -5,8 +5,8 @@
 // (adorym/wrappers.py:322).  Math: SURVEY.md section 3.4.
 //
 // Design (gfx950):
-//   * the complex Py x Px wavefield of one position lives in LDS (pitch P+1 complex => both
-//     row-wise and column-wise lane mappings are bank-conflict-free for ds_read/write_b64);
+//   * the complex Py x Px wavefield of one position lives in LDS, in the permuted image of Layout<> (adm_ms_math.h;
+//     P = 72: pitch 73 with the nine residues of a row 65 elements apart, found by tools/lds/lds_layout_search.c);
 //   * every 1-D transform of length N = R1*R2 is two register-resident radix passes; a wave owns
 //     LPW = 64/G whole lines (G = max(R1,R2) threads per line), so the R1 -> R2 exchange is
 //     wave-local (no workgroup barrier); only the row<->column ownership change needs __syncthreads:
@@ -24,81 +24,28 @@
 #include <hip/hip_runtime.h>
 #include "adm_common.h"
 #include "adm_fft.h"
+#include "adm_ms_math.h"
+#include <type_traits>
 
 namespace adm {
 
-#ifdef ADM_ABL_NOBARRIER
-#define __syncthreads() do { } while (0)
-#endif
-#ifdef ADM_SAFE_SYNC
-#define WAVE_SYNC() __syncthreads()
+#ifdef ADM_STAMPS
+// diagnostic build only (tools/stamps.py): per-wave shader-clock stamps of one slice step of workgroup 0
+__device__ unsigned long long g_stamps[16 * 16];
+__device__ int g_stamp_on;
+#define ADM_STAMP_ON(cond) do { stamp_on = (cond); } while (0)
+#define ADM_STAMP(i) do { if (stamp_on && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ADM_STAMP_DECL bool stamp_on = false
 #else
-// LDS operations of one wave execute in order; this only stops the compiler from reordering.
-#define WAVE_SYNC()                                        \
-    do {                                                   \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                   \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
+#define ADM_STAMP_ON(cond) do { } while (0)
+#define ADM_STAMP(i) do { } while (0)
+#define ADM_STAMP_DECL
 #endif
 
-// LDS layout of the P x P field: element (y, x) lives at  y*Q + posx(x),  posx(x) = (x / R2)*PA + (x % R2)*PB.
-// (PA, PB, Q) = (R2, 1, N+1) is the plain padded row-major image; other triples permute the elements
-// inside a row to spread the stride-R2 accesses of the radix passes over the LDS banks (chosen by an
-// exhaustive conflict count over all wave/lane patterns of the kernel, tools/lds_layout_search.py).
-template <int N, int R1, int R2> struct Layout {
-    static constexpr int PA = R2, PB = 1, Q = N + 1;
-};
-#ifndef ADM_PLAIN_LAYOUT
-template <> struct Layout<72, 8, 9> {
-    static constexpr int PA = 2, PB = 9, Q = 113;
-};
-#endif
 
-template <int N, int R1, int R2> struct Geo {
-    static constexpr int G = (R1 > R2) ? R1 : R2;      // threads per line
-    static constexpr int LPW = 64 / G;                 // lines per wave
-    static constexpr int NWAVES = (N + LPW - 1) / LPW;
-    static constexpr int NT = NWAVES * 64;
-    static constexpr int PA = Layout<N, R1, R2>::PA, PB = Layout<N, R1, R2>::PB, Q = Layout<N, R1, R2>::Q;
-    static constexpr int FLD = N * Q;                  // complex elements of one LDS field image
-    // strides (in complex elements) of the two access patterns in the two roles
-    static constexpr int ROW_P1_K = PA, ROW_P1_T = PB;           // element k*R2 + t of a row
-    static constexpr int ROW_P2_K = PB, ROW_P2_T = PA;           // element t*R2 + k of a row
-    static constexpr int COL_P1_K = R2 * Q, COL_P1_T = Q;        // element k*R2 + t of a column
-    static constexpr int COL_P2_K = Q, COL_P2_T = R2 * Q;        // element t*R2 + k of a column
-    static __device__ __forceinline__ int posx(int x) { return (x / R2) * PA + (x % R2) * PB; }
-};
-
-// ---- one line transform pass set (wave-local) ------------------------------------------------
-// `base` points at the line's origin; element index -> address through the (KS, TS) strides above.
-
-template <int R, int KS> __device__ __forceinline__ void ld_line(cf (&a)[R], const cf* base) {
-#ifndef ADM_ABL_NOLDS
-#pragma unroll
-    for (int k = 0; k < R; ++k) a[k] = base[k * KS];
-#else
-#pragma unroll
-    for (int k = 0; k < R; ++k) asm volatile("" : "+v"(a[k].x), "+v"(a[k].y));
-#endif
-}
-template <int R, int KS> __device__ __forceinline__ void st_line(const cf (&a)[R], cf* base) {
-#ifndef ADM_ABL_NOLDS
-#pragma unroll
-    for (int k = 0; k < R; ++k) base[k * KS] = a[k];
-#else
-#pragma unroll
-    for (int k = 0; k < R; ++k) asm volatile("" :: "v"(a[k].x), "v"(a[k].y));
-#endif
-}
 // pass 1 forward: a[n1] holds x[n1*R2 + t]; radix-R1 then twiddle W_N^(t*k1)
-#ifdef ADM_ABL_NOMATH
-#define ADM_DFT(R, INV, x) do { } while (0)
-#else
-#define ADM_DFT(R, INV, x) Dft<R, INV>::run(x)
-#endif
 template <int R1> __device__ __forceinline__ void p1_fwd(cf (&a)[R1], const cf (&tw)[R1]) {
-    ADM_DFT(R1, false, a);
+    Dft<R1, false>::run(a);
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmul(a[k], tw[k]);
 }
@@ -106,16 +53,12 @@ template <int R1> __device__ __forceinline__ void p1_fwd(cf (&a)[R1], const cf (
 template <int R1> __device__ __forceinline__ void p1_inv(cf (&a)[R1], const cf (&tw)[R1]) {
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmulc(a[k], tw[k]);
-    ADM_DFT(R1, true, a);
+    Dft<R1, true>::run(a);
 }
-
-// position p = k1*R2 + k2 of a scrambled spectrum holds frequency k1 + R1*k2
-template <int R1, int R2> __device__ __forceinline__ int freq_of_pos(int p) { return p / R2 + R1 * (p % R2); }
 
 template <int N, int R1, int R2> struct Ctx {
     using GE = Geo<N, R1, R2>;
     cf* fld;          // LDS field image
-    const cf* hl;     // LDS image (same layout) of H / N^2 in scrambled-frequency order
     int line, t;      // line owned in both roles (row for x passes, column for y passes), thread in line
     bool act1, act2;  // pass-1 role (t < R2) / pass-2 role (t < R1) active
     cf tw[R1];        // W_N^(t*k1)
@@ -135,7 +78,7 @@ __device__ __forceinline__ void x_fwd(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
-        ADM_DFT(R2, false, b);
+        Dft<R2, false>::run(b);
         st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
 }
@@ -146,7 +89,7 @@ __device__ __forceinline__ void x_inv(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
-        ADM_DFT(R2, true, b);
+        Dft<R2, true>::run(b);
         st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
     WAVE_SYNC();
@@ -182,30 +125,35 @@ __device__ __forceinline__ void y_inv_p1(Ctx<N, R1, R2>& c) {
 // psi <- IFFT2( Hmul * FFT2(psi) ), psi in registers `a` (row role) on entry and exit.
 // CONJ: multiply by conj(H) (adjoint).  H already carries the 1/N^2 of the inverse.  The thread <-> (ky, kx)
 // map is static, so H is read from an LDS image with the same addressing as the field element it multiplies
-// (HLDS) or, for the one-off detector-plane Fresnel kernel, from registers `hs`.
-template <int N, int R1, int R2, bool CONJ, bool HLDS>
-__device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2]) {
+// map is static, so H is read from registers `hs` (the slice kernel, or the one-off detector-plane Fresnel kernel).
+//
+// `hook(P<i>)`, i = 0..3, runs at four points spread over the convolution (after the x passes, before and after the
+// spectral multiply, after the second barrier).  The sweeps issue their global loads / stores there, a few per point:
+// issued in one burst around the slice modulation, the 16-24 vector-memory instructions per thread of all 11 waves
+// queue up in the CU's address unit and that burst alone cost ~25 % of a slice step (tools/stamps.py, round 2).
+template <int I> using P = std::integral_constant<int, I>;
+struct NoHook { template <class T> __device__ __forceinline__ void operator()(T) const {} };
+template <int N, int R1, int R2, bool CONJ, class Hook = NoHook>
+__device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], Hook hook = Hook()) {
     using GE = Geo<N, R1, R2>;
     x_fwd<N, R1, R2>(c, a);
+    hook(P<0>());
     __syncthreads();
     y_fwd_p1<N, R1, R2>(c);
+    hook(P<1>());
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
-        ADM_DFT(R2, false, b);
-        if (HLDS) {
-            const cf* hp = c.hl + c.col_p2;
+        Dft<R2, false>::run(b);
 #pragma unroll
-            for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hp[k * GE::COL_P2_K]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hs[k]);
-        }
-        ADM_DFT(R2, true, b);
+        for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hs[k]);
+        Dft<R2, true>::run(b);
         st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
+    hook(P<2>());
     y_inv_p1<N, R1, R2>(c);
     __syncthreads();
+    hook(P<3>());
     x_inv<N, R1, R2>(c, a);
 }
 
@@ -220,7 +168,7 @@ __device__ __forceinline__ void fft2_to_regs(Ctx<N, R1, R2>& c, cf (&a)[R1], cf 
     y_fwd_p1<N, R1, R2>(c);
     if (c.act2) {
         ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
-        ADM_DFT(R2, false, b);
+        Dft<R2, false>::run(b);
     }
 }
 // the matching unnormalised inverse, from registers b[k2] back to real-space registers a
@@ -228,7 +176,7 @@ template <int N, int R1, int R2>
 __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
     if (c.act2) {
-        ADM_DFT(R2, true, b);
+        Dft<R2, true>::run(b);
         st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
     y_inv_p1<N, R1, R2>(c);
@@ -236,95 +184,7 @@ __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], 
     x_inv<N, R1, R2>(c, a);
 }
 
-__device__ __forceinline__ cf conjf2(cf a) { return make_float2(a.x, -a.y); }
-
-// Per-pixel loss term and the factor g with dL/dPsi = g * Psi (adorym/forward_model.py:88-103):
-//   LSQ      term = (|Psi| - t)^2,                         g = grad_scale * (|Psi| - t) / |Psi|     (0 at |Psi| = 0)
-//   Poisson  term = |Psi|^2 pm - t pm log(|Psi|^2 pm),     g = grad_scale * pm * (1 - t / |Psi|^2)
-// grad_scale = 2 / (minibatch * Py * Px) in both cases.
-__device__ __forceinline__ float loss_term(float mag, float t, const MsParams& p, float& g) {
-    if (p.loss_type == 0) {
-        const float diff = mag - t;
-        g = (mag > 0.f) ? p.grad_scale * diff / mag : 0.f;
-        return diff * diff;
-    }
-    const float inten = mag * mag;
-    g = p.grad_scale * p.poisson_mult * (1.f - t / inten);
-    return inten * p.poisson_mult - t * p.poisson_mult * logf(inten * p.poisson_mult);
-}
-
-// Branch-free single-precision sin/cos: 3-term Cody-Waite reduction by pi/2 (exact product steps via
-// fma, good for |x| < ~1e5) + Cephes minimax polynomials on [-pi/4, pi/4] (~1 ulp).  ocml's sincosf
-// is equally accurate but costs several hundred instructions and dozens of branches per call, which
-// made the slice modulation as expensive as the FFTs.
-__device__ __forceinline__ void sincos_fast(float x, float& sn, float& cs) {
-    const float q = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(q, -1.57079601287841796875f, x);
-    r = fmaf(q, -3.1391647326017846353e-7f, r);
-    r = fmaf(q, -5.3903025299577647655e-15f, r);
-    const int iq = (int)q;
-    const float r2 = r * r;
-    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    sp = fmaf(sp * r2, r, r);
-    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    cp = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
-    const bool swap = (iq & 1) != 0;
-    const float s0 = swap ? cp : sp;
-    const float c0 = swap ? sp : cp;
-    sn = (iq & 2) ? -s0 : s0;
-    cs = ((iq + 1) & 2) ? -c0 : c0;
-}
-// exp(x) ~1 ulp: 2^(x*log2e) with the product's rounding error and the low part of log2(e)
-// re-injected to first order; v_exp_f32 itself is a 1-ulp instruction.
-__device__ __forceinline__ float exp_fast(float x) {
-    const float L2E = 1.44269502162933349609375f;
-    const float t = x * L2E;
-    float e = fmaf(x, L2E, -t);
-    e = fmaf(x, 1.925963033500e-8f, e);
-    const float r = __builtin_amdgcn_exp2f(t);
-    return fmaf(r, e * 0.69314718055994530942f, r);
-}
-
-// exp(-k1*beta) * (cos, sin)(-sigma*k1*delta)      (adorym/wrappers.py:600-608)
-__device__ __forceinline__ cf modulator(float2 db, float k1, float sigma) {
-    const float e = exp_fast(-k1 * db.y);
-    const float phi = -sigma * k1 * db.x;
-    float sn, cs;
-#ifndef ADM_NO_SMALL_PHASE_PATH
-    // X-ray phase shifts per slice are tiny (k1*delta ~ 1e-2): when every lane of the wave is inside
-    // [-pi/4, pi/4] the range reduction and quadrant selection are skipped (wave-uniform branch, same
-    // polynomials => bit-identical results to the general path).
-    if (__builtin_amdgcn_ballot_w64(fabsf(phi) > 0.78539816f) == 0) {
-        const float r2 = phi * phi;
-        float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-        sp = fmaf(sp, r2, -1.6666654611e-1f);
-        sn = fmaf(sp * r2, phi, phi);
-        float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-        cp = fmaf(cp, r2, 4.166664568298827e-2f);
-        cs = fmaf(cp * r2, r2, fmaf(r2, -0.5f, 1.0f));
-    } else
-#endif
-    {
-        sincos_fast(phi, sn, cs);
-    }
-    return make_float2(e * cs, e * sn);
-}
-
 // ---- building blocks of the kernel body -------------------------------------------------------------------------
-__device__ __forceinline__ float loss_term_nz(float mag, float t, const MsParams& p, float& g) {
-    // multi-mode variant: pred = sqrt(sum_m |Psi_m|^2); like the reference there is no guard at pred = 0
-    if (p.loss_type == 0) {
-        const float diff = mag - t;
-        g = p.grad_scale * diff / mag;
-        return diff * diff;
-    }
-    const float inten = mag * mag;
-    g = p.grad_scale * p.poisson_mult * (1.f - t / inten);
-    return inten * p.poisson_mult - t * p.poisson_mult * logf(inten * p.poisson_mult);
-}
-
 template <int N, int R1, int R2>
 __device__ __forceinline__ void load_probe(const Ctx<N, R1, R2>& c, cf (&a)[R1], const float2* __restrict__ probe) {
 #pragma unroll
@@ -388,39 +248,33 @@ template <int N, int R1, int R2, bool BIN1, bool RI>
 __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, float2* stash,
                                           const float2* tile_base, size_t slice_stride, bool do_grad) {
     using GE = Geo<N, R1, R2>;
-#ifdef ADM_H_IN_LDS
-    constexpr bool kHLds = true;
-#else
-    constexpr bool kHLds = false;
-#endif
+    const int tid = threadIdx.x;
+    ADM_STAMP_DECL;
     float2 db[R1];
     if (c.act1) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, 0, p.binning, p.Z);
     for (int step = 0; step < p.n_steps; ++step) {
+        ADM_STAMP_ON(blockIdx.x == 0 && step == 100);
+        ADM_STAMP(0);
         if (c.act1) {
+            if (RI) {
+                // the slice IS the complex transmission; its gradient needs the PRE-modulation field
+                if (do_grad) ws_store<R1>(stash + (size_t)step * R1 * GE::NT, GE::NT, tid, a);
 #pragma unroll
-            for (int k = 0; k < R1; ++k) {
-                if (RI) {
-                    // the slice IS the complex transmission; its gradient needs the PRE-modulation field
-                    if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
-                    a[k] = cmul(a[k], db[k]);
-                } else {
-#ifndef ADM_ABL_NOMOD
-                    a[k] = cmul(a[k], modulator(db[k], p.k1, p.sigma));
-#else
-                    a[k] = cmul(a[k], db[k]);
-#endif
-#ifndef ADM_ABL_NOSTASH
-                    if (do_grad) stash[(size_t)(step * R1 + k) * GE::NT] = a[k];
-#endif
-                }
+                for (int k = 0; k < R1; ++k) a[k] = cmul(a[k], db[k]);
+            } else {
+                modulate<R1, false>(a, db, p.k1, p.sigma);
+                ADM_STAMP(1);
+                if (do_grad) ws_store<R1>(stash + (size_t)step * R1 * GE::NT, GE::NT, tid, a);
             }
+            ADM_STAMP(2);
             // next step's tile slice is requested before the propagation so its latency is hidden
             if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
         }
-#ifndef ADM_ABL_NOCONV
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false, kHLds>(c, a, hs);
-#endif
+        ADM_STAMP(3);
+        if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, hs);
+        ADM_STAMP(4);
     }
+    ADM_STAMP_ON(false);
 }
 
 // ACC: add to the tile gradient already stored by a previous probe mode instead of overwriting it
@@ -428,59 +282,49 @@ template <int N, int R1, int R2, bool BIN1, bool ACC, bool RI>
 __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, const float2* stash,
                                           float2* gtile, const float2* tile_base, size_t slice_stride) {
     using GE = Geo<N, R1, R2>;
-#ifdef ADM_H_IN_LDS
-    constexpr bool kHLds = true;
-#else
-    constexpr bool kHLds = false;
-#endif
     const float sk1 = p.sigma * p.k1;
+    const int tid = threadIdx.x;
+    ADM_STAMP_DECL;
     float2 db[R1];
     cf psi[R1];
     if (c.act1) {
         load_db<R1, R2, BIN1>(db, tile_base, slice_stride, p.n_steps - 1, p.binning, p.Z);
-#pragma unroll
-        for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((p.n_steps - 1) * R1 + k) * GE::NT];
+        ws_load<R1>(stash + (size_t)(p.n_steps - 1) * R1 * GE::NT, GE::NT, tid, psi);
     }
     for (int step = p.n_steps - 1; step >= 0; --step) {
+        ADM_STAMP_ON(blockIdx.x == 0 && step == 100);
+        ADM_STAMP(8);
         if (c.act1) {
+            // tile gradient of this modulation step, thread-native layout (coalesced 16-B/lane stores);
+            // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
+            float2 g[R1];
+            float2* grow = gtile + (size_t)step * R1 * GE::NT;
+            if (ACC) ws_load<R1>(grow, GE::NT, tid, g);
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
                 // z = conj(G) * psi'  (delta_beta: psi' is the post-modulation field; real_imag: the stash holds the
                 // pre-modulation field and (d/dre, d/dim) = G * conj(psi) = (Re z, -Im z))
                 const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
                 const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
-                float gd = RI ? zr : sk1 * zi;
-                float gb = RI ? -zi : -p.k1 * zr;
-                // tile gradient of this modulation step, thread-native layout (coalesced 8-B/lane store);
-                // adm_tile_grad_accumulate overlap-adds the tiles afterwards (no atomics in this loop)
-#ifdef ADM_GTILE_PIXEL
-                float2* gq = gtile + (size_t)step * N * N + k * R2;      // pixel-major [step][row][col]; gtile -> (row, t)
-#else
-                float2* gq = gtile + (size_t)(step * R1 + k) * GE::NT;
-#endif
-                if (ACC) { const float2 o = *gq; gd += o.x; gb += o.y; }
-                *gq = make_float2(gd, gb);
-#ifndef ADM_ABL_NOMOD
-                a[k] = cmulc(a[k], RI ? db[k] : modulator(db[k], p.k1, p.sigma));
-#else
-                a[k] = cmulc(a[k], db[k]);
-#endif
+                const float gd = RI ? zr : sk1 * zi;
+                const float gb = RI ? -zi : -p.k1 * zr;
+                g[k] = ACC ? make_float2(g[k].x + gd, g[k].y + gb) : make_float2(gd, gb);
+                if (RI) a[k] = cmulc(a[k], db[k]);
             }
+            ws_store<R1>(grow, GE::NT, tid, g);
+            ADM_STAMP(9);
+            if (!RI) modulate<R1, true>(a, db, p.k1, p.sigma);
+            ADM_STAMP(10);
             if (step > 0) {
                 load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
-#ifndef ADM_ABL_NOSTASH
-#pragma unroll
-                for (int k = 0; k < R1; ++k) psi[k] = stash[(size_t)((step - 1) * R1 + k) * GE::NT];
-#else
-#pragma unroll
-                for (int k = 0; k < R1; ++k) psi[k] = a[k];
-#endif
+                ws_load<R1>(stash + (size_t)(step - 1) * R1 * GE::NT, GE::NT, tid, psi);
             }
         }
-#ifndef ADM_ABL_NOCONV
-        if (step > 0) convolve<N, R1, R2, true, kHLds>(c, a, hs);
-#endif
+        ADM_STAMP(11);
+        if (step > 0) convolve<N, R1, R2, true>(c, a, hs);
+        ADM_STAMP(12);
     }
+    ADM_STAMP_ON(false);
 }
 
 template <int N, int R1, int R2>
@@ -500,7 +344,7 @@ __device__ __forceinline__ void detector_forward(Ctx<N, R1, R2>& c, cf (&a)[R1],
     if (p.det_mode == ADM_DET_FRESNEL_) {
         cf hf[R2];
         load_hfree<N, R1, R2>(hf, p, kx, tc2);
-        convolve<N, R1, R2, false, false>(c, a, hf);
+        convolve<N, R1, R2, false>(c, a, hf);
     } else if (p.det_mode == ADM_DET_FARFIELD_) {
         // Psi = scale * F(psi)  (F forward, or inverse via conjugation when det_inverse)
         if (p.det_inverse) {
@@ -522,7 +366,7 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
     } else if (p.det_mode == ADM_DET_FRESNEL_) {
         cf hf[R2];
         load_hfree<N, R1, R2>(hf, p, kx, tc2);
-        convolve<N, R1, R2, true, false>(c, a, hf);
+        convolve<N, R1, R2, true>(c, a, hf);
     }
 }
 
@@ -532,9 +376,6 @@ template <int N, int R1, int R2, bool BIN1, bool MULTI, bool RI, bool PP>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
-#ifdef ADM_H_IN_LDS
-    __shared__ cf hl[GE::FLD];
-#endif
     __shared__ float red[GE::NWAVES];
 
     const int tid = threadIdx.x;
@@ -542,11 +383,6 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const int li = lane / GE::G;
     Ctx<N, R1, R2> c;
     c.fld = fld;
-#ifdef ADM_H_IN_LDS
-    c.hl = hl;
-#else
-    c.hl = nullptr;
-#endif
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);
@@ -559,12 +395,6 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     c.col_p1 = GE::posx(c.line) + c.t * GE::COL_P1_T;
     c.col_p2 = GE::posx(c.line) + tc2 * GE::COL_P2_T;
     const int b = blockIdx.x;
-#ifdef ADM_SETPRIO
-    // experiment: static wave priorities to break the lockstep of the waves that share a SIMD
-    if (ADM_SETPRIO == 1) { if (wave >= 4 && wave < 8) __builtin_amdgcn_s_setprio(1); else if (wave >= 8) __builtin_amdgcn_s_setprio(2); }
-    if (ADM_SETPRIO == 2) { if (wave >= 6) __builtin_amdgcn_s_setprio(1); }
-    if (ADM_SETPRIO == 3) { if (wave < 4) __builtin_amdgcn_s_setprio(2); else if (wave < 8) __builtin_amdgcn_s_setprio(1); }
-#endif
 
     // ---- static per-thread constants ----
 #pragma unroll
@@ -583,16 +413,6 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         const cf h = p.h[ky * N + kx];
         hs[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
     }
-#ifdef ADM_H_IN_LDS
-    if (c.act2) {
-#pragma unroll
-        for (int k = 0; k < R2; ++k) hl[c.col_p2 + k * GE::COL_P2_K] = hs[k];
-    }
-    __syncthreads();
-    constexpr bool kHLds = true;
-#else
-    constexpr bool kHLds = false;
-#endif
 
     const int2 ps = p.pos[b];
     const int py = ps.x + p.pad_y0, px = ps.y + p.pad_x0;
@@ -600,12 +420,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const size_t slice_stride = (size_t)p.Yp * p.Xp;
     const size_t tile_off = (size_t)(py + c.line) * p.Xp + px + c.t;   // + n1*R2 + slice*slice_stride
     const bool do_grad = (p.want_grad != 0);
-    float2* stash = p.stash + (size_t)b * p.n_modes * p.n_steps * R1 * GE::NT + tid;
-#ifdef ADM_GTILE_PIXEL
-    float2* gtile = p.gtile + (size_t)b * p.n_steps * N * N + c.line * N + c.t;
-#else
-    float2* gtile = p.gtile + (size_t)b * p.n_steps * R1 * GE::NT + tid;
-#endif
+    float2* stash = p.stash + (size_t)b * p.n_modes * p.n_steps * R1 * GE::NT;
+    float2* gtile = p.gtile + (size_t)b * p.n_steps * R1 * GE::NT;
 
     cf a[R1];
     const float2* tile_base = p.obj_rot + tile_off;
@@ -729,6 +545,13 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     }
 }
 
+#ifdef ADM_STAMPS
+}  // namespace adm
+extern "C" int adm_debug_read_stamps(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(adm::g_stamps), bytes < sizeof(adm::g_stamps) ? bytes : sizeof(adm::g_stamps));
+}
+namespace adm {
+#endif
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
     const dim3 g(batch), t(GE::NT);
@@ -761,7 +584,6 @@ __device__ __forceinline__ void init_ctx(Ctx<N, R1, R2>& c, cf* fld, const float
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane / GE::G;
     c.fld = fld;
-    c.hl = nullptr;
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "adm_common.h"
+#include "adm_ms_math.h"
 
 namespace adm {
 
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(256) void rotate_adj_staged_kernel(const float2* __
 // pixel over the positions that cover it: deterministic, no atomics.
 //   cover_build_kernel : per padded pixel (y, x) the list of (position, element) sources
 //   tile_accumulate_kernel : grad_rot[s][y][x] = sum of the sources, for every slice
-// gtile layout per position: [step][k][tid] with pixel (row, col) -> k = col / R2,
-// tid = (row / LPW) * 64 + (row % LPW) * G + col % R2   (the multislice kernel's thread-native order).
+// gtile layout per position: [step] rows of R1 x NT elements, element (k, tid) at ws_elem_offset() (adm_ms_math.h), with
+// pixel (row, col) -> k = col / R2, tid = (row / LPW) * 64 + (row % LPW) * G + col % R2 (the multislice kernel's
+// thread-native order).
 // --------------------------------------------------------------------------------------------
 #define ADM_MAXCOVER 64
 
@@ -299,22 +301,14 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     const size_t cplane = (size_t)g.nrows * g.Xp;
     unsigned* out = cover + (size_t)r * g.Xp + x;
     int cnt = 0;
-#ifdef ADM_GTILE_PIXEL
-    const unsigned per_pos = (unsigned)g.n_steps * g.P * g.P;
-#else
     const unsigned per_pos = (unsigned)g.n_steps * g.R1 * g.NT;
-#endif
     for (int b = 0; b < B; ++b) {
         const int2 p = pos[b];
         const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
         if (row >= 0 && row < g.P && col >= 0 && col < g.P) {
             if (cnt < ADM_MAXCOVER) {
                 const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
-#ifdef ADM_GTILE_PIXEL
-                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + (unsigned)(row * g.P + col);
-#else
-                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + (unsigned)((col / g.R2) * g.NT + tid);
-#endif
+                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + adm::ws_elem_offset(g.R1, g.NT, col / g.R2, tid);
             }
             ++cnt;
         }
@@ -337,11 +331,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     const size_t cplane = (size_t)g.nrows * g.Xp;
     const unsigned* cv = cover + (size_t)r * g.Xp + x;
     const int cnt = (int)cv[0];
-#ifdef ADM_GTILE_PIXEL
-    const size_t step_stride = (size_t)g.P * g.P;
-#else
     const size_t step_stride = (size_t)g.R1 * g.NT;
-#endif
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
     const bool add = (g.row0 + r >= g.add_lo) && (g.row0 + r < g.add_hi);

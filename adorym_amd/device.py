@@ -201,6 +201,10 @@ class Plan(object):
         self.rot_shape = (d.obj_z, d.obj_y + d.pad_y0 + d.pad_y1, d.obj_x + d.pad_x0 + d.pad_x1, 2)
         assert int(np.prod(self.rot_shape)) == ctx.lib.adm_plan_rot_elems(p)
 
+    def set_lean_min_batch(self, n):
+        """Batches of at least n positions use the two-workgroups-per-CU kernel where it applies (0 = never)."""
+        check(self.ctx.lib.adm_plan_set_lean_min_batch(self.handle, int(n)))
+
     def workspace_bytes(self, batch):
         return int(self.ctx.lib.adm_plan_workspace_bytes(self.handle, int(batch)))
 

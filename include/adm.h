@@ -170,6 +170,13 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
                            const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                            float grad_scale, void* workspace, size_t workspace_bytes);
 
+/* Kernel selection.  Two kernels implement adm_multislice_fwd_adj with the same results up to fp32 rounding order: a
+ * latency-oriented one (one workgroup per compute unit; every configuration) and a throughput-oriented one (two
+ * workgroups per compute unit; one probe mode, delta/beta unknowns, binning 1, a transfer function with
+ * H(ky,kx) == H(ky,N-kx), probe 64 or 72).  Batches of at least `min_batch` positions use the second where it applies;
+ * 0 = never (the default: opt-in).  No reference counterpart: a tuning knob of this library. */
+int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch);
+
 /* Same as adm_multislice_fwd_adj with ONE PROBE SET PER POSITION (sub-pixel probe positions, adorym/forward_model.py:
  * 296-311 + 337-375): probes device [batch][n_modes][Py][Px][2]; grad_probes device [batch][n_modes][Py][Px][2] or NULL,
  * OVERWRITTEN with the per-position probe gradients (input of adm_probe_shift_adj). */
