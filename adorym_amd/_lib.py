@@ -52,6 +52,7 @@ SIGNATURES = {
     'adm_host_alloc': (_I, [_VP, _SZ, C.POINTER(_VP)]),
     'adm_host_free': (_I, [_VP, _VP]),
     'adm_d2h_async': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_h2d_async': (_I, [_VP, _VP, _VP, _SZ]),
     'adm_event_sync': (_I, [_VP, _VP]),
     'adm_event_create': (_I, [_VP, C.POINTER(_VP)]),
     'adm_event_destroy': (_I, [_VP, _VP]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     'adm_rotate_adj': (_I, [_VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
     'adm_rotate_adj_staged': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I]),
+    'adm_rotation_csr_scratch_bytes': (_SZ, [_VP]),
+    'adm_rotation_csr_build': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
     'adm_plan_set_lean_min_batch': (_I, [_VP, _I]),
     'adm_multislice_fwd_adj_pp': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),

@@ -161,6 +161,11 @@ extern "C" int adm_d2h_async(adm_ctx* ctx, void* dst, const void* src, size_t by
     if (bytes) ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return ADM_OK;
 }
+extern "C" int adm_h2d_async(adm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || !dst || !src) return fail(ADM_ERR_INVALID, "adm_h2d_async: null argument");
+    if (bytes) ADM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ADM_OK;
+}
 extern "C" int adm_event_sync(adm_ctx* ctx, void* ev) {
     if (!ev) return fail(ADM_ERR_INVALID, "adm_event_sync: null argument");
     ADM_HIP(hipEventSynchronize((hipEvent_t)ev));

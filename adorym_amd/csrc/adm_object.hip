@@ -25,6 +25,7 @@ struct Bilin {
 };
 
 __device__ __forceinline__ Bilin make_bilin(const uint16_t* coords, int xr, int zr, int X, int Z) {
+#pragma clang fp contract(off)      // torch / NumPy evaluate this pipeline without fused multiply-adds: match them bit for bit
     Bilin b;
     if (coords == nullptr) {
         b.i00 = b.i01 = b.i10 = b.i11 = xr * Z + zr;

@@ -1,0 +1,177 @@
+// Device-side construction of the transpose of the bilinear rotation operator of one angle (CSR over object-plane
+// voxels + the per-patch source boxes of adm_rotate_adj_staged).  Same arithmetic and same entry order as the host
+// builder adorym_amd/util.py:build_rotation_adjoint_csr (rows by target voxel, entries by ascending source index), so
+// the adjoint stays a deterministic gather -- but 0.1 ms on the GPU instead of 40-60 ms of NumPy per angle, which
+// stalled the driver on the first minibatch of every angle.
+//
+// Reference being transposed: apply_rotation -> w.grid_sample (adorym/util.py:536-552, adorym/wrappers.py:1105-1147);
+// its autograd backward is torch's grid_sampler_2d_backward (a scatter-add).
+//
+//   emit   : one thread per rotated-frame voxel p = (x', z'): the four (target, weight) pairs of make_bilin as
+//            64-bit keys (target << 32 | source) in fixed slots 4p..4p+3 (invalid pairs get a key above every
+//            target), and atomicMin/Max of the source coordinates into the box of the target's 16 x 16 patch;
+//   sort   : rocPRIM radix sort of the keys (weights as values): rows by target, entries by source;
+//   finish : ptr by binary search, src / lsrc / w from the sorted pairs, boxes (x0, z0, w, h).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hipcub/hipcub.hpp>
+#include "adm_common.h"
+
+namespace adm {
+
+// identical to make_bilin of adm_object.hip (kept in step by tests/test_gpu_parity.py: GPU-built vs host-built tables)
+struct Bilin4 {
+    int idx[4];
+    float w[4];
+};
+__device__ __forceinline__ Bilin4 bilin4(const uint16_t* coords, int xr, int zr, int X, int Z) {
+#pragma clang fp contract(off)      // torch / NumPy evaluate this pipeline without fused multiply-adds: match them bit for bit
+    Bilin4 b;
+    const __half* ch = reinterpret_cast<const __half*>(coords) + 2 * ((size_t)xr * Z + zr);
+    const double x_old = (double)__half2float(ch[0]);
+    const double z_old = (double)__half2float(ch[1]);
+    const float gz = (float)(-1.0 + 2.0 * z_old / (double)X + 1.0 / (double)X);
+    const float gx = (float)(-1.0 + 2.0 * x_old / (double)Z + 1.0 / (double)Z);
+    float iz = ((gz + 1.f) * (float)Z - 1.f) / 2.f;
+    float ix = ((gx + 1.f) * (float)X - 1.f) / 2.f;
+    iz = fminf((float)(Z - 1), fmaxf(iz, 0.f));
+    ix = fminf((float)(X - 1), fmaxf(ix, 0.f));
+    const float fz = floorf(iz), fx = floorf(ix);
+    const float tz = iz - fz, tx = ix - fx;
+    const int z0 = (int)fz, x0 = (int)fx;
+    const bool vz = (z0 + 1 <= Z - 1), vx = (x0 + 1 <= X - 1);
+    const int z1 = vz ? z0 + 1 : z0, x1 = vx ? x0 + 1 : x0;
+    b.idx[0] = x0 * Z + z0; b.idx[1] = x0 * Z + z1; b.idx[2] = x1 * Z + z0; b.idx[3] = x1 * Z + z1;
+    b.w[0] = (1.f - tx) * (1.f - tz);
+    b.w[1] = vz ? (1.f - tx) * tz : 0.f;
+    b.w[2] = vx ? tx * (1.f - tz) : 0.f;
+    b.w[3] = (vx && vz) ? tx * tz : 0.f;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void rotcsr_init_kernel(int* box, int nblk) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nblk) {
+        box[4 * i + 0] = 0x7fffffff; box[4 * i + 1] = 0x7fffffff;
+        box[4 * i + 2] = -1; box[4 * i + 3] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void rotcsr_emit_kernel(const uint16_t* __restrict__ coords, int X, int Z, int Yp, int Xp, int pad_x0,
+                                                          unsigned long long* __restrict__ keys, float* __restrict__ vals,
+                                                          int* __restrict__ box) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= X * Z) return;
+    const int xr = p / Z, zr = p - xr * Z;
+    const Bilin4 b = bilin4(coords, xr, zr, X, Z);
+    const unsigned src = (unsigned)((size_t)zr * Yp * Xp + pad_x0 + xr);
+    const int nbx = (X + 15) / 16;
+    const unsigned long long none = (unsigned long long)(X * Z) << 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool valid = b.w[j] != 0.f;
+        keys[4 * (size_t)p + j] = valid ? (((unsigned long long)b.idx[j] << 32) | src) : none;
+        vals[4 * (size_t)p + j] = b.w[j];
+        if (valid) {
+            const int tx = b.idx[j] / Z, tz = b.idx[j] - tx * Z;
+            int* q = box + 4 * ((tz / 16) * nbx + tx / 16);
+            atomicMin(q + 0, xr); atomicMin(q + 1, zr);
+            atomicMax(q + 2, xr); atomicMax(q + 3, zr);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rotcsr_boxes_kernel(const int* __restrict__ box, int nblk, int4* __restrict__ boxes) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nblk) return;
+    int x0 = box[4 * i], z0 = box[4 * i + 1];
+    const int x1 = box[4 * i + 2], z1 = box[4 * i + 3];
+    int bw = 1, bh = 1;
+    if (x1 < 0) { x0 = z0 = 0; }
+    else { bw = x1 - x0 + 1; bh = z1 - z0 + 1; }
+    if (bw * bh > 4096) bw = 0;          // no usable box: adm_rotate_adj_staged gathers that patch from global memory
+    boxes[i] = make_int4(x0, z0, bw, bh);
+}
+
+__global__ __launch_bounds__(256) void rotcsr_finish_kernel(const unsigned long long* __restrict__ keys, const float* __restrict__ vals,
+                                                            int n, int X, int Z, int Yp, int Xp, int pad_x0,
+                                                            const int4* __restrict__ boxes, int* __restrict__ ptr,
+                                                            int* __restrict__ src, unsigned short* __restrict__ lsrc,
+                                                            float* __restrict__ w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int XZ = X * Z;
+    if (i <= XZ) {
+        // ptr[t] = first sorted entry whose target is >= t
+        const unsigned long long want = (unsigned long long)i << 32;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        ptr[i] = lo;
+    }
+    if (i < n) {
+        const unsigned long long k = keys[i];
+        const int tg = (int)(k >> 32);
+        if (tg < XZ) {
+            const unsigned s = (unsigned)(k & 0xffffffffull);
+            const int zs = (int)(s / (unsigned)(Yp * Xp));
+            const int xs = (int)(s - (unsigned)zs * (unsigned)(Yp * Xp)) - pad_x0;
+            const int tx = tg / Z, tz = tg - tx * Z;
+            const int4 bx = boxes[(tz / 16) * ((X + 15) / 16) + tx / 16];
+            src[i] = (int)s;
+            w[i] = vals[i];
+            lsrc[i] = (unsigned short)(bx.z == 0 ? 0 : (zs - bx.y) * bx.z + (xs - bx.x));
+        }
+    }
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace adm
+
+using namespace adm;
+
+extern "C" size_t adm_rotation_csr_scratch_bytes(const adm_plan* plan) {
+    if (!plan) return 0;
+    const size_t n = 4 * (size_t)plan->d.obj_x * plan->d.obj_z;
+    size_t temp = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                             (const float*)nullptr, (float*)nullptr, (int)n, 0, 64, (hipStream_t)0);
+    const size_t nblk = (size_t)((plan->d.obj_x + 15) / 16) * ((plan->d.obj_z + 15) / 16);
+    return 2 * align_up(n * 8) + 2 * align_up(n * 4) + align_up(nblk * 16) + align_up(temp) + 256;
+}
+
+extern "C" int adm_rotation_csr_build(adm_plan* plan, const uint16_t* coords, int32_t* csr_ptr, int32_t* csr_src, uint16_t* csr_lsrc,
+                                      float* csr_w, int32_t* boxes, void* scratch, size_t scratch_bytes) {
+    if (!plan || !coords || !csr_ptr || !csr_src || !csr_lsrc || !csr_w || !boxes || !scratch)
+        return fail(ADM_ERR_INVALID, "adm_rotation_csr_build: null argument");
+    if (scratch_bytes < adm_rotation_csr_scratch_bytes(plan)) return fail(ADM_ERR_INVALID, "adm_rotation_csr_build: scratch too small");
+    const adm_plan_desc& d = plan->d;
+    const int X = d.obj_x, Z = d.obj_z;
+    if ((size_t)d.obj_z * plan->Yp * plan->Xp >= 0xffffffffull) return fail(ADM_ERR_UNSUPPORTED, "adm_rotation_csr_build: rotated frame too large for 32-bit source offsets");
+    const size_t n = 4 * (size_t)X * Z;
+    const int nblk = ((X + 15) / 16) * ((Z + 15) / 16);
+    char* s = (char*)scratch;
+    unsigned long long* keys_a = (unsigned long long*)s; s += align_up(n * 8);
+    unsigned long long* keys_b = (unsigned long long*)s; s += align_up(n * 8);
+    float* vals_a = (float*)s; s += align_up(n * 4);
+    float* vals_b = (float*)s; s += align_up(n * 4);
+    int* box = (int*)s; s += align_up((size_t)nblk * 16);
+    void* temp = s;
+    size_t temp_bytes = scratch_bytes - (size_t)(s - (char*)scratch);
+    hipStream_t st = plan->ctx->stream;
+    hipLaunchKernelGGL(rotcsr_init_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, box, nblk);
+    hipLaunchKernelGGL(rotcsr_emit_kernel, dim3((X * Z + 255) / 256), dim3(256), 0, st, coords, X, Z, plan->Yp, plan->Xp, d.pad_x0, keys_a,
+                       vals_a, box);
+    ADM_HIP(hipGetLastError());
+    int end_bit = 33;
+    while (end_bit < 64 && ((unsigned long long)(X * Z) >> (end_bit - 32)) != 0) ++end_bit;
+    ADM_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, (const unsigned long long*)keys_a, keys_b, (const float*)vals_a, vals_b,
+                                               (int)n, 0, end_bit, st));
+    hipLaunchKernelGGL(rotcsr_boxes_kernel, dim3((nblk + 255) / 256), dim3(256), 0, st, (const int*)box, nblk, (int4*)boxes);
+    hipLaunchKernelGGL(rotcsr_finish_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, st, (const unsigned long long*)keys_b,
+                       (const float*)vals_b, (int)n, X, Z, plan->Yp, plan->Xp, d.pad_x0, (const int4*)boxes, csr_ptr, csr_src, csr_lsrc, csr_w);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}

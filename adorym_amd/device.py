@@ -151,6 +151,12 @@ class PinnedArray(object):
         buf = (C.c_char * max(self.nbytes, 1)).from_address(h.value)
         self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
 
+    def copy_to_async(self, dev, nbytes=None):
+        """Queue host -> device of the first ``nbytes`` on the context's stream; this array must stay untouched until an
+        event recorded afterwards has happened."""
+        check(self.ctx.lib.adm_h2d_async(self.ctx.handle, dev.ptr, self.handle, int(nbytes if nbytes is not None else min(self.nbytes, dev.nbytes))))
+        return self
+
     def copy_from_async(self, dev, nbytes=None):
         check(self.ctx.lib.adm_d2h_async(self.ctx.handle, self.handle, dev.ptr, int(nbytes if nbytes is not None else min(self.nbytes, dev.nbytes))))
         return self
@@ -163,6 +169,37 @@ class PinnedArray(object):
                 self.handle = None
         except Exception:
             pass
+
+
+class UploadRing(object):
+    """Pinned staging ring owned by a context user: upload(dev, host_array) copies the array into the next pinned slot
+    and queues an asynchronous host-to-device copy -- the host never waits for the stream (DeviceArray.set does).  A slot
+    is reused only after the event recorded behind its copy has happened."""
+
+    def __init__(self, ctx, slot_bytes, n_slots=4):
+        self.ctx = ctx
+        self.slot_bytes = int(slot_bytes)
+        self.slots = [PinnedArray(ctx, (self.slot_bytes,), np.uint8) for _ in range(n_slots)]
+        self.events = [None] * n_slots
+        self.k = 0
+
+    def upload(self, dev, host):
+        host = np.ascontiguousarray(host, dtype=dev.dtype)
+        nb = host.nbytes
+        if nb > dev.nbytes:
+            raise ValueError('upload larger than the device array')
+        if nb > self.slot_bytes:
+            dev.set(host) if nb == dev.nbytes else dev.view(0, host.shape).set(host)      # oversize: blocking path
+            return
+        k = self.k
+        self.k = (k + 1) % len(self.slots)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        else:
+            self.events[k] = Event(self.ctx)
+        self.slots[k].array[:nb] = host.reshape(-1).view(np.uint8)
+        self.slots[k].copy_to_async(dev, nb)
+        self.events[k].record()
 
 
 def _fptr(a):
@@ -200,6 +237,12 @@ class Plan(object):
         self.pads = ((d.pad_y0, d.pad_y1), (d.pad_x0, d.pad_x1))
         self.rot_shape = (d.obj_z, d.obj_y + d.pad_y0 + d.pad_y1, d.obj_x + d.pad_x0 + d.pad_x1, 2)
         assert int(np.prod(self.rot_shape)) == ctx.lib.adm_plan_rot_elems(p)
+
+    def rotation_csr_scratch(self):
+        """Device scratch of adm_rotation_csr_build, allocated once per plan (stream-ordered reuse)."""
+        if getattr(self, '_csr_scratch', None) is None:
+            self._csr_scratch = DeviceArray(self.ctx, (int(self.ctx.lib.adm_rotation_csr_scratch_bytes(self.handle)),), np.uint8)
+        return self._csr_scratch
 
     def set_lean_min_batch(self, n):
         """Batches of at least n positions use the two-workgroups-per-CU kernel where it applies (0 = never)."""

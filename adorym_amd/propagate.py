@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import check
 from .constants import PI
-from .device import Context, DeviceArray, Plan
+from .device import Context, DeviceArray, Plan, UploadRing
 from .util import calculate_pad_len, rotation_lookup, build_rotation_adjoint_csr
 
 
@@ -58,13 +58,27 @@ class RotationTable(object):
         return self.coords.ptr
 
     def csr(self, plan):
+        """(ptr, src, lsrc, w, boxes) device arrays of adm_rotate_adj_staged, built on the GPU (adm_rotation_csr_build,
+        asynchronous: ~0.1 ms on the stream instead of 40-60 ms of NumPy per angle)."""
         key = (plan.rot_shape, plan.pads)
         if self._csr is None or self._csr_key != key:
-            Zp, Yp, Xp, _ = plan.rot_shape
-            parts = build_rotation_adjoint_csr(self.host, self.obj_size, Yp, Xp, plan.pads[1][0], staged=True)
-            self._csr = tuple(self.ctx.array(a) for a in parts)          # ptr, src, lsrc, w, boxes
+            _, X, Z = self.obj_size
+            n = 4 * X * Z
+            nblk = ((X + 15) // 16) * ((Z + 15) // 16)
+            ctx = self.ctx
+            parts = (DeviceArray(ctx, (X * Z + 1,), np.int32), DeviceArray(ctx, (n,), np.int32), DeviceArray(ctx, (n,), np.uint16),
+                     DeviceArray(ctx, (n,), np.float32), DeviceArray(ctx, (nblk, 4), np.int32))
+            scratch = plan.rotation_csr_scratch()
+            check(ctx.lib.adm_rotation_csr_build(plan.handle, self.coords.ptr, parts[0].ptr, parts[1].ptr, parts[2].ptr, parts[3].ptr,
+                                                 parts[4].ptr, scratch.ptr, scratch.nbytes))
+            self._csr = parts
             self._csr_key = key
         return self._csr
+
+    def csr_host(self, plan):
+        """The same tables from the host builder (tests compare the two)."""
+        Zp, Yp, Xp, _ = plan.rot_shape
+        return build_rotation_adjoint_csr(self.host, self.obj_size, Yp, Xp, plan.pads[1][0], staged=True)
 
 
 class MultisliceEngine(object):
@@ -146,6 +160,8 @@ class MultisliceEngine(object):
         self._target = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
         self._pred = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
         self._loss = DeviceArray(self.ctx, (batch,), np.float32)
+        # pinned staging for the per-minibatch uploads (targets, positions): asynchronous, the host never drains the stream
+        self._ring = UploadRing(self.ctx, batch * Py * Px * 4, n_slots=4)
         self.max_batch = batch
 
     def y_footprint(self, pos_batch):
@@ -192,13 +208,13 @@ class MultisliceEngine(object):
             self._cur_pos = self._all_pos_dev.view(2 * run, (B, 2))
         else:
             self._cur_pos = self._pos.view(0, (B, 2))
-            self._cur_pos.set(pos)
+            self._ring.upload(self._cur_pos, pos)
         self._pos_host = pos
         if isinstance(target, DeviceArray):
             self._cur_target = target
         else:
             self._cur_target = self._target.view(0, (B,) + self.probe_size)
-            self._cur_target.set(np.asarray(target, dtype=np.float32))
+            self._ring.upload(self._cur_target, np.asarray(target, dtype=np.float32))
         self._B = B
         return B
 
@@ -243,8 +259,33 @@ class MultisliceEngine(object):
         if want_grad and accumulate:
             self.accumulate_tiles()
 
+    MAX_COVER = 64        # ADM_MAXCOVER of adm_object.hip: cover-list entries per rotated-frame pixel
+
+    def _check_cover(self, pos):
+        """The overlap-add keeps at most MAX_COVER tiles per pixel; more would silently drop gradient contributions.
+        Checked on the host BEFORE the launch (a batch of <= MAX_COVER positions cannot overflow), cached per position set,
+        so the asynchronous driver path is covered too, not only the blocking loss()."""
+        if len(pos) <= self.MAX_COVER:
+            return
+        key = pos.tobytes()
+        cache = self.__dict__.setdefault('_cover_ok', {})
+        if key not in cache:
+            Py, Px = self.probe_size
+            y0 = pos[:, 0] - pos[:, 0].min()
+            x0 = pos[:, 1] - pos[:, 1].min()
+            d = np.zeros((int(y0.max()) + Py + 1, int(x0.max()) + Px + 1), np.int32)
+            np.add.at(d, (y0, x0), 1)
+            np.add.at(d, (y0 + Py, x0), -1)
+            np.add.at(d, (y0, x0 + Px), -1)
+            np.add.at(d, (y0 + Py, x0 + Px), 1)
+            cache[key] = int(d.cumsum(0).cumsum(1).max())
+        if cache[key] > self.MAX_COVER:
+            raise RuntimeError('tile overlap-add: a pixel is covered by %d tiles of this launch (limit %d); use a smaller '
+                               'minibatch_size' % (cache[key], self.MAX_COVER))
+
     def accumulate_tiles(self):
         """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
+        self._check_cover(self._pos_host)
         check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
                                                     self._pos_host.ctypes.data, self.grad_rot.ptr))
         self._accumulated = True
@@ -275,6 +316,8 @@ class MultisliceEngine(object):
         y_lo = int(self._pos_host[:, 0].min())
         y_hi = int(self._pos_host[:, 0].max()) + Py
         self._acc_parts = []
+        for o, n in parts:
+            self._check_cover(self._pos_host[o:o + n])
         for i, (o, n) in enumerate(parts):
             ws = self._ws_parts[i]
             check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,

@@ -72,6 +72,10 @@ int adm_d2d(adm_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);  /*
 int adm_host_alloc(adm_ctx* ctx, size_t bytes, void** hptr);
 int adm_host_free(adm_ctx* ctx, void* hptr);
 int adm_d2h_async(adm_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes);
+/* adm_h2d_async: src must come from adm_host_alloc and must not be rewritten before an event recorded after the call has
+ * happened; the copy is ordered on the context's stream like a kernel (no host synchronisation).  Replaces the
+ * per-minibatch host->device hand-over of the measured data (adorym/forward_model.py:113-119). */
+int adm_h2d_async(adm_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes);
 
 /* ---- events: kernel timing on the context's stream --------------------------------- */
 int adm_event_create(adm_ctx* ctx, void** ev);
@@ -144,6 +148,15 @@ int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr
  * patch without a usable box, which gathers through csr_src as adm_rotate_adj_csr does. */
 int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
                           const uint16_t* csr_lsrc, const float* csr_w, const int32_t* boxes, float* grad_obj, int y_lo, int y_hi);
+/* Builds, on the device, everything adm_rotate_adj_staged needs for one angle from the fp16 lookup table `coords`
+ * (device, [X*Z][2]): csr_ptr [X*Z+1], csr_src / csr_lsrc / csr_w [4*X*Z] (only the first csr_ptr[X*Z] entries are
+ * meaningful), boxes [ceil(Z/16)*ceil(X/16)][4].  Rows ordered by target voxel, entries by ascending source offset: the same
+ * table the host builder (adorym_amd/util.py:build_rotation_adjoint_csr) produces, so the gather stays deterministic.
+ * scratch: device memory of adm_rotation_csr_scratch_bytes(plan) bytes.  Asynchronous on the context's stream.
+ * Transposes adorym/util.py:536-552 + adorym/wrappers.py:1105-1147 (what torch's grid_sampler_2d_backward scatters). */
+size_t adm_rotation_csr_scratch_bytes(const adm_plan* plan);
+int adm_rotation_csr_build(adm_plan* plan, const uint16_t* coords, int32_t* csr_ptr, int32_t* csr_src, uint16_t* csr_lsrc,
+                           float* csr_w, int32_t* boxes, void* scratch, size_t scratch_bytes);
 
 /* ---- R3,R5-R8,R10  multislice forward + loss + adjoint ------------------------------
  * Replaces, for one minibatch of `batch` probe positions of one rotation angle:

@@ -1,0 +1,147 @@
+"""
+Round-2 additions, all through the C ABI on a real MI355X (pytest -m gpu):
+  * the device-built rotation-adjoint tables (adm_rotation_csr_build) equal the host builder's, entry for entry;
+  * the pinned upload ring (adm_h2d_async) delivers what the blocking path delivers;
+  * the overlap-add refuses, BEFORE launching, a batch that covers a pixel with more than 64 tiles -- also on the
+    driver's asynchronous path (the overflow flag was only read by the blocking loss());
+  * the two-workgroups-per-CU kernel (adm_ms_lean.hip) against the latency kernel and against the fp64 oracle.
+"""
+import os
+import numpy as np
+import pytest
+
+import cases
+from oracle import adorym_oracle as O      # checker only
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope='module')
+def A():
+    import adorym_amd
+    return adorym_amd
+
+
+@pytest.fixture(scope='module')
+def ctx(A):
+    c = A.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize('size,theta,pos', [((12, 12, 12), 0.3, [(-3, -2), (5, 4)]), ((9, 40, 24), 3.44159, [(0, 0)]),
+                                            ((6, 256, 256), 0.7853982, [(-2, -36), (1, 228)]), ((5, 64, 64), 0.0, [(0, -5)])])
+def test_device_built_rotation_tables_equal_host_builder(A, ctx, size, theta, pos):
+    """ptr / src / lsrc / boxes identical, weights identical bit for bit (same fp32 pipeline on both sides); the object and
+    the padded frame are non-square and the positions hang over the edges so that pad_x0 > 0."""
+    P = 8
+    eng = A.MultisliceEngine(ctx, size, (P, P), np.array(pos), cases.ENERGY_EV, cases.PSIZE_CM, max_batch=len(pos))
+    tab = A.RotationTable(ctx, size, np.float32(theta))
+    dev = [a.get() for a in tab.csr(eng.plan)]
+    ptr, src, lsrc, w, boxes = tab.csr_host(eng.plan)
+    nnz = int(ptr[-1])
+    assert np.array_equal(dev[0], ptr)
+    assert np.array_equal(dev[1][:nnz], src)
+    assert np.array_equal(dev[4].reshape(boxes.shape), boxes)
+    assert np.array_equal(dev[2][:nnz], lsrc)
+    assert np.array_equal(dev[3][:nnz].view(np.uint32), w.view(np.uint32))
+    # and the adjoint evaluated with them equals the atomic scatter of the same operator
+    r = cases.rng(5)
+    eng.grad_rot.set(r.standard_normal(eng.plan.rot_shape).astype(np.float32))
+    g1, g2 = ctx.zeros((*size, 2)), ctx.zeros((*size, 2))
+    eng.rotate_adjoint(g1, tab)
+    eng.rotate_adjoint(g2, tab.coords)
+    assert np.abs(g1.get() - g2.get()).max() <= 5e-6 * np.abs(g2.get()).max()
+
+
+def test_upload_ring_matches_blocking_upload(A, ctx):
+    r = cases.rng(11)
+    dev = A.DeviceArray(ctx, (7, 33), np.float32)
+    ring = A.UploadRing(ctx, 7 * 33 * 4, n_slots=2)
+    for i in range(5):                       # more uploads than slots: slots are recycled behind their events
+        h = r.standard_normal((7, 33)).astype(np.float32)
+        ring.upload(dev, h)
+        assert np.array_equal(dev.get(), h)
+    small = A.DeviceArray(ctx, (4, 2), np.int32)
+    ring.upload(small, np.arange(8, dtype=np.int32).reshape(4, 2))
+    assert np.array_equal(small.get().ravel(), np.arange(8))
+    big = A.DeviceArray(ctx, (3000,), np.float32)         # larger than a slot: falls back to the blocking copy
+    hb = r.standard_normal(3000).astype(np.float32)
+    ring.upload(big, hb)
+    assert np.array_equal(big.get(), hb)
+
+
+def test_overlap_add_refuses_more_than_64_tiles_per_pixel(A, ctx):
+    Y, X, S, P = 40, 40, 2, 16
+    pos = np.array([(3, 4)] * 70)                         # 70 duplicates: every tile pixel is covered 70 times
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=70)
+    r = cases.rng(2)
+    obj = ctx.array(np.stack([r.uniform(0, 1e-3, (Y, X, S)), r.uniform(0, 1e-4, (Y, X, S))], -1).astype(np.float32))
+    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
+    eng.set_batch(pos, np.ones((70, P, P), np.float32))
+    eng.rotate(obj, None)
+    with pytest.raises(RuntimeError, match='covered by 70 tiles'):
+        eng.multislice(probe)                             # raises before the overlap-add is launched
+    eng.set_batch(pos[:64], np.ones((64, P, P), np.float32))
+    eng.multislice(probe)
+    assert np.isfinite(eng.loss())
+
+
+def test_driver_refuses_overcovered_fused_angle(A, ctx, tmp_path):
+    """The same guard through reconstruct_ptychography's asynchronous path ('per angle' fuses 80 positions, 72 of them on
+    one spot)."""
+    n_pos, P, N = 80, 16, 32
+    pos = np.array([(4, 4)] * 72 + [(i, 2 * i) for i in range(8)])
+    r = cases.rng(3)
+    prj = (np.abs(r.standard_normal((1, n_pos, P, P))) + 1).astype(np.float32)
+    fn = os.path.join(str(tmp_path), 'd.npz')
+    np.savez(fn, data=prj)
+    with pytest.raises(RuntimeError, match='tiles of this launch'):
+        A.reconstruct_ptychography(fname=fn, save_path=str(tmp_path), output_folder='o', obj_size=(N, N, 4), probe_pos=pos,
+                                   theta_st=0, theta_end=0, n_theta=1, energy_ev=cases.ENERGY_EV, psize_cm=cases.PSIZE_CM,
+                                   minibatch_size=8, n_epochs=1, update_scheme='per angle', free_prop_cm='inf',
+                                   probe_type='gaussian', probe_mag_sigma=4, probe_phase_sigma=4, probe_phase_max=0.5,
+                                   initial_guess=[np.full((N, N, 4), 1e-4), np.full((N, N, 4), 1e-5)], gamma=0, alpha_d=None,
+                                   random_theta=False, store_checkpoint=False, use_checkpoint=False, cpu_only=False)
+
+
+@pytest.mark.parametrize('P,free_prop', [(72, 'inf'), (64, 0), (72, 1e-4)])
+def test_throughput_kernel_vs_latency_kernel_and_oracle(A, ctx, P, free_prop):
+    """adm_plan_set_lean_min_batch(1) routes the batch through ms_lean_kernel.  Well-conditioned problem (data = forward
+    of a structured truth): loss within 1e-5 of the fp64 oracle, gradient within 5e-4 of it (the far-field
+    gradient of a random-texture object sits at 1.6e-4 for BOTH kernels: fp32 conditioning) and the two
+    kernels within 2e-4 of each other."""
+    r = cases.rng(77)
+    Y, X, S, B = P + 20, P + 24, 12, 5
+    truth = np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1)
+    guess = (0.7 * truth + 0.3 * truth.mean((0, 1, 2), keepdims=True)).astype(np.float32)
+    pos = np.stack([r.integers(-5, 25, B), r.integers(-5, 29, B)], 1)
+    pr = (r.standard_normal((P, P)) + 1j * r.standard_normal((P, P)))
+    pr = pr * np.exp(-((np.arange(P) - P / 2) ** 2)[:, None] / 300 - ((np.arange(P) - P / 2) ** 2)[None] / 300)
+    probe_h = np.stack([pr.real, pr.imag], -1)[None].astype(np.float32)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=free_prop, max_batch=B)
+    probe = ctx.array(probe_h)
+    # oracle (fp64): data from the truth, loss/gradient at the guess
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=free_prop)
+    pc = probe_h[0, ..., 0].astype(np.float64) + 1j * probe_h[0, ..., 1]
+    tt, _ = O.extract_tiles(truth, pos, (P, P))
+    meas = O.predict(tt, pc, phys, 'float64')[0]
+    loss64, _, g64, _ = O.forward_adjoint_object(guess.astype(np.float64), None, pc, pos, meas, phys, 'float64')
+    out = []
+    for lean in (0, 1):
+        eng.plan.set_lean_min_batch(lean)
+        eng.set_batch(pos, meas.astype(np.float32))
+        eng.rotate(ctx.array(guess), None)
+        eng.multislice(probe, want_pred=False)
+        g = ctx.zeros(guess.shape)
+        eng.rotate_adjoint(g, None)
+        out.append((eng.loss(), g.get()))
+    for loss, g in out:
+        assert abs(loss - loss64) <= 1e-5 * abs(loss64)
+        assert rel(g, g64) < 5e-4
+    assert rel(out[1][1], out[0][1]) < 2e-4
