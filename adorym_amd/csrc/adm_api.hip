@@ -244,6 +244,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
     p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
     p->reg_stats = nullptr;
+    p->reg_partial = nullptr;
     p->det_weight_dev = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
     {   // the throughput kernel reads H from a table folded along kx: exact mirror symmetry required
@@ -284,6 +285,7 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
     if (plan->twid_dev) adm_free(plan->ctx, plan->twid_dev);
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
+    if (plan->reg_partial) (void)hipFree(plan->reg_partial);
     if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
     delete plan;
     return ADM_OK;

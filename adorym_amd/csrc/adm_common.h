@@ -29,6 +29,7 @@ struct adm_plan {
     float2* twid_dev;      // [Px] exp(-2 pi i j / N)
     float* det_weight_dev; // [Py*Px] beamstop weights or nullptr (adm_plan_set_detector_mask)
     float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
+    float* reg_partial;    // [obj_y*obj_x] per-row partial sums of the regulariser value (lazily allocated)
     bool h_sym;            // H(ky, kx) == H(ky, N - kx) for the slice and detector kernels (every get_kernel() output)
     int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
 };

@@ -45,6 +45,13 @@ class Context(object):
         a.zero_()
         return a
 
+    def uploader(self, min_slot_bytes=1 << 20):
+        """A context-wide pinned upload ring for small tables (rotation lookups, ...): asynchronous host-to-device."""
+        ring = getattr(self, '_uploader', None)
+        if ring is None or ring.slot_bytes < min_slot_bytes:
+            ring = self._uploader = UploadRing(self, max(int(min_slot_bytes), 1 << 20), n_slots=4)
+        return ring
+
     def array(self, host, dtype=None):
         host = np.ascontiguousarray(host, dtype=dtype)
         a = DeviceArray(self, host.shape, host.dtype)

@@ -47,7 +47,20 @@ class RotationTable(object):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.host = rotation_lookup(self.obj_size, theta) if coords_fp16 is None else np.asarray(coords_fp16, dtype=np.float16)
-        self.coords = ctx.array(np.ascontiguousarray(self.host).view(np.uint16))
+        # ONE allocation per angle: [fp16 table | ptr | src | w | lsrc | boxes]; the table goes up through the context's
+        # pinned ring (no stream synchronisation when the driver meets a new angle in the middle of an epoch)
+        _, X, Z = self.obj_size
+        n = 4 * X * Z
+        nblk = ((X + 15) // 16) * ((Z + 15) // 16)
+        al = lambda v: (v + 255) & ~255
+        sizes = [X * Z * 2 * 2, (X * Z + 1) * 4, n * 4, n * 4, n * 2, nblk * 16]
+        offs = np.concatenate([[0], np.cumsum([al(v) for v in sizes])]).astype(int)
+        self._arena = DeviceArray(ctx, (int(offs[-1]),), np.uint8)
+        sub = lambda i, shape, dt: DeviceArray(ctx, shape, dt, ptr=self._arena.ptr + int(offs[i]))
+        self.coords = sub(0, (X * Z, 2), np.uint16)
+        self._parts = (sub(1, (X * Z + 1,), np.int32), sub(2, (n,), np.int32), sub(4, (n,), np.uint16), sub(3, (n,), np.float32),
+                       sub(5, (nblk, 4), np.int32))          # ptr, src, lsrc, w, boxes
+        ctx.uploader(sizes[0]).upload(self.coords, np.ascontiguousarray(self.host).view(np.uint16).reshape(X * Z, 2))
         self._csr = None
         self._csr_key = None
         th = float(theta)
@@ -62,12 +75,8 @@ class RotationTable(object):
         asynchronous: ~0.1 ms on the stream instead of 40-60 ms of NumPy per angle)."""
         key = (plan.rot_shape, plan.pads)
         if self._csr is None or self._csr_key != key:
-            _, X, Z = self.obj_size
-            n = 4 * X * Z
-            nblk = ((X + 15) // 16) * ((Z + 15) // 16)
             ctx = self.ctx
-            parts = (DeviceArray(ctx, (X * Z + 1,), np.int32), DeviceArray(ctx, (n,), np.int32), DeviceArray(ctx, (n,), np.uint16),
-                     DeviceArray(ctx, (n,), np.float32), DeviceArray(ctx, (nblk, 4), np.int32))
+            parts = self._parts
             scratch = plan.rotation_csr_scratch()
             check(ctx.lib.adm_rotation_csr_build(plan.handle, self.coords.ptr, parts[0].ptr, parts[1].ptr, parts[2].ptr, parts[3].ptr,
                                                  parts[4].ptr, scratch.ptr, scratch.nbytes))

@@ -105,23 +105,28 @@ def cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize):
     return time.perf_counter() - t1
 
 
-def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=3):
-    """Secondary figure (not `value`): the reference's update_scheme='per angle' -- the 17 minibatches of one angle
-    (529 positions padded to 544, ptychography.py:820-823) see the same object, so adorym_amd fuses them into one
-    launch: every CU has work.  One step = whole-object rotation + 544 positions fwd/adjoint + overlap-add +
-    back-rotation + 17x regulariser gradient + Adam."""
+def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_groups, label, reps=3):
+    """Secondary figures (not `value`): steps whose global batch holds `n_groups` reference minibatches of ONE angle, fused
+    into one launch so that every CU has work.  Two reference semantics give such a step:
+      * update_scheme='per angle' (adorym/ptychography.py:1095-1099): the 17 minibatches of an angle (529 positions padded
+        to 544, :816-823) see the same object and are accumulated before the update;
+      * `mpirun -n R` (:786,905-909,1113-1114): the global batch is R x minibatch_size positions, every rank's loss is the
+        mean over its own minibatch, the gradients are SUMMED and every rank adds the regulariser term -- `virtual_ranks`
+        R on one GPU is exactly that sum.
+    One step = whole-object rotation + n_groups*32 positions fwd/adjoint + overlap-add + back-rotation + regulariser
+    gradient (x n_groups) + Adam."""
     import time as _t
     mb = cfg['minibatch_size']
     n_pos = len(cfg['probe_pos'])
-    k = -(-n_pos // mb)
-    ind = np.concatenate([np.arange(n_pos), np.arange(k * mb - n_pos)])
+    B = n_groups * mb
+    ind = np.arange(B) % n_pos
     pos = cfg['probe_pos'][ind]
-    B = len(ind)
     Py, Px = cfg['probe_size']
     tgt = ctx.empty((B, Py, Px))
     any_t = next(iter(targets.values()))
-    for j in range(k):                       # synthetic magnitudes: tile the ones generated for the main run
+    for j in range(n_groups):                # synthetic magnitudes: tile the ones generated for the main run
         tgt.view(j * mb * Py * Px, (mb, Py, Px)).copy_from(any_t)
+    eng._reserve(B)
     e0, e1 = ctx.event(), ctx.event()
     kern = []
     ctx.sync()
@@ -135,8 +140,8 @@ def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=
         eng.rotate(state.obj, tables[it], None)
         ctx.fork()
         state.finish_update()
-        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * k, cfg['alpha_b'] * k, cfg['gamma'] * k,
-                                       state.grad.ptr, None))
+        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * n_groups, cfg['alpha_b'] * n_groups,
+                                       cfg['gamma'] * n_groups, state.grad.ptr, None))
         ctx.end_fork()
         ctx.join()                  # (the side work is short; the overlapped launch below forks again)
         e0.record()
@@ -151,10 +156,79 @@ def per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check, reps=
     dt = (_t.perf_counter() - t0) / reps
     Y, X, Z = cfg['obj_size']
     alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
-    return {'update_scheme': 'per angle', 'positions_per_step': B, 'value': B / dt, 'unit': 'probe-positions/s',
-            'ms_per_step': 1e3 * dt, 'fwd_adj_overlap_add_ms': float(np.mean(kern)),
-            'fwd_adj_overlap_add_frac_of_hbm_peak': alg / (np.mean(kern) * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            'whole_step_frac_of_hbm_peak': alg / dt / 1e9 / PEAK_HBM_GBS, 'loss_last': loss}
+    out = {'positions_per_step': B, 'value': B / dt, 'unit': 'probe-positions/s',
+           'ms_per_step': 1e3 * dt, 'fwd_adj_overlap_add_ms': float(np.mean(kern)),
+           'fwd_adj_overlap_add_frac_of_hbm_peak': alg / (np.mean(kern) * 1e-3) / 1e9 / PEAK_HBM_GBS,
+           'whole_step_frac_of_hbm_peak': alg / dt / 1e9 / PEAK_HBM_GBS, 'loss_last': loss}
+    out.update(label)
+    return out
+
+
+def kernel_sweep(ctx, eng, probe, cfg, targets, batches=(1, 8, 32, 64, 128, 256, 512, 544), reps=3):
+    """Duration of the multislice forward+adjoint launch alone (HIP events on its stream) over the number of positions in
+    flight: ms per launch, positions/s and fraction of the HBM roofline with SURVEY 8(d)'s algorithmic bytes."""
+    mb = cfg['minibatch_size']
+    Py, Px = cfg['probe_size']
+    Y, X, Z = cfg['obj_size']
+    n_pos = len(cfg['probe_pos'])
+    any_t = next(iter(targets.values()))
+    e0, e1 = ctx.event(), ctx.event()
+    rows = []
+    for B in batches:
+        eng._reserve(B)
+        tgt = ctx.empty((B, Py, Px))
+        for j in range(0, B, mb):
+            n = min(mb, B - j)
+            tgt.view(j * Py * Px, (n, Py, Px)).copy_from(any_t.view(0, (n, Py, Px)))
+        eng.set_batch(cfg['probe_pos'][(np.arange(B) + 200) % n_pos], tgt)
+        ts = []
+        for r in range(reps + 1):
+            e0.record()
+            if B > eng.N_CU:
+                eng.multislice_overlapped(probe, grad_scale=2.0 / (mb * Py * Px))
+            else:
+                eng.multislice(probe, accumulate=False)
+            e1.record()
+            ts.append(e0.elapsed_ms(e1))
+        ms = float(np.min(ts[1:]))
+        alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
+        rows.append({'positions': B, 'ms': ms, 'positions_per_s': B / (ms * 1e-3), 'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     'includes_overlap_add_of_all_but_last_round': B > eng.N_CU})
+    return rows
+
+
+def driver_measure(cfg, n_theta=16, update_scheme='immediate'):
+    """The PRODUCT's driver, not the engine loop: one epoch of adorym_amd.reconstruct_ptychography over `n_theta` angles of
+    config 3 that it has never seen (rotation tables and their adjoint CSR are built inside the timed run), host-resident
+    measured data handed over minibatch by minibatch (adorym/forward_model.py:113-119).  Step time = MEAN spacing of the
+    per-minibatch time stamps of convergence/loss_rank_0.txt (adorym/ptychography.py:1261), first-touch angles included."""
+    import tempfile
+    import adorym_amd as A
+    from adorym_amd import workloads as W
+    r = np.random.default_rng(0)
+    n_pos = len(cfg['probe_pos'])
+    Py, Px = cfg['probe_size']
+    prj = (np.abs(r.standard_normal((n_theta, n_pos, Py, Px), dtype=np.float32)) * 30)
+    g = W.random_guess(cfg['obj_size'], seed=1)
+    import contextlib
+    with tempfile.TemporaryDirectory() as td, open(os.devnull, 'w') as sink, contextlib.redirect_stdout(sink):
+        t0 = time.perf_counter()        # (the driver's progress lines go to the sink: stdout carries the one JSON line)
+        st = A.reconstruct_ptychography(
+            fname=prj, obj_size=cfg['obj_size'], probe_pos=cfg['probe_pos'], theta_st=0, theta_end=2 * np.pi, n_theta=n_theta,
+            energy_ev=cfg['energy_ev'], psize_cm=cfg['psize_cm'], free_prop_cm='inf', minibatch_size=cfg['minibatch_size'], n_epochs=1,
+            alpha_d=cfg['alpha_d'], alpha_b=cfg['alpha_b'], gamma=cfg['gamma'], learning_rate=cfg['learning_rate'], optimizer='adam',
+            initial_guess=[g[..., 0], g[..., 1]], save_path=td, output_folder='drv', store_checkpoint=False, use_checkpoint=False,
+            update_scheme=update_scheme, return_state=True, **cfg['probe'])
+        wall = time.perf_counter() - t0
+        lines = open(os.path.join(st['output_folder'], 'convergence', 'loss_rank_0.txt')).read().strip().split('\n')[1:]
+    ts = np.array([float(l.split(',')[3]) for l in lines])
+    n = len(ts)
+    mean_ms = 1e3 * (ts[-1] - ts[0]) / (n - 1)
+    per_step = cfg['minibatch_size'] if update_scheme == 'immediate' else -(-n_pos // cfg['minibatch_size']) * cfg['minibatch_size']
+    return {'update_scheme': update_scheme, 'first_touch_angles': n_theta, 'logged_steps': n, 'positions_per_step': per_step,
+            'ms_per_step_mean': mean_ms, 'ms_per_step_max': float(1e3 * np.diff(ts).max()), 'value': per_step / (mean_ms * 1e-3),
+            'unit': 'probe-positions/s', 'wall_s_incl_setup_and_output': wall,
+            'how': 'mean spacing of the time stamps of convergence/loss_rank_0.txt over the whole epoch'}
 
 
 def main():
@@ -164,7 +238,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--minibatch', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-per-angle', action='store_true', help="skip the secondary update_scheme='per angle' measurement")
+    ap.add_argument('--no-per-angle', action='store_true', help="skip the secondary full-chip legs (per angle, virtual ranks, sweep)")
+    ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
     ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed (RCCL) path even with one rank')
     args = ap.parse_args()
 
@@ -318,7 +393,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         if world == 1 and not args.no_per_angle:
-            out['per_angle'] = per_angle_measure(ctx, eng, state, probe, tables, cfg, targets, check)
+            k_angle = -(-n_pos // B)
+            out['per_angle'] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle,
+                                                   {'update_scheme': 'per angle'})
+            for R in (8, 16):
+                out['virtual_ranks_%d' % R] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, R,
+                                                                  {'update_scheme': 'immediate', 'virtual_ranks': R,
+                                                                   'semantics': 'global batch R x 32 of one angle, gradients summed (mpirun -n R)'})
+            out['kernel_sweep'] = kernel_sweep(ctx, eng, probe, cfg, targets)
+        if world == 1 and not args.no_driver:
+            out['driver'] = driver_measure(cfg, 16, 'immediate')
+            out['driver']['engine_loop_ms_per_step'] = ms_per_step
+            out['driver']['ratio_to_engine_loop'] = out['driver']['ms_per_step_mean'] / ms_per_step
+            out['driver_per_angle'] = driver_measure(cfg, 16, 'per angle')
     else:
         out = None
     if use_dist:
