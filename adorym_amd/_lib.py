@@ -58,6 +58,15 @@ SIGNATURES = {
     'adm_event_destroy': (_I, [_VP, _VP]),
     'adm_event_record': (_I, [_VP, _VP]),
     'adm_event_elapsed_ms': (_I, [_VP, _VP, _VP, C.POINTER(_F)]),
+    'adm_comm_unique_id': (_I, [_VP]),
+    'adm_comm_init': (_I, [_VP, _I, _I, _VP]),
+    'adm_comm_destroy': (_I, [_VP]),
+    'adm_comm_rank': (_I, [_VP]),
+    'adm_comm_size': (_I, [_VP]),
+    'adm_reduce_scatter': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_all_gather': (_I, [_VP, _VP, _VP, _SZ]),
+    'adm_all_reduce': (_I, [_VP, _VP, _SZ, _I]),
+    'adm_broadcast': (_I, [_VP, _VP, _SZ, _I]),
     'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
     'adm_plan_destroy': (_I, [_VP]),
     'adm_plan_set_detector_mask': (_I, [_VP, _VP]),

@@ -10,8 +10,13 @@ over RCCL/xGMI through ``torch.distributed`` (backend "nccl" is RCCL on ROCm).  
 only: it owns the process group and the buffers that the collectives touch; every kernel is libadm's
 and runs on the same HIP stream (the context is created on torch's current stream).
 
-Backends: LocalComm (1 rank, no torch import), TorchComm('nccl') on GPUs, TorchComm('gloo') on host
-buffers for CPU tests of the sharding logic.
+Backends:
+  LocalComm            1 rank, no torch import;
+  RcclComm             the product's multi-GPU backend: collectives through libadm's C ABI (adm_reduce_scatter / adm_all_gather /
+                       adm_all_reduce: RCCL, dlopen'ed) on the context's own stream and on libadm's own device buffers; a
+                       torch.distributed *gloo* group is only the rendezvous / control plane (unique id, seeds, barriers);
+  TorchComm('nccl')    the same collectives through torch.distributed (kept as an alternative);
+  TorchComm('gloo')    host buffers, for CPU tests of the sharding logic.
 """
 import os
 import numpy as np
@@ -61,6 +66,8 @@ class TorchComm(object):
         if init and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29511')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
             kw = {}
             if backend == 'nccl':
                 if device_index is None:
@@ -122,6 +129,14 @@ class TorchComm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
+    def all_reduce_device(self, dev):
+        """In-place sum over ranks of a libadm device array, through a torch tensor (host bounce: this backend has no
+        view of libadm's memory; RcclComm reduces in place on the device)."""
+        g = self.torch.from_numpy(dev.get()).to(self.device)
+        self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM)
+        dev.set(g.cpu().numpy())
+        return dev
+
     def max_over_ranks(self, value):
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -142,8 +157,102 @@ class TorchComm(object):
             self.dist.destroy_process_group()
 
 
+class RcclComm(object):
+    """One process per GPU; data plane = RCCL behind the C ABI, control plane = a gloo group (env:// rendezvous:
+    RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run).  ``attach(ctx)`` must be
+    called once with the rank's Context before the first device collective (the driver does)."""
+    backend = 'rccl'
+
+    def __init__(self, device_index=None, init=True):
+        import torch
+        import torch.distributed as dist
+        self.torch = torch
+        self.dist = dist
+        if init and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29511')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
+            dist.init_process_group(backend='gloo')
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+        self.device_index = int(os.environ.get('LOCAL_RANK', '0')) if device_index is None else int(device_index)
+        self.ctx = None
+
+    def attach(self, ctx):
+        """Create the RCCL communicator of this rank on ``ctx`` (collective over all ranks)."""
+        import ctypes as C
+        from ._lib import check
+        if self.ctx is ctx:
+            return self
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(ctx.lib.adm_comm_unique_id(uid))
+        raw = self.bcast_object(bytes(uid.raw), root=0)
+        uid = C.create_string_buffer(raw, 128)
+        check(ctx.lib.adm_comm_init(ctx.handle, self.rank, self.size, uid))
+        self.ctx = ctx
+        return self
+
+    def stream_handle(self):
+        return None             # the context owns its stream; RCCL is enqueued on it by libadm
+
+    # ---- buffers the collectives touch: libadm device arrays ----
+    def alloc(self, n, dtype=None):
+        return self.ctx.zeros((int(n),))
+
+    # ---- device collectives (asynchronous on the context's stream) ----
+    def reduce_scatter_sum(self, full, shard_out):
+        from ._lib import check
+        check(self.ctx.lib.adm_reduce_scatter(self.ctx.handle, full.ptr, shard_out.ptr, shard_out.size))
+
+    def all_gather(self, full_out, shard_in):
+        from ._lib import check
+        check(self.ctx.lib.adm_all_gather(self.ctx.handle, shard_in.ptr, full_out.ptr, shard_in.size))
+
+    def all_reduce_device(self, dev):
+        """In-place sum over ranks of a libadm device array (small parameter gradients: they never visit the host)."""
+        from ._lib import check
+        check(self.ctx.lib.adm_all_reduce(self.ctx.handle, dev.ptr, dev.size, 0))
+        return dev
+
+    # ---- control plane (host) ----
+    def barrier(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+        self.dist.barrier()
+
+    def shard_range(self, n):
+        return shard_bounds(n, self.size, self.rank)
+
+    def _host_reduce(self, value, op):
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def max_over_ranks(self, value):
+        return self._host_reduce(value, self.dist.ReduceOp.MAX)
+
+    def sum_over_ranks(self, value):
+        return self._host_reduce(value, self.dist.ReduceOp.SUM)
+
+    def bcast_object(self, obj, root=0):
+        lst = [obj]
+        self.dist.broadcast_object_list(lst, src=root)
+        return lst[0]
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+            self.ctx.lib.adm_comm_destroy(self.ctx.handle)
+            self.ctx = None
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
 def from_env():
-    """LocalComm unless launched under torch.distributed.run with WORLD_SIZE > 1."""
+    """LocalComm unless launched under torch.distributed.run with WORLD_SIZE > 1 (then RCCL through the C ABI;
+    ADM_COMM=torch selects the torch.distributed collectives instead)."""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        return TorchComm('nccl')
+        return TorchComm('nccl') if os.environ.get('ADM_COMM', 'rccl') == 'torch' else RcclComm()
     return LocalComm()

@@ -44,6 +44,9 @@ extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
     }
     c->main_stream = c->stream;
     c->join_pending = false;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_size = 1;
     hipError_t e2 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -85,6 +88,7 @@ extern "C" int adm_ctx_destroy(adm_ctx* ctx) {
     if (!ctx) return ADM_OK;
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->main_stream);
+    (void)adm_comm_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);

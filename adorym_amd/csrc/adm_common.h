@@ -17,6 +17,8 @@ struct adm_ctx {
     hipEvent_t ev_fork, ev_join;
     bool owns_stream;
     bool join_pending;
+    void* comm;              // ncclComm_t of adm_comm_init (adm_comm.hip) or nullptr
+    int comm_rank, comm_size;
 };
 
 struct adm_plan {

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libadm.so')
-SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip', 'adm_ms_lean.hip', 'adm_rotcsr.hip', 'adm_holo.hip']
+SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip', 'adm_ms_lean.hip', 'adm_rotcsr.hip', 'adm_comm.hip', 'adm_holo.hip']
 HDRS = ['adm_common.h', 'adm_fft.h', 'adm_ms_math.h', os.path.join('..', '..', 'include', 'adm.h')]
 
 
@@ -43,7 +43,7 @@ def build(force=False, extra=(), out=None, tag=''):
     failed = [c for c, p_ in zip(cmds, procs) if p_.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs + ['-ldl'])
     return out
 
 

@@ -24,7 +24,9 @@ class HipOps(object):
         self.ctx = ctx
 
     def wrap(self, tensor, n):
-        """Non-owning DeviceArray over a torch CUDA tensor (kept alive by the caller)."""
+        """Non-owning DeviceArray over a torch CUDA tensor (kept alive by the caller); libadm arrays pass through."""
+        if isinstance(tensor, DeviceArray):
+            return tensor
         return DeviceArray(self.ctx, (n,), np.float32, ptr=tensor.data_ptr())
 
     def alloc(self, n):
@@ -77,7 +79,13 @@ class DataParallelObject(object):
         self.hi = min(self.lo + self.per, self.n)
         self._keep = []
         self.dist = R > 1 or getattr(comm, 'backend', 'local') != 'local'
-        if self.dist:
+        # RcclComm works on libadm's own buffers, in place: the reduced shard lands in its slot of the gradient buffer and the
+        # updated shard is gathered from its slot of the object (no staging copies, no torch tensors)
+        self.inplace = self.dist and getattr(comm, 'backend', '') == 'rccl'
+        if self.inplace:
+            self.obj = ops.alloc(self.n_pad)
+            self.grad = ops.alloc(self.n_pad)
+        elif self.dist:
             t_obj, t_grad = comm.alloc(self.n_pad), comm.alloc(self.n_pad)
             self.t_obj, self.t_grad = t_obj, t_grad
             self.t_gshard, self.t_xshard = comm.alloc(self.per), comm.alloc(self.per)
@@ -115,7 +123,10 @@ class DataParallelObject(object):
         after the next rotation, where it overlaps the next multislice kernel (which keeps only `minibatch` of the 256
         CUs busy).  Same arithmetic, same result; nothing outside ``first`` may be read before finish_update()."""
         self.finish_update()
-        if self.dist:
+        if self.inplace:
+            self.comm.reduce_scatter_sum(self.grad, self.grad.view(self.lo, (self.per,)))
+            g, g_base = self.grad, 0
+        elif self.dist:
             self.comm.reduce_scatter_sum(self.t_grad, self.t_gshard)
             g, g_base = self.gshard, self.lo
         else:
@@ -126,7 +137,9 @@ class DataParallelObject(object):
             self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, f_lo, f_hi)
         else:
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, self.hi)
-        if self.dist:
+        if self.inplace:
+            self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
+        elif self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
 

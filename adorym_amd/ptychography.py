@@ -194,6 +194,8 @@ def reconstruct_ptychography(
     stream = comm.stream_handle() if hasattr(comm, 'stream_handle') else None
     dev_index = getattr(comm, 'device_index', None)
     ctx = Context(gpu_index if dev_index is None else dev_index, stream=stream)
+    if hasattr(comm, 'attach'):
+        comm.attach(ctx)            # RCCL communicator of this rank on the context's stream (adm_comm_init)
 
     if rank == 0:
         timestr = str(datetime.datetime.today())
@@ -712,9 +714,7 @@ def reconstruct_ptychography(
             if optimize_probe:
                 if probe_update_delay <= i_batch + i_epoch * n_batch < probe_update_limit:
                     if n_ranks > 1:
-                        g = comm.torch.from_numpy(probe_grad_dev.get()).to(comm.device)
-                        comm.all_reduce_sum(g)
-                        probe_grad_dev.set(g.cpu().numpy())
+                        comm.all_reduce_device(probe_grad_dev)
                     opt_probe.apply_gradient(probe_dev, probe_grad_dev, i_opt_batch, **opt_probe.options_dict)
                 else:
                     print_flush('  Probe is not updated because current batch is out of the specified range ({}, {}).'.format(
@@ -724,9 +724,7 @@ def reconstruct_ptychography(
             if optimize_all_probe_pos and i_batch + i_epoch * n_batch >= other_params_update_delay:
                 corr_dev = optimizable_params['probe_pos_correction']
                 if n_ranks > 1:
-                    g = comm.torch.from_numpy(pos_grad_dev.get()).to(comm.device)
-                    comm.all_reduce_sum(g)
-                    pos_grad_dev.set(g.cpu().numpy())
+                    comm.all_reduce_device(pos_grad_dev)
                 opt_probe_pos.apply_gradient(corr_dev, pos_grad_dev, i_opt_batch, **opt_probe_pos.options_dict)
                 # prevent position drifting: subtract the mean over (theta, position)
                 _lib.check(ctx.lib.adm_center_rows(ctx.handle, corr_dev.ptr, corr_dev.size // 2, 2))
@@ -738,9 +736,7 @@ def reconstruct_ptychography(
                         continue
                     gdev = free_prop_grad_dev if name_ == 'free_prop_cm' else affine_grad_dev
                     if n_ranks > 1:
-                        g = comm.torch.from_numpy(gdev.get()).to(comm.device)
-                        comm.all_reduce_sum(g)
-                        gdev.set(g.cpu().numpy())
+                        comm.all_reduce_device(gdev)
                     o_.apply_gradient(optimizable_params[name_], gdev, i_opt_batch, **o_.options_dict)
                 if opt_prj_affine is not None:
                     # "regularize transformation of image 0": matrix 0 is pinned to the identity

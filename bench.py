@@ -240,7 +240,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-per-angle', action='store_true', help="skip the secondary full-chip legs (per angle, virtual ranks, sweep)")
     ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
-    ap.add_argument('--force-dist', action='store_true', help='use the torch.distributed (RCCL) path even with one rank')
+    ap.add_argument('--force-dist', action='store_true', help='use the multi-GPU (RCCL) code path even with one rank')
+    ap.add_argument('--comm', choices=('rccl', 'torch'), default='rccl',
+                    help="collectives through libadm's C ABI (default) or through torch.distributed's nccl backend")
     args = ap.parse_args()
 
     import torch
@@ -256,10 +258,17 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
-    comm = C.TorchComm('nccl', device_index=local_rank) if use_dist else C.LocalComm()
+    if not use_dist:
+        comm = C.LocalComm()
+    elif args.comm == 'torch':
+        comm = C.TorchComm('nccl', device_index=local_rank)
+    else:
+        comm = C.RcclComm(device_index=local_rank)
     rank = comm.rank
-    # libadm kernels and the RCCL collectives share one explicit stream (see TorchComm)
+    # libadm kernels and the RCCL collectives share one stream: the context's own (RcclComm) or torch's (TorchComm)
     ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
+    if hasattr(comm, 'attach'):
+        comm.attach(ctx)
 
     cfg = W.c3_config()
     B = args.minibatch
@@ -383,6 +392,7 @@ def main():
             'config': {'workload': cfg['name'], 'object': [Y, X, Z], 'probe': [Py, Px], 'slices': Z,
                        'minibatch_per_gpu': B, 'global_batch': world * B, 'update_scheme': 'immediate', 'optimizer': 'adam',
                        'regularizers': 'L1+TV', 'far_field': True, 'parallelism': 'dp%d' % world,
+                       'collectives': getattr(comm, 'backend', 'local'),
                        'step': 'rotate_fwd + multislice fwd/loss/adjoint + rotate_adj + reg_grad + (reduce_scatter) + adam (+all_gather)'},
             'roofline': {'bound': 'hbm', 'kernel': 'ms_fwd_adj_kernel<72,8,9>', 'achieved': achieved, 'peak': PEAK_HBM_GBS,
                          'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS, 'traffic': traffic,
@@ -411,6 +421,12 @@ def main():
     if use_dist:
         comm.close()            # RCCL may print its banner here; the JSON line goes last
     if out is not None:
+        # RCCL prints a banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 

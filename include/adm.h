@@ -84,6 +84,28 @@ int adm_event_record(adm_ctx* ctx, void* ev);
 int adm_event_elapsed_ms(adm_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* blocks on ev_stop */
 int adm_event_sync(adm_ctx* ctx, void* ev);                                        /* blocks until ev has happened */
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel mode (one process per GPU): RCCL over xGMI, loaded with dlopen on first use.
+ * They replace the reference's mpi4py object collectives (pickle through host memory):
+ *   gradient.arr = comm.allreduce(gradient.arr)      adorym/ptychography.py:1113-1114  -> adm_reduce_scatter of the object
+ *       gradient, fused optimiser step on the owned shard, adm_all_gather of the updated shards
+ *   comm.allreduce(w.to_numpy(opt.grads))            adorym/optimizers.py:1025,1041,1053,1064,1079 -> adm_all_reduce
+ *   comm.bcast / comm.Bcast                          adorym/ptychography.py:217,411,485-487,664-665,796 -> adm_broadcast
+ * adm_comm_unique_id: 128 bytes, created by one rank and handed to all ranks by the host side's rendezvous.
+ * adm_comm_init: collective over the `nranks` contexts.  All transfers use device pointers, are enqueued on the
+ * context's stream and are asynchronous; counts are in floats (bytes for adm_broadcast).
+ * adm_reduce_scatter: recv[0..recv_count) = sum over ranks of send[rank*recv_count ...]; send holds nranks*recv_count.
+ * adm_all_gather:     recv[r*send_count ...] = rank r's send[0..send_count).  adm_all_reduce: in place, sum (op_max = 0) or max. */
+int adm_comm_unique_id(void* out128);
+int adm_comm_init(adm_ctx* ctx, int rank, int nranks, const void* unique_id128);
+int adm_comm_destroy(adm_ctx* ctx);
+int adm_comm_rank(adm_ctx* ctx);
+int adm_comm_size(adm_ctx* ctx);
+int adm_reduce_scatter(adm_ctx* ctx, const float* send, float* recv, size_t recv_count);
+int adm_all_gather(adm_ctx* ctx, const float* send, float* recv, size_t send_count);
+int adm_all_reduce(adm_ctx* ctx, float* buf, size_t count, int op_max);
+int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root);
+
 /* ---- plan: static geometry + physics of one reconstruction ------------------------- */
 typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;
 typedef enum { ADM_LOSS_LSQ = 0, ADM_LOSS_POISSON = 1 } adm_loss_type;

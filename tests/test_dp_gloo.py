@@ -147,3 +147,100 @@ def test_deferred_update_equals_full_update():
     assert np.array_equal(sp.obj[:n], ref.obj[:n])
     for a, b in zip(sp.moments, ref.moments):
         assert np.array_equal(a[:n], b[:n])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The in-place exchange of the RCCL backend (adorym_amd/dp.py, `inplace`): the reduced shard lands in its slot of the gradient
+# buffer and the updated shard is gathered from its slot of the object.  A stand-in with RcclComm's interface (backend
+# 'rccl', buffers with .view(offset, shape)) runs the SAME DataParallelObject code over gloo on host buffers.
+class HostBuf(object):
+    def __init__(self, a):
+        self.a = a
+        self.size = a.size
+
+    def view(self, off, shape):
+        return HostBuf(self.a[off:off + int(np.prod(shape))])
+
+    def __getitem__(self, k):
+        return self.a[k]
+
+    def __setitem__(self, k, v):
+        self.a[k] = v
+
+
+class HostOps(NumpyOps):
+    def wrap(self, t, n):
+        return t
+
+    def alloc(self, n):
+        return HostBuf(np.zeros(n, np.float32))
+
+    def zero(self, buf):
+        buf.a[...] = 0
+
+    def adam(self, x, g, g_base, m, v, mv_base, lo, hi, *a):
+        NumpyOps.adam(self, x.a, g.a, g_base, m.a, v.a, mv_base, lo, hi, *a)
+
+    def gd(self, x, g, g_base, lo, hi, *a):
+        NumpyOps.gd(self, x.a, g.a, g_base, lo, hi, *a)
+
+
+def _worker_inplace(rank, world, port, shape, seed, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    from adorym_amd.comm import RcclComm
+    from adorym_amd.dp import DataParallelObject
+
+    class GlooAsRccl(RcclComm):          # control plane = the real RcclComm code; data plane = gloo on host buffers
+        def reduce_scatter_sum(self, full, shard_out):
+            t = torch.from_numpy(full.a.copy())
+            self.dist.all_reduce(t)
+            shard_out.a[...] = t.numpy()[self.rank * shard_out.size:(self.rank + 1) * shard_out.size]
+
+        def all_gather(self, full_out, shard_in):
+            parts = [torch.empty(shard_in.size) for _ in range(self.size)]
+            self.dist.all_gather(parts, torch.from_numpy(shard_in.a.copy()))
+            full_out.a[...] = torch.cat(parts).numpy()
+
+    comm = GlooAsRccl()
+    try:
+        st = DataParallelObject(HostOps(), comm, shape)
+        assert st.inplace
+        n = st.n
+        r = np.random.default_rng(seed)
+        st.obj.a[:n] = (r.standard_normal(n) * 1e-3).astype(np.float32)
+        for it in range(3):
+            g_all = [np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world)]
+            st.zero_grad()
+            st.grad.a[:n] += g_all[rank]
+            st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+        seeds = comm.bcast_object(4242 if rank == 0 else None, root=0)
+        comm.barrier()
+        out_q.put((rank, np.array(st.obj.a[:n]), comm.max_over_ranks(rank), comm.sum_over_ranks(1.0), seeds))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize('shape', [(4, 5, 6, 2), (3, 3, 3, 2)])
+def test_inplace_exchange_of_the_rccl_backend_world2(shape):
+    import torch.multiprocessing as mp
+    from oracle import adorym_oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_inplace, args=(r, world, port, shape, 7, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    n = int(np.prod(shape))
+    x = (np.random.default_rng(7).standard_normal(n) * 1e-3).astype(np.float32)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    for it in range(3):
+        g = sum(np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world))
+        x, m, v = O.adam_step(x, g, m, v, it, 1e-4)
+        x = np.clip(x, 0, None)
+    for rank, obj, mx, sm, seed in res:
+        assert np.allclose(obj, x, rtol=2e-6, atol=1e-9)
+        assert (mx, sm, seed) == (world - 1, float(world), 4242)
+    assert np.array_equal(res[0][1], res[1][1])          # every rank holds the same object after the gather

@@ -145,3 +145,44 @@ def test_throughput_kernel_vs_latency_kernel_and_oracle(A, ctx, P, free_prop):
         assert abs(loss - loss64) <= 1e-5 * abs(loss64)
         assert rel(g, g64) < 5e-4
     assert rel(out[1][1], out[0][1]) < 2e-4
+
+
+def test_rccl_comm_world1_equals_local_bitwise(A, ctx):
+    """The multi-GPU code path (adm_comm_init, in-place adm_reduce_scatter / adm_all_gather through RCCL, sharded update) at
+    world size 1 gives bit for bit what the single-GPU path gives after 3 Adam steps and a GD step; the small-gradient
+    all-reduce leaves a 1-rank buffer unchanged."""
+    import socket
+    from adorym_amd import comm as C
+    from adorym_amd.dp import DataParallelObject, HipOps
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    shape = (5, 6, 7, 2)
+    r = cases.rng(9)
+    n = int(np.prod(shape))
+    x0 = (r.standard_normal(n) * 1e-3).astype(np.float32)
+    grads = [r.standard_normal(n).astype(np.float32) for _ in range(4)]
+    rc = C.RcclComm(device_index=0).attach(ctx)
+    try:
+        assert (rc.rank, rc.size) == (0, 1) and ctx.lib.adm_comm_size(ctx.handle) == 1
+        out = []
+        for comm in (C.LocalComm(), rc):
+            st = DataParallelObject(HipOps(ctx), comm, shape)
+            assert st.inplace == (comm is rc)
+            st.obj.view(0, (n,)).set(x0)
+            for it in range(3):
+                st.zero_grad()
+                st.grad.view(0, (n,)).set(grads[it])
+                st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+            st.zero_grad()
+            st.grad.view(0, (n,)).set(grads[3])
+            st.exchange_and_update('gd', 0, {'step_size': 1e-5})
+            out.append((st.obj.view(0, (n,)).get(), st.moments[0].get(), st.moments[1].get()))
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a[:n], b[:n])
+        small = ctx.array(grads[0][:100])
+        rc.all_reduce_device(small)
+        assert np.array_equal(small.get(), grads[0][:100])
+        assert rc.max_over_ranks(3.5) == 3.5 and rc.bcast_object({'a': 1}) == {'a': 1}
+        rc.barrier()
+    finally:
+        rc.close()
