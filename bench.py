@@ -268,7 +268,20 @@ def main():
     # libadm kernels and the RCCL collectives share one stream: the context's own (RcclComm) or torch's (TorchComm)
     ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
     if hasattr(comm, 'attach'):
-        comm.attach(ctx)
+        # all ranks agree on whether the C-ABI communicator came up; if it did not on any of them, every rank falls back
+        # to torch.distributed's nccl backend (same collectives, torch tensors as buffers) instead of failing the run
+        try:
+            comm.attach(ctx)
+            ok = 1.0
+        except Exception as e:
+            sys.stderr.write('bench.py: rank %d: RCCL through the C ABI failed (%r)\n' % (rank, e))
+            ok = 0.0
+        if comm.sum_over_ranks(ok) < world:
+            comm.ctx = None
+            comm.close()                        # leaves the gloo group; TorchComm opens an nccl one on the same rendezvous
+            ctx.close()
+            comm = C.TorchComm('nccl', device_index=local_rank)
+            ctx = A.Context(local_rank, stream=comm.stream_handle())
 
     cfg = W.c3_config()
     B = args.minibatch
