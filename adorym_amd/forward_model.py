@@ -80,6 +80,44 @@ class ForwardModel(object):
                 return i
         raise ValueError('{} is not in the argument list.'.format(arg))
 
+    # ---- the plugin contract's last-layer pieces (adorym/forward_model.py:75-147) -------------------------------------
+    # A forward-model plugin whose predict() returns magnitudes on the HOST combines them with these exactly as the
+    # reference's ForwardModel does.  The built-in models do not go through them: their loss is evaluated inside the
+    # multislice kernel (loss_term, adm_ms_math.h) and the regulariser inside reg_grad_kernel.
+    def get_regularization_value(self, obj, device=None):
+        """Sum of the registered regularisers' values for ``obj`` (DeviceArray [Y,X,Z,2]); adorym/forward_model.py:75-80."""
+        reg = float(self._regularize(obj, None)) if hasattr(self, '_regularize') else 0.0
+        return reg
+
+    def get_mismatch_loss(self, this_pred_batch, this_prj_batch):
+        """LSQ / Poisson mismatch of predicted magnitudes and measured data (host arrays), adorym/forward_model.py:88-103."""
+        pred = np.asarray(this_pred_batch, dtype=np.float32)
+        meas = np.abs(np.asarray(this_prj_batch)).astype(np.float32)
+        pm = np.float32(getattr(self, 'poisson_multiplier', None) or 1.)
+        if self.loss_function_type == 'lsq':
+            if self.raw_data_type == 'intensity':
+                meas = np.sqrt(meas)
+            return np.mean((pred - meas) ** 2)
+        if self.raw_data_type == 'magnitude':
+            meas = meas ** 2
+        return np.mean(pred ** 2 * pm - meas * pm * np.log(pred ** 2 * pm))
+
+    def loss(self, this_pred_batch, this_prj_batch, obj):
+        """(Regularised) loss from predicted MAGNITUDES, with the beamstop selection of adorym/forward_model.py:121-147;
+        stores ``current_loss``."""
+        pred = np.asarray(this_pred_batch)
+        meas = np.asarray(this_prj_batch)
+        beamstop = self.common_vars.get('beamstop') if self.common_vars else None
+        if beamstop is not None:
+            keep = np.asarray(beamstop) >= 1e-5
+            pred = pred[:, keep]
+            meas = meas[:, keep]
+        val = float(self.get_mismatch_loss(pred, meas))
+        if len(self.reg_list) > 0:
+            val += float(self.get_regularization_value(obj, device=self.device))
+        self.current_loss = val
+        return val
+
     def get_data(self, this_i_theta, this_ind_batch, theta_downsample=None, ds_level=1):
         """abs(prj[i_theta*theta_downsample, ind_batch]) (forward_model.py:113-119); sqrt of it for intensity
         data (the sqrt of get_mismatch_loss, :92-93, folded in here).  Returns a float32 host array."""

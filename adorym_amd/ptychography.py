@@ -26,6 +26,7 @@ from . import _lib
 from . import global_settings
 from .array_ops import ObjectFunction, Gradient, Mask
 from .comm import LocalComm, from_env
+from .util import epoch_task_list, rank_batch
 from .constants import PI
 from .device import Context
 from .differentiator import Differentiator
@@ -71,17 +72,108 @@ def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_nam
             pickle.dump(params, f_pcp)
 
 
-def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks=1):
-    """adorym/misc.py:197-211.  Returns (i_epoch, i_batch, obj [Y,X,Z,2], moments or None)."""
+def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks=1, obj_shape=None, shard_size=None):
+    """adorym/misc.py:197-211 + load_params_checkpoint (adorym/ptychography.py:462).  Everything is read and shape-checked
+    BEFORE anything is returned, so a partial checkpoint cannot leave a run half restored.
+    Returns (i_epoch, i_batch, obj [Y,X,Z,2], moments or None, params dict or None)."""
+    import pickle
     path = os.path.join(output_folder, 'checkpoint')
     i_epoch, i_batch = [int(i) for i in np.loadtxt(os.path.join(path, 'checkpoint.txt'))]
     obj = np.load(os.path.join(path, 'obj_checkpoint.npy'))
+    if obj_shape is not None and tuple(obj.shape) != tuple(obj_shape):
+        raise ValueError('obj_checkpoint.npy has shape %s, expected %s' % (obj.shape, tuple(obj_shape)))
     mom = None
     if n_moments > 0:
         f1 = os.path.join(path, 'opt_{}_params_checkpoint.npy'.format(opt_name))
         fr = os.path.join(path, 'opt_{}_params_checkpoint_rank_{}.npy'.format(opt_name, rank))
         mom = np.load(f1 if n_ranks == 1 else fr)
-    return i_epoch, i_batch, obj, mom
+        if len(mom) != n_moments:
+            raise ValueError('optimizer checkpoint holds %d moment arrays, expected %d' % (len(mom), n_moments))
+        if n_ranks > 1 and shard_size is not None and mom[0].size != shard_size:
+            raise ValueError('optimizer checkpoint shard has %d elements, expected %d (written with another rank count?)'
+                             % (mom[0].size, shard_size))
+    params = None
+    fp = os.path.join(path, 'params_{}'.format(rank))
+    if os.path.exists(fp):
+        with open(fp, 'rb') as f_pcp:
+            params = pickle.load(f_pcp)
+    return i_epoch, i_batch, obj, mom, params
+
+
+_SUMMARY_VARS = ('obj_size probe_size output_folder theta_downsample n_theta n_epochs learning_rate alpha_d alpha_b gamma n_dp_batch '
+                 'minibatch_size free_prop_cm psize_cm energy_ev fname cpu_only optimizer probe_mag_sigma probe_phase_sigma '
+                 'probe_phase_max probe_learning_rate probe_type optimize_probe_defocusing probe_defocusing_learning_rate '
+                 'optimizer_probe_defocusing optimize_all_probe_pos all_probe_pos_learning_rate optimizer_all_probe_pos '
+                 'optimize_probe_pos_offset probe_pos_offset_learning_rate optimizer_probe_pos_offset shared_file_object '
+                 'reweighted_l1 initial_guess binning').split()
+
+
+def create_summary(save_path, values, verbose=True):
+    """summary.txt of a run (adorym/misc.py:149-176, preset 'ptycho'): one '{:<30}{}' line per reported parameter; a
+    learning rate is left out when a ready-made optimiser object was passed for that parameter, names that do not exist
+    in this run are skipped (the reference's bare except)."""
+    os.makedirs(save_path, exist_ok=True)
+    lines = []
+    for name in _SUMMARY_VARS:
+        if name == 'learning_rate' and values.get('optimizer') is not None and not isinstance(values.get('optimizer'), str):
+            continue
+        if name.endswith('_learning_rate') and values.get('optimizer_' + name[:-14]) is not None:
+            continue
+        if name not in values:
+            continue
+        v = values[name]
+        if name == 'fname' and not isinstance(v, str):
+            v = '<array %s>' % (np.shape(v),)
+        lines.append('{:<30}{}\n'.format(name, str(v)))
+    with open(os.path.join(save_path, 'summary.txt'), 'w') as f_sum:
+        f_sum.writelines(lines)
+    if verbose:
+        print('============== PARAMETERS ==============')
+        print(''.join(lines))
+        print('========================================')
+
+
+def _write_intermediate(output_folder, arr, unknown_type, i_epoch, i_batch, save_history, opt_ls, probe_dev, params, n_theta,
+                        is_multi_dist):
+    """output_object(full_output=False) + output_intermediate_parameters of the reference: object TIFFs under
+    intermediate/object (named by (epoch, batch) when save_history, else overwritten), and one file set per optimised
+    parameter under intermediate/<what>."""
+    tag = '_{}_{}'.format(i_epoch, i_batch) if save_history else ''
+    od = os.path.join(output_folder, 'intermediate', 'object')
+    os.makedirs(od, exist_ok=True)
+    if unknown_type == 'delta_beta':
+        write_tiff(arr[..., 0], os.path.join(od, 'delta' + tag), dtype='float32')
+        write_tiff(arr[..., 1], os.path.join(od, 'beta' + tag), dtype='float32')
+    else:
+        write_tiff(np.sqrt(arr[..., 0] ** 2 + arr[..., 1] ** 2), os.path.join(od, 'obj_mag' + tag), dtype='float32')
+        write_tiff(np.arctan2(arr[..., 1], arr[..., 0]), os.path.join(od, 'obj_phase' + tag), dtype='float32')
+    host = lambda v: v.get() if hasattr(v, 'get') else np.asarray(v)
+    for o_ in opt_ls:
+        if o_.name == 'obj':
+            continue
+        if o_.name == 'probe':
+            pd_ = os.path.join(output_folder, 'intermediate', 'probe')
+            os.makedirs(pd_, exist_ok=True)
+            pa = probe_dev.get()
+            write_tiff(np.sqrt(pa[..., 0] ** 2 + pa[..., 1] ** 2), os.path.join(pd_, 'probe_mag' + tag), dtype='float32')
+            write_tiff(np.arctan2(pa[..., 1], pa[..., 0]), os.path.join(pd_, 'probe_phase' + tag), dtype='float32')
+        elif o_.name == 'probe_pos_correction':
+            pd_ = os.path.join(output_folder, 'intermediate', 'probe_pos')
+            os.makedirs(pd_, exist_ok=True)
+            corr = host(params['probe_pos_correction'])
+            if is_multi_dist:
+                np.savetxt(os.path.join(pd_, 'probe_pos_correction_{}_{}.txt'.format(i_epoch, i_batch)), corr)
+            else:
+                for i_t in range(n_theta):
+                    np.savetxt(os.path.join(pd_, 'probe_pos_correction_{}_{}_{}.txt'.format(i_epoch, i_batch, i_t)), corr[i_t])
+        elif o_.name == 'prj_affine_ls':
+            pd_ = os.path.join(output_folder, 'intermediate', 'prj_affine')
+            os.makedirs(pd_, exist_ok=True)
+            np.savetxt(os.path.join(pd_, 'prj_affine_{}.txt'.format(i_epoch)), np.concatenate(host(params['prj_affine_ls']), 0))
+        else:
+            pd_ = os.path.join(output_folder, 'intermediate', o_.name)
+            os.makedirs(pd_, exist_ok=True)
+            np.savetxt(os.path.join(pd_, '{}_{}.txt'.format(o_.name, i_epoch)), np.atleast_1d(host(params[o_.name])))
 
 
 def _not_implemented(cond, what):
@@ -151,6 +243,8 @@ def reconstruct_ptychography(
     ``backend`` accepts 'hip' (and, for script compatibility, the reference's 'pytorch' / 'autograd' names,
     which are mapped to 'hip' with a warning).
     """
+    _call_args = dict(locals())         # the keyword surface as called (for summary.txt); first statement on purpose
+    _call_args.update(_call_args.pop('kwargs', {}))
     t_zero = time.time()
     comm = kwargs.pop('comm', None) or from_env()
     return_state = kwargs.pop('return_state', False)
@@ -353,20 +447,34 @@ def reconstruct_ptychography(
     obj.arr.set(init)
     del init
     # ---- checkpoint restore (ptychography.py:458-487) ----
+    # Read into temporaries, agree across ranks, then commit: either every rank resumes from the same (epoch, batch) or
+    # none does (the reference broadcasts rank 0's counters, :485-487).  The other optimisable parameters of the
+    # checkpoint (probe, position corrections, distances, affine matrices) are applied once they exist, further down.
     starting_epoch, starting_batch = 0, 0
+    restored_params = None
     if use_checkpoint:
+        loaded, why = None, ''
         try:
-            starting_epoch, starting_batch, obj_arr, mom = restore_checkpoint(output_folder, len(state.moments), rank=rank,
-                                                                              n_ranks=n_ranks)
+            loaded = restore_checkpoint(output_folder, len(state.moments), rank=rank, n_ranks=n_ranks,
+                                        obj_shape=(*this_obj_size, 2), shard_size=state.per)
+        except Exception as e:       # missing / partial / mismatching checkpoint
+            why = repr(e)
+        all_ok = comm.sum_over_ranks(1.0 if loaded is not None else 0.0) >= n_ranks
+        if all_ok:
+            counters = comm.bcast_object((loaded[0], loaded[1]), root=0)
+            all_ok = comm.sum_over_ranks(1.0 if counters == (loaded[0], loaded[1]) else 0.0) >= n_ranks
+        if all_ok:
+            starting_epoch, starting_batch, obj_arr, mom, restored_params = loaded
             obj.arr.set(obj_arr)
             for k_, m_ in enumerate(state.moments):
                 m_.set(np.ascontiguousarray(mom[k_]).reshape(-1)[:m_.size] if n_ranks == 1 else mom[k_])
             print_flush('Resuming from checkpoint: epoch {}, batch {}.'.format(starting_epoch, starting_batch), sto_rank, rank,
                         **stdout_options)
-        except Exception:
+        else:
+            msg = 'Checkpoint not used ({}); starting from epoch 0.'.format(why or 'another rank could not restore, or the ranks disagree')
             if force_to_use_checkpoint:
-                raise
-            starting_epoch, starting_batch = 0, 0
+                raise RuntimeError(msg)
+            print_flush(msg, sto_rank, rank, **stdout_options)
     gradient = Gradient(obj)
     gradient.arr = state.grad.view(0, (*this_obj_size, 2))
 
@@ -516,6 +624,32 @@ def reconstruct_ptychography(
         opt_ls.append(opt_probe_pos)
         pos_grad_dev = ctx.zeros(corr_shape)
 
+    # ---- the checkpoint's other parameters (load_params_checkpoint, adorym/ptychography.py:462) ----
+    def params_to_host():
+        """optimizable_params under the reference's keys, as host arrays (what the reference pickles into params_{rank})."""
+        pa_ = probe_dev.get()
+        out_ = {'probe_real': pa_[..., 0], 'probe_imag': pa_[..., 1]}
+        for k_, v_ in optimizable_params.items():
+            if k_ in ('probe_real', 'probe_imag'):
+                continue
+            out_[k_] = v_.get() if hasattr(v_, 'get') else v_
+        return out_
+
+    if restored_params is not None:
+        if 'probe_real' in restored_params and 'probe_imag' in restored_params:
+            pr_ = np.stack([np.asarray(restored_params['probe_real']), np.asarray(restored_params['probe_imag'])], -1)
+            if pr_.shape != probe_dev.shape:
+                raise ValueError('checkpointed probe has shape %s, this run uses %s' % (pr_.shape[:-1], probe_dev.shape[:-1]))
+            probe_dev.set(pr_.astype(np.float32))
+        for k_ in ('probe_pos_correction', 'free_prop_cm', 'prj_affine_ls', 'probe_defocus_mm', 'probe_pos_offset', 'prj_pos_offset',
+                   'tilt_ls'):
+            if k_ in restored_params and k_ in optimizable_params:
+                cur_ = optimizable_params[k_]
+                if hasattr(cur_, 'set'):
+                    cur_.set(np.asarray(restored_params[k_], dtype=np.float32).reshape(cur_.shape))
+                else:
+                    optimizable_params[k_] = restored_params[k_]
+
     diff = Differentiator()
     calculate_loss = forward_model.get_loss_function()
     diff.create_loss_node(calculate_loss, opt_args_ls)
@@ -525,6 +659,9 @@ def reconstruct_ptychography(
     comm.barrier()
     f_conv = open(os.path.join(output_folder, 'convergence', 'loss_rank_{}.txt'.format(rank)), 'w')
     f_conv.write('i_epoch,i_batch,loss,time\n')
+    if rank == 0:       # adorym/ptychography.py:776 -> misc.py:149-176
+        create_summary(output_folder, dict(_call_args, output_folder=output_folder, probe_size=list(probe_size), n_theta=n_theta,
+                                           obj_size=list(this_obj_size)), verbose=False)
     print_flush('Optimizer started.', sto_rank, rank, **stdout_options)
     if probe_update_limit is None:
         probe_update_limit = np.inf
@@ -554,30 +691,9 @@ def reconstruct_ptychography(
     while cont:
         t0 = time.time()
         n_tot_per_batch = minibatch_size * n_ranks
-        np.random.seed(i_epoch)
-        if not two_d_mode:
-            theta_ind_ls = np.arange(n_theta)
-            np.random.shuffle(theta_ind_ls)
-        else:
-            temp = abs(theta_ls - theta_ls[0]) < 1e-5
-            theta_ind_ls = np.array([np.nonzero(temp)[0][0]])
-        ind_list_rand = None
-        for i, i_theta in enumerate(theta_ind_ls):
-            n_pos = len(probe_pos)
-            spots_ls = range(n_pos)
-            if randomize_probe_pos:
-                spots_ls = np.random.choice(spots_ls, len(spots_ls), replace=False)
-            if update_scheme == 'immediate' and n_pos % minibatch_size != 0:
-                spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % minibatch_size],
-                                                                minibatch_size - (n_pos % minibatch_size), replace=False))
-            elif update_scheme == 'per angle' and n_pos % n_tot_per_batch != 0:
-                spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % n_tot_per_batch],
-                                                                n_tot_per_batch - (n_pos % n_tot_per_batch), replace=False))
-            if i == 0:
-                ind_list_rand = np.zeros([len(theta_ind_ls) * len(spots_ls), 2], dtype='int32')
-            temp = np.stack([np.array([i_theta] * len(spots_ls)), spots_ls], axis=1)
-            ind_list_rand[i * len(spots_ls):(i + 1) * len(spots_ls), :] = temp
-        ind_list_rand = split_tasks(ind_list_rand, n_tot_per_batch)
+        ind_list_rand = epoch_task_list(i_epoch, n_theta, len(probe_pos), minibatch_size, n_ranks, update_scheme=update_scheme,
+                                        randomize_probe_pos=randomize_probe_pos,
+                                        fixed_theta=(int(np.nonzero(abs(theta_ls - theta_ls[0]) < 1e-5)[0][0]) if two_d_mode else None))
         n_batch = len(ind_list_rand)
         i_opt_batch = starting_epoch * n_batch + starting_batch      # (:848), re-evaluated every epoch like the reference
         initialize_gradients = True
@@ -593,22 +709,19 @@ def reconstruct_ptychography(
                 state.finish_update()
                 host_obj = obj.arr.get() if rank == 0 else None
                 host_mom = [m_.get() for m_ in state.moments] if (rank == 0 or n_ranks > 1) else []
-                pk = {'probe': probe_dev.get()} if rank == 0 or True else None
+                pk = params_to_host()       # the reference pickles the whole optimizable_params dict (misc.py:179-194)
                 _ckpt_thread[0] = threading.Thread(target=save_checkpoint, args=(i_epoch, i_batch, output_folder, host_obj, host_mom),
                                                    kwargs=dict(rank=rank, n_ranks=n_ranks, params=pk))
                 _ckpt_thread[0].start()
             t_elapsed = (time.time() - t_zero) / 60
+            if t_max_min is not None and n_ranks > 1:
+                t_elapsed = comm.bcast_object(t_elapsed, root=0)     # one decision for all ranks: nobody is left in a collective
             if t_max_min is not None and t_elapsed >= t_max_min:
                 print_flush('Terminating program because maximum time limit is reached.', sto_rank, rank, **stdout_options)
                 sys.exit()
             print_flush('Epoch {}, batch {} of {} started.'.format(i_epoch, i_batch, n_batch), sto_rank, rank, **stdout_options)
             t00 = time.time()
-            if len(ind_list_rand[i_batch]) < n_tot_per_batch:
-                n_supp = n_tot_per_batch - len(ind_list_rand[i_batch])
-                ind_list_rand[i_batch] = np.concatenate([ind_list_rand[i_batch], ind_list_rand[0][:n_supp]])
-            this_ind_batch_allranks = ind_list_rand[i_batch]
-            this_i_theta = int(this_ind_batch_allranks[rank * minibatch_size, 0])
-            this_ind_batch = np.sort(this_ind_batch_allranks[rank * minibatch_size:(rank + 1) * minibatch_size, 1])
+            this_i_theta, this_ind_batch = rank_batch(ind_list_rand, i_batch, rank, minibatch_size, n_ranks)
             this_pos_batch = probe_pos_int[this_ind_batch]
             is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != this_i_theta
             print_flush('  Current rank is processing angle ID {}.'.format(this_i_theta), sto_rank, rank, **stdout_options)
@@ -741,6 +854,14 @@ def reconstruct_ptychography(
                 if opt_prj_affine is not None:
                     # "regularize transformation of image 0": matrix 0 is pinned to the identity
                     _lib.check(ctx.lib.adm_d2d(ctx.handle, optimizable_params['prj_affine_ls'].ptr, affine_identity_dev.ptr, 6 * 4))
+
+            # ---- intermediate output (ptychography.py:1231-1246; util.py:1958-2028, optimizers.py:1111-1160) ----
+            if save_intermediate and ((save_intermediate_level == 'epoch' and i_batch == n_batch - 1) or save_intermediate_level == 'batch'):
+                if rank == 0 and is_last_batch_of_this_theta:
+                    state.finish_update()
+                    _write_intermediate(output_folder, obj.arr.get(), unknown_type, i_epoch, i_batch, save_history, opt_ls,
+                                        probe_dev, optimizable_params, n_theta, is_multi_dist)
+                comm.barrier()
 
             # ---- finishing a batch (ptychography.py:1231-1271) ----
             this_log = (i_epoch, i_batch, forward_model.take_loss_thunk() if builtin_model else (lambda v=forward_model.current_loss: v), t00)

@@ -187,3 +187,47 @@ def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0, staged=Fal
     lsrc = np.where(too_big[blk], 0, (zs - z0[blk]) * bw[blk] + (xs - x0[blk]))
     boxes = np.stack([x0, z0, bw, bh], -1).astype(np.int32)
     return ptr.astype(np.int32), sr.astype(np.int32), lsrc.astype(np.uint16), ww.astype(np.float32), boxes
+
+
+def epoch_task_list(i_epoch, n_theta, n_pos, minibatch_size, n_ranks=1, update_scheme='immediate', randomize_probe_pos=False,
+                    fixed_theta=None):
+    """The (i_theta, i_pos) task list of one epoch, split into global batches of n_ranks * minibatch_size pairs
+    (adorym/ptychography.py:791-847, split_tasks util.py:1629-1635).  Same legacy-RNG draw order as the reference
+    (np.random.seed(i_epoch); shuffle of the angle indices; the permutation that pads the positions of an angle to a
+    multiple of the batch), so the batches are the reference's bit for bit.  ``fixed_theta``: two_d_mode's single angle."""
+    n_tot_per_batch = minibatch_size * n_ranks
+    np.random.seed(i_epoch)
+    if fixed_theta is None:
+        theta_ind_ls = np.arange(n_theta)
+        np.random.shuffle(theta_ind_ls)
+    else:
+        theta_ind_ls = np.array([fixed_theta])
+    ind_list_rand = None
+    for i, i_theta in enumerate(theta_ind_ls):
+        spots_ls = range(n_pos)
+        if randomize_probe_pos:
+            spots_ls = np.random.choice(spots_ls, len(spots_ls), replace=False)
+        if update_scheme == 'immediate' and n_pos % minibatch_size != 0:
+            spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % minibatch_size],
+                                                            minibatch_size - (n_pos % minibatch_size), replace=False))
+        elif update_scheme == 'per angle' and n_pos % n_tot_per_batch != 0:
+            spots_ls = np.append(spots_ls, np.random.choice(spots_ls[:-n_pos % n_tot_per_batch],
+                                                            n_tot_per_batch - (n_pos % n_tot_per_batch), replace=False))
+        if i == 0:
+            ind_list_rand = np.zeros([len(theta_ind_ls) * len(spots_ls), 2], dtype='int32')
+        temp = np.stack([np.array([i_theta] * len(spots_ls)), spots_ls], axis=1)
+        ind_list_rand[i * len(spots_ls):(i + 1) * len(spots_ls), :] = temp
+    return split_tasks(ind_list_rand, n_tot_per_batch)
+
+
+def rank_batch(ind_list_rand, i_batch, rank, minibatch_size, n_ranks=1):
+    """What rank ``rank`` processes in global batch ``i_batch`` (adorym/ptychography.py:897-908): a short last batch is
+    topped up from the first one (in place, like the reference), the rank takes pairs [rank*mb, (rank+1)*mb), all of one
+    angle, position indices sorted.  Returns (i_theta, sorted position indices)."""
+    n_tot_per_batch = minibatch_size * n_ranks
+    if len(ind_list_rand[i_batch]) < n_tot_per_batch:
+        n_supp = n_tot_per_batch - len(ind_list_rand[i_batch])
+        ind_list_rand[i_batch] = np.concatenate([ind_list_rand[i_batch], ind_list_rand[0][:n_supp]])
+    b = ind_list_rand[i_batch]
+    i_theta = int(b[rank * minibatch_size, 0])
+    return i_theta, np.sort(b[rank * minibatch_size:(rank + 1) * minibatch_size, 1])

@@ -244,3 +244,34 @@ def test_inplace_exchange_of_the_rccl_backend_world2(shape):
         assert np.allclose(obj, x, rtol=2e-6, atol=1e-9)
         assert (mx, sm, seed) == (world - 1, float(world), 4242)
     assert np.array_equal(res[0][1], res[1][1])          # every rank holds the same object after the gather
+
+
+def test_product_task_split_matches_reference_golden_both_ranks():
+    """The DRIVER's own task-list code (adorym_amd/util.py epoch_task_list / rank_batch, called by reconstruct_ptychography)
+    against golden F8 captured from the reference for 1 and 2 ranks (adorym/ptychography.py:791-847, 897-908), and rank 1's
+    share against the reference rule."""
+    sys.path.insert(0, ROOT)
+    from adorym_amd.util import epoch_task_list, rank_batch
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'F8_tasks.npz'))
+    n_theta, n_pos, mb = 5, 7, 3
+    for n_ranks in (1, 2):
+        seen_theta, seen_ind = [], []
+        for e in (0, 1):
+            batches = epoch_task_list(e, n_theta, n_pos, mb, n_ranks)
+            assert len(batches) == int(g['r%d_e%d_ntask' % (n_ranks, e)])
+            for k, b in enumerate(batches):
+                assert np.array_equal(b, g['r%d_e%d_task_%d' % (n_ranks, e, k)])
+            for k in range(len(batches)):
+                th, ind = rank_batch(batches, k, 0, mb, n_ranks)
+                seen_theta.append(th); seen_ind.append(ind)
+                if n_ranks == 2:
+                    full = batches[k]
+                    assert len(full) == 2 * mb                      # topped up in place by rank_batch
+                    th1, ind1 = rank_batch(batches, k, 1, mb, n_ranks)
+                    assert th1 == full[mb, 0] and np.array_equal(ind1, np.sort(full[mb:2 * mb, 1]))
+                    assert len(set(full[mb:, 0])) == 1              # all of a rank's pairs share one angle
+        assert np.array_equal(np.array(seen_theta), g['r%d_rank0_theta' % n_ranks])
+        assert np.array_equal(np.stack(seen_ind), g['r%d_rank0_ind' % n_ranks])
+    # config 3's padded minibatch is the deterministic set SURVEY R17 describes
+    last = epoch_task_list(0, 2, 529, 32, 1)[16]
+    assert sorted(last[:, 1].tolist()) == list(range(0, 15)) + list(range(512, 529))
