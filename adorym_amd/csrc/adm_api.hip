@@ -318,12 +318,14 @@ extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
 
 extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
     if (!plan || batch <= 0) return 0;
-    // [stash: B*M*per | tile gradients: B*per | cover lists (Yp*Xp*(1+64) u32) + overflow flag | detector fields: B*M*G*NT]
+    // [stash: B*M*per | tile gradients: B*per | cover lists (Yp*Xp*(1+64) u32) + overflow flag | detector fields: B*M*G*NT |
+    //  per-position probe gradients: B*M*Py*Px]
     const size_t per = adm::ms_ws_per_pos(plan) * sizeof(float2);
     const int N = plan->d.probe_x;
     const int G = ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N);
     const size_t det = plan->d.n_modes > 1 ? (size_t)batch * plan->d.n_modes * G * ms_threads_for(N) * sizeof(float2) : 0;
-    return (size_t)batch * (plan->d.n_modes + 1) * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64 + det;
+    const size_t gpp = (size_t)batch * plan->d.n_modes * N * N * sizeof(float2);
+    return (size_t)batch * (plan->d.n_modes + 1) * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64 + det + gpp;
 }
 
 namespace adm {
@@ -334,6 +336,12 @@ size_t ms_ws_per_pos(const adm_plan* plan) {
 size_t ws_off_gtile(const adm_plan* plan, int batch) { return (size_t)batch * plan->d.n_modes * ms_ws_per_pos(plan) * sizeof(float2); }
 size_t ws_off_cover(const adm_plan* plan, int batch) { return ws_off_gtile(plan, batch) + (size_t)batch * ms_ws_per_pos(plan) * sizeof(float2); }
 size_t ws_off_det(const adm_plan* plan, int batch) { return ws_off_cover(plan, batch) + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64; }
+size_t ws_off_gprobe(const adm_plan* plan, int batch) {
+    const int N = plan->d.probe_x;
+    const int G = ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N);
+    const size_t det = plan->d.n_modes > 1 ? (size_t)batch * plan->d.n_modes * G * ms_threads_for(N) * sizeof(float2) : 0;
+    return ws_off_det(plan, batch) + det;
+}
 }  // namespace adm
 
 static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
@@ -385,16 +393,21 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
     p.poisson_mult = d.poisson_multiplier;
     p.real_imag = d.unknown_type;
     p.det_weight = plan->det_weight_dev;
+    const size_t probe_elems = (size_t)d.n_modes * d.probe_y * d.probe_x;
     if (per_position) {
         if (d.binning != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: binning > 1 is not implemented with per-position probes");
-        p.probe_bstride = p.gprobe_bstride = (size_t)d.n_modes * d.probe_y * d.probe_x;
-        if (grad_probe && want_grad)
-            ADM_HIP(hipMemsetAsync(grad_probe, 0, (size_t)batch * p.gprobe_bstride * sizeof(float2), plan->ctx->stream));
+        p.probe_bstride = p.gprobe_bstride = probe_elems;       // every position stores its own gradient slot
+    } else if (grad_probe && want_grad) {
+        // shared probe: per-position slots in the workspace, summed in a fixed order into grad_probe after the launch
+        p.grad_probe = (float2*)((char*)workspace + ws_off_gprobe(plan, batch));
+        p.gprobe_bstride = probe_elems;
     }
     const bool lean = plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
                       d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
     if (lean) ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
     else ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    if (!per_position && grad_probe && want_grad)
+        ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
     return ADM_OK;
 }
 

@@ -88,6 +88,8 @@ size_t ms_ws_per_pos(const adm_plan* plan);   // float2 elements of one position
 size_t ws_off_gtile(const adm_plan* plan, int batch);
 size_t ws_off_cover(const adm_plan* plan, int batch);
 size_t ws_off_det(const adm_plan* plan, int batch);
+size_t ws_off_gprobe(const adm_plan* plan, int batch);
+hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* out, hipStream_t st);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 bool ms_lean_supported(int n);

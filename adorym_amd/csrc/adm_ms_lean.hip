@@ -369,12 +369,10 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT), 6) void ms_lean_kernel(MsPara
         }
     }
     if (p.grad_probe && c.act1) {
+        // this position's own slot (plain stores); probe_grad_reduce_kernel sums the slots in a fixed order
+        float2* gp = p.grad_probe + (size_t)b * p.gprobe_bstride + line * N + t;
 #pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            float* gp = reinterpret_cast<float*>(p.grad_probe + line * N + k * R2 + t);
-            atomicAdd(gp, a[k].x);
-            atomicAdd(gp + 1, a[k].y);
-        }
+        for (int k = 0; k < R1; ++k) gp[k * R2] = a[k];
     }
 }
 

@@ -192,13 +192,20 @@ __device__ __forceinline__ void load_probe(const Ctx<N, R1, R2>& c, cf (&a)[R1],
 }
 
 template <int N, int R1, int R2>
-__device__ __forceinline__ void add_probe_grad(const Ctx<N, R1, R2>& c, const cf (&a)[R1], float2* grad_probe) {
+__device__ __forceinline__ void add_probe_grad(const Ctx<N, R1, R2>& c, const cf (&a)[R1], float2* grad_probe, bool own_slot) {
     if (grad_probe && c.act1) {
+        if (own_slot) {
+            // this position's own [Py][Px] slot: plain stores; the slots are summed in a fixed order afterwards
+            // (probe_grad_reduce_kernel), so the probe gradient is bit-reproducible like the object gradient
 #pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            float* gp = reinterpret_cast<float*>(grad_probe + c.line * N + k * R2 + c.t);
-            atomicAdd(gp, a[k].x);
-            atomicAdd(gp + 1, a[k].y);
+            for (int k = 0; k < R1; ++k) grad_probe[c.line * N + k * R2 + c.t] = a[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                float* gp = reinterpret_cast<float*>(grad_probe + c.line * N + k * R2 + c.t);
+                atomicAdd(gp, a[k].x);
+                atomicAdd(gp + 1, a[k].y);
+            }
         }
     }
 }
@@ -464,7 +471,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
         rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
-        add_probe_grad<N, R1, R2>(c, a, (PP && p.grad_probe) ? p.grad_probe + (size_t)b * p.gprobe_bstride : p.grad_probe);
+        add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr, p.gprobe_bstride != 0);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
         // pred = sqrt(sum_m |Psi_m|^2): the detector-plane fields of all modes are parked in HBM (thread-native
@@ -540,7 +547,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
             detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
             if (m == 0) rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
             else rev_sweep<N, R1, R2, BIN1, true, RI>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
-            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (PP ? (size_t)b * p.gprobe_bstride : 0) + (size_t)m * N * N : nullptr);
+            add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride + (size_t)m * N * N : nullptr,
+                                      p.gprobe_bstride != 0);
         }
     }
 }
@@ -683,7 +691,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
             }
         }
         ifft2_from_regs<N, R1, R2>(c, bg, a);
-        add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr);
+        add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr, false);
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #pragma unroll

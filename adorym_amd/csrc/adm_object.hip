@@ -424,6 +424,23 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float2* __restrict_
     }
 }
 
+// out[i] += sum_b part[b][i], b ascending: the per-position probe gradients of a launch, summed deterministically
+__global__ __launch_bounds__(256) void probe_grad_reduce_kernel(const float2* __restrict__ part, int batch, size_t n, float2* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float2 acc = out[i];
+    for (int b = 0; b < batch; ++b) {
+        const float2 v = part[(size_t)b * n + i];
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    out[i] = acc;
+}
+hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* out, hipStream_t st) {
+    hipLaunchKernelGGL(probe_grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, batch, n, out);
+    return hipGetLastError();
+}
+
 // *out += sum(partial[0..n)) in a fixed order (one block)
 __global__ __launch_bounds__(1024) void reg_value_reduce_kernel(const float* __restrict__ partial, int n, float* out) {
     __shared__ float red[16];

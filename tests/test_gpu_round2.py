@@ -186,3 +186,32 @@ def test_rccl_comm_world1_equals_local_bitwise(A, ctx):
         rc.barrier()
     finally:
         rc.close()
+
+
+@pytest.mark.parametrize('lean', [0, 1])
+def test_probe_gradient_is_bitwise_reproducible(A, ctx, lean):
+    """the probe gradient was accumulated with float atomics.  Every position now stores its own slot and the
+    slots are summed in a fixed order: two launches on the same inputs agree bit for bit, and the sum over a batch equals
+    the sum of its two halves launched separately (+=) to fp32 rounding."""
+    r = cases.rng(21)
+    P, Y, X, S, B = 72, 100, 110, 6, 40
+    pos = np.stack([r.integers(-8, Y - 60, B), r.integers(-8, X - 60, B)], 1)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
+    eng.plan.set_lean_min_batch(lean)
+    obj = ctx.array(np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1).astype(np.float32))
+    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
+    meas = (np.abs(r.standard_normal((B, P, P))) * 20).astype(np.float32)
+    eng.rotate(obj, None)
+    outs = []
+    for rep in range(2):
+        eng.set_batch(pos, meas)
+        gp = ctx.zeros(probe.shape)
+        eng.multislice(probe, grad_probe=gp)
+        outs.append(gp.get())
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.abs(outs[0]).max() > 0
+    gp = ctx.zeros(probe.shape)
+    for half in (slice(0, B // 2), slice(B // 2, B)):
+        eng.set_batch(pos[half], meas[half])
+        eng.multislice(probe, grad_probe=gp, grad_scale=2.0 / (B * P * P))
+    assert np.abs(gp.get() - outs[0]).max() <= 2e-6 * np.abs(outs[0]).max()
