@@ -444,3 +444,75 @@ def test_real_imag_overhanging_tiles_vs_oracle(A, ctx):
     loss = eng.loss_and_grad(ctx.array(obj, np.float32), d_grad, None, ctx.array(c2(probe)), pos, target)
     assert abs(loss - loss_o) <= 1e-5 * abs(loss_o)
     assert rel(d_grad.get(), g_o) < 1e-4
+
+
+@pytest.mark.parametrize('theta', [0.4, 0.7953982])
+def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta):
+    """BASELINE's config 3 at FULL size on the GPU -- 256^3 object, 72x72 probe, 256 slices, rotation by theta (0.4 rad
+    and a 45-degree-class angle), L1 + TV -- against the fp64 oracle, gradient judged on the footprint planes under the
+    3x rule measured against the REFERENCE-STRUCTURED fp32 restatement (oracle/torch_structured.py, bit-identical to
+    the reference's PyTorch-CPU path).  Rotation about axis 0 acts on every y plane separately, so the CPU checkers work
+    on the slab of planes the minibatch touches (+1 plane each side for the TV stencil); the minibatch is 6 positions of
+    the scan (two rows of the 23x23 grid) instead of 32 to keep the fp64 / autograd CPU work near a minute per angle --
+    the batch size only enters through the 2/(B*Py*Px) factor."""
+    from oracle import torch_structured as T
+    from adorym_amd.util import rotation_lookup
+    N, P = 256, 72
+    theta = np.float32(theta)
+    ys = np.arange(23) * 12 - 36
+    allpos = np.array([(y, x) for y in ys for x in ys])
+    sel = [11 * 23 + 0, 11 * 23 + 7, 11 * 23 + 22, 12 * 23 + 3, 12 * 23 + 12, 12 * 23 + 19]      # rows y = 96 and 108, x from -36 to 228
+    pos = allpos[sel]
+    y_lo, y_hi = int(pos[:, 0].min()), int(pos[:, 0].max()) + P          # footprint planes [96, 180)
+    s0, s1 = y_lo - 1, y_hi + 1                                           # slab for the CPU checkers
+    r = cases.rng(61)
+    shp = (s1 - s0, N, N)
+    truth = np.stack([3e-4 * cases.smooth_field(shp, 71, cutoff=0.12), 1.5e-5 * cases.smooth_field(shp, 72, cutoff=0.12)], -1)
+    guess = np.stack([3e-4 * cases.smooth_field(shp, 73, cutoff=0.12), 1.5e-5 * cases.smooth_field(shp, 74, cutoff=0.12)], -1)
+    guess = 0.6 * truth + 0.4 * guess
+    coords = rotation_lookup((N, N, N), theta)
+    cfgp = dict(probe_type='gaussian', probe_mag_sigma=6, probe_phase_sigma=6, probe_phase_max=0.5)
+    from adorym_amd.util import initialize_probe
+    pr, pi = initialize_probe((P, P), **cfgp)
+    probe = np.squeeze(pr) + 1j * np.squeeze(pi)
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm='inf')
+    pos_s = pos - np.array([s0, 0])
+    tt, _ = O.extract_tiles(O.rotate_fwd(truth, coords, np.float64), pos_s, (P, P))
+    meas = O.predict(tt, probe, phys, 'float64')[0]
+    del tt
+    a_d, a_b, gam = 1e-9 * 1.7e7, 1e-10 * 1.7e7, 1e-9 * 1.7e7
+    V = float(N) ** 3
+
+    def reg_grad(x):
+        # regulariser gradient of the FULL object restricted to the slab's interior planes: the oracle normalises by the
+        # slab's own size, the object's is N^3
+        sc = x.shape[0] * x.shape[1] * x.shape[2] / V
+        return (O.l1_value_grad(x, a_d, a_b)[1] + O.tv_value_grad(x, gam)[1]) * sc
+
+    loss64, _, g64, _ = O.forward_adjoint_object(guess, coords, probe, pos_s, meas, phys, 'float64')
+    g64 = (g64 + reg_grad(guess))[1:-1]
+    # the reference's own arithmetic in fp32: its op structure on PyTorch-CPU autograd, fp32 rotation either side
+    g32in = guess.astype(np.float32)
+    rot32 = O.rotate_fwd(g32in, coords, np.float32)
+    loss32, grot32 = T.loss_and_grad(rot32, pos_s, probe, phys.h, phys.k1, meas.astype(np.float32))
+    g32 = (O.rotate_adj(np.asarray(grot32), coords, np.float32) + reg_grad(g32in).astype(np.float32))[1:-1]
+    del rot32, grot32
+    # ---- GPU: the full 256^3 object (zero outside the slab; the TV term sees that edge only on the two slab-edge planes,
+    # which are not compared) ----
+    obj = np.zeros((N, N, N, 2), np.float32)
+    obj[s0:s1] = guess
+    eng = A.MultisliceEngine(ctx, (N, N, N), (P, P), allpos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=len(pos))
+    d_obj = ctx.array(obj)
+    d_grad = ctx.zeros(obj.shape)
+    tab = A.RotationTable(ctx, (N, N, N), theta)
+    d_probe = ctx.array(c2(probe))
+    loss = eng.loss_and_grad(d_obj, d_grad, tab, d_probe, pos, meas.astype(np.float32))
+    from adorym_amd._lib import check
+    check(ctx.lib.adm_reg_grad(eng.plan.handle, d_obj.ptr, a_d, a_b, gam, d_grad.ptr, None))
+    g = d_grad.get()[y_lo:y_hi]
+    assert abs(loss - loss64) <= 3 * abs(loss32 - loss64) + 1e-5 * abs(loss64), (loss, loss64, loss32)
+    e, e32 = rel(g, g64), rel(g32, g64)
+    print('full-size C3 minibatch, theta %.4f: gradient rel-L2 vs fp64 %.2e (reference-structured fp32: %.2e)' % (theta, e, e32))
+    assert e <= 3 * e32 + 1e-5 and e < 5e-3, (e, e32)
+    # outside the footprint the data term is exactly zero: only the regulariser (of the zero object: sign(0) = 0) remains
+    assert not d_grad.get()[:max(0, s0 - 1)].any()
