@@ -7,6 +7,20 @@
 
 namespace adm {
 
+// Diagnostic build only (python adorym_amd/csrc/build.py --variant stamps -DADM_STAMPS; tools/stamps.py): per-wave shader-clock
+// stamps of one slice step of workgroup 0.  In the production build the three macros expand to nothing.  Every stamp is
+// itself a scalar-memory read plus a global store, so it perturbs what it measures (each costs the wave ~100 cycles and
+// the stores of the 11 waves queue in the CU's store path): read phase ORDER and skew from it, not absolute store costs.
+#ifdef ADM_STAMPS
+#define ADM_STAMP_DECL bool stamp_on = false
+#define ADM_STAMP_ON(cond) do { stamp_on = (cond); } while (0)
+#define ADM_STAMP(i) do { if (stamp_on && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ADM_STAMP_DECL
+#define ADM_STAMP_ON(cond) do { } while (0)
+#define ADM_STAMP(i) do { } while (0)
+#endif
+
 #ifdef ADM_SAFE_SYNC
 #define WAVE_SYNC() __syncthreads()
 #else

@@ -30,16 +30,7 @@
 namespace adm {
 
 #ifdef ADM_STAMPS
-// diagnostic build only (tools/stamps.py): per-wave shader-clock stamps of one slice step of workgroup 0
-__device__ unsigned long long g_stamps[16 * 16];
-__device__ int g_stamp_on;
-#define ADM_STAMP_ON(cond) do { stamp_on = (cond); } while (0)
-#define ADM_STAMP(i) do { if (stamp_on && (threadIdx.x & 63) == 0) g_stamps[(threadIdx.x >> 6) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define ADM_STAMP_DECL bool stamp_on = false
-#else
-#define ADM_STAMP_ON(cond) do { } while (0)
-#define ADM_STAMP(i) do { } while (0)
-#define ADM_STAMP_DECL
+__device__ unsigned long long g_stamps[16 * 16];     // diagnostic build only, see ADM_STAMP in adm_ms_math.h
 #endif
 
 
