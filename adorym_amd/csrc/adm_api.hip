@@ -231,10 +231,9 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     if (!d.h_re || !d.h_im) return fail(ADM_ERR_INVALID, "adm_plan_create: transfer function missing");
     if (d.det_mode == ADM_DET_FRESNEL && (!d.hfree_re || !d.hfree_im))
         return fail(ADM_ERR_INVALID, "adm_plan_create: det_mode fresnel needs hfree");
-    if (d.probe_y != d.probe_x)
-        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: non-square probes are not implemented yet");
-    if (ms_threads_for(d.probe_x) == 0)
-        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size not in the compiled set {8,12,16,18,24,27,32,36,64,72}");
+    const bool tuned = (d.probe_y == d.probe_x) && ms_threads_for(d.probe_x) != 0;
+    if (!tuned && !ms_generic_supported(d.probe_y, d.probe_x))
+        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe too large for one workgroup (Py*Px <= 16384 and the field must fit 160 KB of LDS)");
     if (d.n_modes < 1 || d.n_modes > 64) return fail(ADM_ERR_INVALID, "adm_plan_create: n_modes must be in [1, 64]");
     if (d.pad_y0 + d.obj_y + d.pad_y1 < d.probe_y || d.pad_x0 + d.obj_x + d.pad_x1 < d.probe_x)
         return fail(ADM_ERR_INVALID, "adm_plan_create: padded object smaller than the probe");
@@ -247,13 +246,30 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->Xp = d.pad_x0 + d.obj_x + d.pad_x1;
     p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
     p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
+    p->hs_dev = p->hfree_s_dev = p->twid_y_dev = nullptr;
+    p->generic = !tuned;
+    {   // radix lists of the generic kernel's transforms: 8, 4, 2, 9, 3, 5, 7, then whatever primes remain
+        auto factor = [](int n, int* r) {
+            int cnt = 0;
+            const int pref[] = {8, 4, 2, 9, 3, 5, 7};
+            for (int q : pref) while (n > 1 && n % q == 0 && cnt < 8) { r[cnt++] = q; n /= q; }
+            for (int q = 11; n > 1 && cnt < 8; q += 2) while (n % q == 0 && cnt < 8) { r[cnt++] = q; n /= q; }
+            return n == 1 ? cnt : -1;
+        };
+        p->gen_nrx = factor(d.probe_x, p->gen_rx);
+        p->gen_nry = factor(d.probe_y, p->gen_ry);
+        if (p->gen_nrx < 0 || p->gen_nry < 0) {
+            delete p;
+            return fail(ADM_ERR_UNSUPPORTED, "adm_plan_create: probe size with more than 8 prime-power factors");
+        }
+    }
     p->reg_stats = nullptr;
     p->reg_partial = nullptr;
     p->det_weight_dev = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
     {   // the throughput kernel reads H from a table folded along kx: exact mirror symmetry required
         const int N = d.probe_x;
-        bool sym = true;
+        bool sym = tuned;
         for (int ky = 0; ky < d.probe_y && sym; ++ky)
             for (int kx = 1; kx < N; ++kx) {
                 const size_t i = (size_t)ky * N + kx, j = (size_t)ky * N + (N - kx);
@@ -265,15 +281,24 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     }
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
-    if (!rc) {
-        const int N = d.probe_x;
+    for (int axis = 0; axis < 2 && !rc; ++axis) {
+        const int N = axis == 0 ? d.probe_x : d.probe_y;
         std::vector<float> re(N), im(N);
         for (int j = 0; j < N; ++j) {
             const double a = -2.0 * M_PI * (double)j / (double)N;
             re[j] = (float)std::cos(a);
             im[j] = (float)std::sin(a);
         }
-        rc = upload_c(ctx, re.data(), im.data(), N, &p->twid_dev);
+        rc = upload_c(ctx, re.data(), im.data(), N, axis == 0 ? &p->twid_dev : &p->twid_y_dev);
+    }
+    if (!rc) {   // H / (Py*Px) with ONE rounding per element (division in double), for the generic kernel
+        std::vector<float> re(npx), im(npx);
+        for (size_t i = 0; i < npx; ++i) { re[i] = (float)((double)d.h_re[i] / (double)npx); im[i] = (float)((double)d.h_im[i] / (double)npx); }
+        rc = upload_c(ctx, re.data(), im.data(), npx, &p->hs_dev);
+        if (!rc && d.det_mode == ADM_DET_FRESNEL) {
+            for (size_t i = 0; i < npx; ++i) { re[i] = (float)((double)d.hfree_re[i] / (double)npx); im[i] = (float)((double)d.hfree_im[i] / (double)npx); }
+            rc = upload_c(ctx, re.data(), im.data(), npx, &p->hfree_s_dev);
+        }
     }
     if (rc) {
         adm_plan_destroy(p);
@@ -288,6 +313,9 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->h_dev) adm_free(plan->ctx, plan->h_dev);
     if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
     if (plan->twid_dev) adm_free(plan->ctx, plan->twid_dev);
+    if (plan->twid_y_dev) adm_free(plan->ctx, plan->twid_y_dev);
+    if (plan->hs_dev) adm_free(plan->ctx, plan->hs_dev);
+    if (plan->hfree_s_dev) adm_free(plan->ctx, plan->hfree_s_dev);
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
     if (plan->reg_partial) (void)hipFree(plan->reg_partial);
     if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
@@ -321,27 +349,29 @@ extern "C" size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch) {
     // [stash: B*M*per | tile gradients: B*per | cover lists (Yp*Xp*(1+64) u32) + overflow flag | detector fields: B*M*G*NT |
     //  per-position probe gradients: B*M*Py*Px]
     const size_t per = adm::ms_ws_per_pos(plan) * sizeof(float2);
-    const int N = plan->d.probe_x;
-    const int G = ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N);
-    const size_t det = plan->d.n_modes > 1 ? (size_t)batch * plan->d.n_modes * G * ms_threads_for(N) * sizeof(float2) : 0;
-    const size_t gpp = (size_t)batch * plan->d.n_modes * N * N * sizeof(float2);
+    const size_t det = adm::ws_det_bytes(plan, batch);
+    const size_t gpp = (size_t)batch * plan->d.n_modes * plan->d.probe_y * plan->d.probe_x * sizeof(float2);
     return (size_t)batch * (plan->d.n_modes + 1) * per + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64 + det + gpp;
 }
 
 namespace adm {
-size_t ms_ws_per_pos(const adm_plan* plan) {
-    return (size_t)plan->n_steps * ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x);
+size_t ms_row_elems(const adm_plan* plan) {      // float2 elements of one workspace row (one modulation step of one position)
+    if (plan->generic) return (size_t)plan->d.probe_y * plan->d.probe_x;
+    return (size_t)ms_r1_for(plan->d.probe_x) * ms_threads_for(plan->d.probe_x);
+}
+size_t ms_ws_per_pos(const adm_plan* plan) { return (size_t)plan->n_steps * ms_row_elems(plan); }
+size_t ws_det_bytes(const adm_plan* plan, int batch) {   // parked detector-plane fields of the probe modes
+    if (plan->d.n_modes <= 1) return 0;
+    const int N = plan->d.probe_x;
+    const size_t per_mode = plan->generic ? (size_t)plan->d.probe_y * N
+                                          : (size_t)(ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N)) * ms_threads_for(N);
+    return (size_t)batch * plan->d.n_modes * per_mode * sizeof(float2);
 }
 // byte offsets of the workspace sections
 size_t ws_off_gtile(const adm_plan* plan, int batch) { return (size_t)batch * plan->d.n_modes * ms_ws_per_pos(plan) * sizeof(float2); }
 size_t ws_off_cover(const adm_plan* plan, int batch) { return ws_off_gtile(plan, batch) + (size_t)batch * ms_ws_per_pos(plan) * sizeof(float2); }
 size_t ws_off_det(const adm_plan* plan, int batch) { return ws_off_cover(plan, batch) + (size_t)plan->Yp * plan->Xp * 65 * sizeof(unsigned) + 64; }
-size_t ws_off_gprobe(const adm_plan* plan, int batch) {
-    const int N = plan->d.probe_x;
-    const int G = ms_r1_for(N) > ms_r2_for(N) ? ms_r1_for(N) : ms_r2_for(N);
-    const size_t det = plan->d.n_modes > 1 ? (size_t)batch * plan->d.n_modes * G * ms_threads_for(N) * sizeof(float2) : 0;
-    return ws_off_det(plan, batch) + det;
-}
+size_t ws_off_gprobe(const adm_plan* plan, int batch) { return ws_off_det(plan, batch) + ws_det_bytes(plan, batch); }
 }  // namespace adm
 
 static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
@@ -402,12 +432,31 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
         p.grad_probe = (float2*)((char*)workspace + ws_off_gprobe(plan, batch));
         p.gprobe_bstride = probe_elems;
     }
+    if (plan->generic) {
+        if (per_position) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: per-position probes need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
+        p.gen_py = d.probe_y; p.gen_px = d.probe_x;
+        p.gen_nrx = plan->gen_nrx; p.gen_nry = plan->gen_nry;
+        for (int i = 0; i < 8; ++i) { p.gen_rx[i] = plan->gen_rx[i]; p.gen_ry[i] = plan->gen_ry[i]; }
+        p.gen_twid_y = plan->twid_y_dev; p.gen_hs = plan->hs_dev; p.gen_hfree_s = plan->hfree_s_dev;
+        ADM_HIP(ms_generic_launch(p, batch, plan->ctx->stream));
+        if (grad_probe && want_grad)
+            ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
+        return ADM_OK;
+    }
     const bool lean = plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
                       d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
     if (lean) ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
     else ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     if (!per_position && grad_probe && want_grad)
         ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_plan_set_generic(adm_plan* plan, int on) {
+    if (!plan) return fail(ADM_ERR_INVALID, "adm_plan_set_generic: null plan");
+    const bool tuned = (plan->d.probe_y == plan->d.probe_x) && ms_threads_for(plan->d.probe_x) != 0;
+    if (!on && !tuned) return fail(ADM_ERR_INVALID, "adm_plan_set_generic: this probe size has no tuned kernel");
+    plan->generic = on != 0;
     return ADM_OK;
 }
 
@@ -435,6 +484,7 @@ extern "C" int adm_probe_shift(adm_plan* plan, const float* probe, const float* 
                                float* probes_out) {
     if (!plan || !probe || !shifts || !probes_out) return fail(ADM_ERR_INVALID, "adm_probe_shift: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_probe_shift: batch must be positive");
+    if (plan->generic) return fail(ADM_ERR_UNSUPPORTED, "adm_probe_shift: sub-pixel probe shifts need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
     ShiftParams q;
     std::memset(&q, 0, sizeof(q));
     q.probe = (const float2*)probe;
@@ -451,6 +501,7 @@ extern "C" int adm_probe_shift_adj(adm_plan* plan, const float* probe, const flo
                                    const float* grad_probes, float* grad_probe, float* grad_shifts) {
     if (!plan || !probe || !shifts || !grad_probes || !grad_shifts) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: batch must be positive");
+    if (plan->generic) return fail(ADM_ERR_UNSUPPORTED, "adm_probe_shift_adj: sub-pixel probe shifts need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
     ShiftParams q;
     std::memset(&q, 0, sizeof(q));
     q.probe = (const float2*)probe;

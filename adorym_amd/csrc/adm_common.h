@@ -32,6 +32,11 @@ struct adm_plan {
     float* det_weight_dev; // [Py*Px] beamstop weights or nullptr (adm_plan_set_detector_mask)
     float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
     float* reg_partial;    // [obj_y*obj_x] per-row partial sums of the regulariser value (lazily allocated)
+    bool generic;          // probe size outside the tuned kernels' set (or forced): adm_ms_generic.hip, pixel-major workspace rows
+    int gen_nrx, gen_nry, gen_rx[8], gen_ry[8];   // radix lists of the x / y transforms of the generic kernel
+    float2* hs_dev;        // [Py*Px] H / (Py*Px), one rounding per element (generic kernel)
+    float2* hfree_s_dev;   // same for the detector-plane Fresnel kernel, or nullptr
+    float2* twid_y_dev;    // [Py] exp(-2 pi i j / Py)
     bool h_sym;            // H(ky, kx) == H(ky, N - kx) for the slice and detector kernels (every get_kernel() output)
     int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
 };
@@ -69,6 +74,11 @@ struct MsParams {
     const float* det_weight;   // [P][P] 0/1 weights of the detector pixels in the loss (beamstop), reference layout; or nullptr
     size_t probe_bstride;      // float2 elements between the probes of consecutive positions (0 = one shared probe set)
     size_t gprobe_bstride;     // same for grad_probe (per-position gradients when the probes are per position)
+    // generic kernel (adm_ms_generic.hip) only
+    int gen_py, gen_px, gen_nrx, gen_nry, gen_rx[8], gen_ry[8];
+    const float2* gen_twid_y;  // [Py]; twid is [Px]
+    const float2* gen_hs;      // [Py][Px] H / (Py*Px)
+    const float2* gen_hfree_s; // [Py][Px] or nullptr
 };
 // per-position sub-pixel probe shifts (adorym/util.py:380-397, forward_model.py:296-311)
 struct ShiftParams {
@@ -84,7 +94,9 @@ struct ShiftParams {
 };
 int ms_threads_for(int n);
 int ms_r2_for(int n);
-size_t ms_ws_per_pos(const adm_plan* plan);   // float2 elements of one position's stash of ONE mode
+size_t ms_ws_per_pos(const adm_plan* plan);
+size_t ms_row_elems(const adm_plan* plan);
+size_t ws_det_bytes(const adm_plan* plan, int batch);   // float2 elements of one position's stash of ONE mode
 size_t ws_off_gtile(const adm_plan* plan, int batch);
 size_t ws_off_cover(const adm_plan* plan, int batch);
 size_t ws_off_det(const adm_plan* plan, int batch);
@@ -93,6 +105,9 @@ hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* ou
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 bool ms_lean_supported(int n);
+bool ms_generic_supported(int py, int px);
+int ms_generic_threads(int py, int px);
+hipError_t ms_generic_launch(const MsParams& p, int batch, hipStream_t st);
 hipError_t ms_lean_launch(int n, const MsParams& p, int batch, hipStream_t st);
 hipError_t shift_launch(int n, const ShiftParams& q, int batch, bool adjoint, hipStream_t st);
 }  // namespace adm

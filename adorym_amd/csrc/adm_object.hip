@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void rotate_adj_staged_kernel(const float2* __
 #define ADM_MAXCOVER 64
 
 struct TileGeom {
-    int Yp, Xp, pad_y0, pad_x0, P, R1, R2, G, LPW, NT, n_steps, binning, Z;
+    int Yp, Xp, pad_y0, pad_x0, Py, Px, R1, R2, G, LPW, NT, n_steps, binning, Z;
+    int pixel_major;      // rows written by the generic kernel: [Py][Px]; else the tuned kernels' thread-native order
+    int row_elems;        // float2 elements of one row (one modulation step of one position)
     int row0, nrows;      // padded-row window touched by the batch
     int add_lo, add_hi;   // padded rows [add_lo, add_hi) already hold an earlier part of the same batch: accumulate there
 };
@@ -302,14 +304,19 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     const size_t cplane = (size_t)g.nrows * g.Xp;
     unsigned* out = cover + (size_t)r * g.Xp + x;
     int cnt = 0;
-    const unsigned per_pos = (unsigned)g.n_steps * g.R1 * g.NT;
+    const unsigned per_pos = (unsigned)g.n_steps * g.row_elems;
     for (int b = 0; b < B; ++b) {
         const int2 p = pos[b];
         const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
-        if (row >= 0 && row < g.P && col >= 0 && col < g.P) {
+        if (row >= 0 && row < g.Py && col >= 0 && col < g.Px) {
             if (cnt < ADM_MAXCOVER) {
-                const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
-                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + adm::ws_elem_offset(g.R1, g.NT, col / g.R2, tid);
+                unsigned off;
+                if (g.pixel_major) off = (unsigned)(row * g.Px + col);
+                else {
+                    const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
+                    off = adm::ws_elem_offset(g.R1, g.NT, col / g.R2, tid);
+                }
+                out[(size_t)(1 + cnt) * cplane] = (unsigned)b * per_pos + off;
             }
             ++cnt;
         }
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     const size_t cplane = (size_t)g.nrows * g.Xp;
     const unsigned* cv = cover + (size_t)r * g.Xp + x;
     const int cnt = (int)cv[0];
-    const size_t step_stride = (size_t)g.R1 * g.NT;
+    const size_t step_stride = (size_t)g.row_elems;
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
     const bool add = (g.row0 + r >= g.add_lo) && (g.row0 + r < g.add_hi);
@@ -760,13 +767,16 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     const adm_plan_desc& d = plan->d;
     const int N = d.probe_x;
     TileGeom g;
-    g.Yp = plan->Yp; g.Xp = plan->Xp; g.pad_y0 = d.pad_y0; g.pad_x0 = d.pad_x0; g.P = N;
-    g.R1 = ms_r1_for(N); g.R2 = ms_r2_for(N); g.G = g.R1 > g.R2 ? g.R1 : g.R2; g.LPW = 64 / g.G; g.NT = ms_threads_for(N);
+    g.Yp = plan->Yp; g.Xp = plan->Xp; g.pad_y0 = d.pad_y0; g.pad_x0 = d.pad_x0; g.Py = d.probe_y; g.Px = d.probe_x;
+    g.pixel_major = plan->generic ? 1 : 0;
+    g.row_elems = (int)ms_row_elems(plan);
+    g.R1 = g.R2 = g.G = g.LPW = 1; g.NT = 64;
+    if (!plan->generic) { g.R1 = ms_r1_for(N); g.R2 = ms_r2_for(N); g.G = g.R1 > g.R2 ? g.R1 : g.R2; g.LPW = 64 / g.G; g.NT = ms_threads_for(N); }
     g.n_steps = plan->n_steps; g.binning = d.binning; g.Z = d.obj_z;
     int ymin = pos_host[0], ymax = pos_host[0];
     for (int b = 1; b < batch; ++b) { ymin = pos_host[2 * b] < ymin ? pos_host[2 * b] : ymin; ymax = pos_host[2 * b] > ymax ? pos_host[2 * b] : ymax; }
     g.row0 = ymin + d.pad_y0;
-    g.nrows = ymax - ymin + N;
+    g.nrows = ymax - ymin + d.probe_y;
     g.add_lo = g.add_hi = 0;
     if (add) {                      // accumulate into this part's own rows (an earlier part wrote the whole batch window)
         g.add_lo = g.row0;
@@ -778,7 +788,7 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
         g.nrows = win_y_hi - win_y_lo;
     }
     if (g.row0 < 0 || g.row0 + g.nrows > g.Yp) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: a position lies outside the padded frame");
-    const size_t per = (size_t)plan->n_steps * g.R1 * g.NT;
+    const size_t per = (size_t)plan->n_steps * g.row_elems;
     if ((size_t)batch * per >= 0xFFFFFFFFull) return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate: batch too large for 32-bit tile offsets");
     char* ws = (char*)workspace;
     const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));

@@ -251,6 +251,11 @@ class Plan(object):
             self._csr_scratch = DeviceArray(self.ctx, (int(self.ctx.lib.adm_rotation_csr_scratch_bytes(self.handle)),), np.uint8)
         return self._csr_scratch
 
+    def set_generic(self, on=True):
+        """Route this plan through the any-size kernel (adm_ms_generic.hip) even if a tuned kernel exists for its probe size;
+        call before the first workspace is sized."""
+        check(self.ctx.lib.adm_plan_set_generic(self.handle, 1 if on else 0))
+
     def set_lean_min_batch(self, n):
         """Batches of at least n positions use the two-workgroups-per-CU kernel where it applies (0 = never)."""
         check(self.ctx.lib.adm_plan_set_lean_min_batch(self.handle, int(n)))

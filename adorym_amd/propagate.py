@@ -104,7 +104,7 @@ class MultisliceEngine(object):
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
                  n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta',
-                 beamstop=None):
+                 beamstop=None, generic=False):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -133,6 +133,8 @@ class MultisliceEngine(object):
                          normalize_fft=normalize_fft, h_free=h_free,
                          loss_type={'lsq': _lib.LOSS_LSQ, 'poisson': _lib.LOSS_POISSON}[loss_function_type],
                          poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
+        if generic:
+            self.plan.set_generic(True)       # the any-size kernel even where a tuned one exists (tests, A/B timing)
         self.unknown_type = unknown_type
         self.loss_function_type = loss_function_type
         self.pads = pads

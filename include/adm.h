@@ -211,6 +211,13 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
  * H(ky,kx) == H(ky,N-kx), probe 64 or 72).  Batches of at least `min_batch` positions use the second where it applies;
  * 0 = never (the default: opt-in).  No reference counterpart: a tuning knob of this library. */
 int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch);
+/* Probe sizes.  Any Py x Px with Py*Px <= 16384 whose field fits the LDS is accepted (the reference takes whatever
+ * prj.shape[-2:] is, adorym/ptychography.py:313-317).  Square sizes in {8,12,16,18,24,27,32,36,64,72} run the tuned
+ * register-resident kernels; every other size -- and every size after adm_plan_set_generic(plan, 1) -- runs the generic
+ * kernel (adm_ms_generic.hip: run-time radix lists, any prime factors, non-square).  Call it before the first workspace is
+ * sized: the two kernels lay their workspace rows out differently.  Per-position probes (adm_multislice_fwd_adj_pp,
+ * adm_probe_shift*) exist for the tuned sizes only. */
+int adm_plan_set_generic(adm_plan* plan, int on);
 
 /* Same as adm_multislice_fwd_adj with ONE PROBE SET PER POSITION (sub-pixel probe positions, adorym/forward_model.py:
  * 296-311 + 337-375): probes device [batch][n_modes][Py][Px][2]; grad_probes device [batch][n_modes][Py][Px][2] or NULL,

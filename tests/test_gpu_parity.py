@@ -104,11 +104,17 @@ def test_forward_only_matches_full(A, ctx):
 
 
 def test_unsupported_configs_raise(A, ctx):
+    """Unlisted and non-square probe sizes now run the generic kernel (tests/test_gpu_round2.py); what still raises is a
+    probe whose field does not fit one workgroup, and per-position probes on a size without a tuned kernel."""
     pos = np.array([(0, 0)])
+    A.MultisliceEngine(ctx, (20, 20, 4), (20, 20), pos, 5000., 1e-7)                # unlisted size: accepted
+    A.MultisliceEngine(ctx, (16, 12, 4), (16, 12), pos, 5000., 1e-7)                # non-square: accepted
     with pytest.raises(NotImplementedError):
-        A.MultisliceEngine(ctx, (20, 20, 4), (20, 20), pos, 5000., 1e-7)            # size not compiled
+        A.MultisliceEngine(ctx, (200, 200, 2), (160, 160), pos, 5000., 1e-7)        # 25 600 pixels: more than one workgroup holds
+    eng = A.MultisliceEngine(ctx, (30, 30, 2), (20, 20), pos, 5000., 1e-7, max_batch=1)
+    eng.set_batch(pos, np.ones((1, 20, 20), np.float32))
     with pytest.raises(NotImplementedError):
-        A.MultisliceEngine(ctx, (16, 12, 4), (16, 12), pos, 5000., 1e-7)            # non-square
+        eng.multislice(ctx.zeros((1, 20, 20, 2)), shifts=ctx.zeros((1, 2)))          # sub-pixel probe shifts need a tuned size
 
 
 # --------------------------------------------------------------------------- F4 rotation

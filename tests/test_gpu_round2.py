@@ -215,3 +215,76 @@ def test_probe_gradient_is_bitwise_reproducible(A, ctx, lean):
         eng.set_batch(pos[half], meas[half])
         eng.multislice(probe, grad_probe=gp, grad_scale=2.0 / (B * P * P))
     assert np.abs(gp.get() - outs[0]).max() <= 2e-6 * np.abs(outs[0]).max()
+
+
+def _generic_case(A, ctx, Py, Px, S=5, B=3, free_prop='inf', binning=1, n_modes=1, unknown_type='delta_beta', generic=False, seed=0):
+    """Forward + gradients of one minibatch against the fp64 oracle (and its fp32 run for the 3x rule)."""
+    r = cases.rng(900 + Py * 7 + Px + seed)
+    Y, X = Py + 9, Px + 11
+    if unknown_type == 'delta_beta':
+        mk = lambda: np.stack([2e-3 * r.uniform(size=(Y, X, S)), 2e-4 * r.uniform(size=(Y, X, S))], -1)
+    else:
+        mk = lambda: np.stack([1 + 1e-2 * r.standard_normal((Y, X, S)), 2e-2 * r.standard_normal((Y, X, S))], -1)
+    obj, truth = mk(), mk()
+    pos = np.stack([r.integers(-3, 9, B), r.integers(-3, 11, B)], 1)
+    probes = (0.5 + r.uniform(0, 1, (n_modes, Py, Px))) * np.exp(1j * r.uniform(-np.pi, np.pi, (n_modes, Py, Px)))
+    phys = O.Physics((Py, Px), 5000., 1e-7, free_prop_cm=free_prop, binning=binning, unknown_type=unknown_type)
+    tt, _ = O.extract_tiles(truth, pos, (Py, Px), unknown_type)
+    target = O.predict(tt, probes, phys, 'float64')[0]
+    loss_o, pred_o, g_o, gp_o = O.forward_adjoint_object(obj, None, probes, pos, target, phys, 'float64')
+    _, _, g32, _ = O.forward_adjoint_object(obj.astype(np.float32), None, probes, pos, target, phys, 'float32')
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (Py, Px), pos, 5000., 1e-7, free_prop_cm=free_prop, binning=binning,
+                             n_probe_modes=n_modes, unknown_type=unknown_type, generic=generic)
+    d_grad = ctx.zeros(obj.shape)
+    d_gp = ctx.zeros((n_modes, Py, Px, 2))
+    eng.set_batch(pos, target)
+    eng.rotate(ctx.array(obj, np.float32), None)
+    eng.multislice(ctx.array(np.stack([probes.real, probes.imag], -1).astype(np.float32)), grad_probe=d_gp, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    assert rel(eng.pred(), pred_o) < 5e-6, rel(eng.pred(), pred_o)
+    assert abs(eng.loss() - loss_o) <= 3e-5 * abs(loss_o)
+    e, e32 = rel(d_grad.get(), g_o), rel(g32, g_o)
+    assert e < 2e-4 and e <= 3 * e32 + 2e-5, (Py, Px, e, e32)
+    assert rel(d_gp.get(), np.stack([gp_o.real, gp_o.imag], -1)) < 2e-4
+
+
+@pytest.mark.parametrize('Py,Px', [(48, 48), (96, 96), (128, 128), (100, 100), (40, 56), (26, 35), (13, 22), (72, 64)])
+def test_any_probe_size_vs_oracle(A, ctx, Py, Px):
+    """probe sizes outside the compiled set and non-square probes raised; the reference takes whatever
+    prj.shape[-2:] is (adorym/ptychography.py:313-317).  adm_ms_generic.hip: 128 x 128 (SURVEY's config-1 shape), 48, 96,
+    100 (factor 5), non-square, odd primes 13 / 7 x 5, and a mixed 72 x 64."""
+    _generic_case(A, ctx, Py, Px)
+
+
+@pytest.mark.parametrize('kw', [dict(free_prop=0), dict(free_prop=1e-4), dict(binning=2, S=5), dict(n_modes=3), dict(unknown_type='real_imag'),
+                                dict(n_modes=2, free_prop=0)])
+def test_generic_kernel_variants_vs_oracle(A, ctx, kw):
+    _generic_case(A, ctx, 20, 28, **kw)
+
+
+def test_generic_kernel_equals_tuned_kernel_at_72(A, ctx):
+    """The same minibatch through the tuned kernel and through the generic one (forced): both within the oracle bar, and
+    within 1e-4 of each other on the gradient."""
+    _generic_case(A, ctx, 72, 72, generic=False, seed=5)
+    _generic_case(A, ctx, 72, 72, generic=True, seed=5)
+
+
+def test_driver_runs_with_a_non_square_unlisted_probe(A, ctx, tmp_path):
+    """reconstruct_ptychography end to end with a 20 x 28 probe (no tuned kernel): loss decreases, outputs written."""
+    r = cases.rng(8)
+    N, S, Py, Px = 40, 6, 20, 28
+    pos = np.array([(y, x) for y in (0, 8, 16) for x in (0, 6, 12)])
+    truth = np.stack([2e-3 * cases.smooth_field((N, N, S), 1), 2e-4 * cases.smooth_field((N, N, S), 2)], -1)
+    phys = O.Physics((Py, Px), 5000., 1e-7, free_prop_cm='inf')
+    pm, pp = A.util.initialize_probe((Py, Px), 'gaussian', probe_mag_sigma=5, probe_phase_sigma=5, probe_phase_max=0.5)
+    probe = np.squeeze(pm) + 1j * np.squeeze(pp)
+    tt, _ = O.extract_tiles(truth, pos, (Py, Px))
+    prj = O.predict(tt, probe, phys, 'float64')[0][None].astype(np.float32)
+    st = A.reconstruct_ptychography(fname=prj, obj_size=(N, N, S), probe_pos=pos, theta_st=0, theta_end=0, n_theta=1, energy_ev=5000.,
+                                    psize_cm=1e-7, free_prop_cm='inf', minibatch_size=3, n_epochs=3, learning_rate=2e-5, optimizer='adam',
+                                    initial_guess=[0.5 * truth[..., 0], 0.5 * truth[..., 1]], probe_type='gaussian', probe_mag_sigma=5,
+                                    probe_phase_sigma=5, probe_phase_max=0.5, gamma=0, alpha_d=None, save_path=str(tmp_path),
+                                    output_folder='o', store_checkpoint=False, use_checkpoint=False, return_state=True)
+    l = np.array(st['losses'])
+    assert np.all(np.isfinite(l)) and l[-3:].mean() < 0.85 * l[:3].mean()
+    assert os.path.exists(os.path.join(st['output_folder'], 'delta_ds_1.tiff'))
