@@ -288,3 +288,62 @@ def test_driver_runs_with_a_non_square_unlisted_probe(A, ctx, tmp_path):
     l = np.array(st['losses'])
     assert np.all(np.isfinite(l)) and l[-3:].mean() < 0.85 * l[:3].mean()
     assert os.path.exists(os.path.join(st['output_folder'], 'delta_ds_1.tiff'))
+
+
+def test_c2_sixteen_virtual_ranks_sum_vs_oracle(A, ctx):
+    """BASELINE's config 2 says 'minibatch 16', but the reference forces minibatch_size = 1 for undivided full-field data
+    (adorym/ptychography.py:342-346): 16 in flight = 16 ranks x 1 angle each, gradients SUMMED (:1113-1114), every rank
+    adding the L1 term (forward_model.py:138-139), one Adam step.  The same global batch on one GPU: 16 angles accumulated
+    into one gradient buffer, one exchange_and_update -- against the fp64 oracle's sum and Adam step."""
+    from adorym_amd.dp import DataParallelObject, HipOps
+    from adorym_amd.comm import LocalComm
+    N, R = 64, 16
+    truth = np.stack([2e-5 * cases.smooth_field((N, N, N), 171), 2e-7 * cases.smooth_field((N, N, N), 172)], -1)
+    guess = np.stack([1.2e-5 * cases.smooth_field((N, N, N), 173), 1.2e-7 * cases.smooth_field((N, N, N), 174)], -1)
+    thetas = np.linspace(0, 2 * np.pi, 50, dtype='float32')[3:3 + R]
+    phys = O.Physics((N, N), 800., 0.67e-7, free_prop_cm=0)
+    probe = np.ones((N, N), complex)
+    pos = np.array([(0, 0)])
+    a_d, a_b = 1e-9 * 64 ** 3, 1e-10 * 64 ** 3
+    g64 = np.zeros_like(guess)
+    g32 = np.zeros(guess.shape, np.float32)
+    losses64, data = [], []
+    for th in thetas:
+        c = O.rotation_coords((N, N, N), th)
+        meas = np.abs(O.multislice_forward(O.rotate_fwd(truth, c, 'float64')[None], probe, phys, 'float64'))
+        data.append(meas.astype(np.float32))
+        l, _, g, _ = O.forward_adjoint_object(guess, c, probe, pos, meas.astype(np.float32).astype(np.float64), phys, 'float64')
+        g64 += g + O.l1_value_grad(guess, a_d, a_b)[1]
+        losses64.append(l)
+        g32 += O.forward_adjoint_object(guess.astype(np.float32), c, probe, pos, meas.astype(np.float32), phys, 'float32')[2] \
+            + O.l1_value_grad(guess.astype(np.float32), a_d, a_b)[1].astype(np.float32)
+    x64, _, _ = O.adam_step(guess, g64, np.zeros_like(guess), np.zeros_like(guess), 0, 1e-7)
+    # ---- GPU ----
+    eng = A.MultisliceEngine(ctx, (N, N, N), (N, N), pos, 800., 0.67e-7, free_prop_cm=0, max_batch=1)
+    st = DataParallelObject(HipOps(ctx), LocalComm(), (N, N, N, 2))
+    n = guess.size
+    st.obj.view(0, (n,)).set(guess.astype(np.float32).ravel())
+    obj = st.obj.view(0, (N, N, N, 2))
+    grad = st.grad.view(0, (N, N, N, 2))
+    st.zero_grad()
+    d_probe = ctx.array(c2(probe)[None])
+    from adorym_amd._lib import check
+    losses = []
+    for th, meas in zip(thetas, data):
+        tab = A.RotationTable(ctx, (N, N, N), th)
+        losses.append(eng.loss_and_grad(obj, grad, tab, d_probe, pos, meas))
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, obj.ptr, a_d, a_b, 0.0, grad.ptr, None))       # every virtual rank adds it
+    g = grad.get()
+    st.exchange_and_update('adam', 0, {'step_size': 1e-7})
+    x = st.obj.view(0, (N, N, N, 2)).get()
+    assert np.allclose(losses, losses64, rtol=2e-5)
+    # weak object (delta ~ 1e-5), near field: the data gradient is a small difference of O(1) magnitudes, so fp32 -- the
+    # reference's own included -- sits at the per-cent level against fp64 (SURVEY.md 0.1 / 8c): 3x rule against the fp32 oracle
+    e, e32 = rel(g, g64), rel(g32, g64)
+    assert e <= 3 * e32 + 1e-5, (e, e32)
+    d = np.abs(x - x64)
+    assert np.sqrt(np.mean(d ** 2)) < 1e-8 and (d > 3e-8).mean() < 2e-3       # Adam's first step is lr * sign-like: lr = 1e-7
+
+
+def c2(z):
+    return np.stack([z.real, z.imag], -1).astype(np.float32)
