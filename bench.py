@@ -53,7 +53,7 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         O.forward_adjoint_tiles(tiles, probe, meas, phys, 'float32')
         t_used += time.perf_counter() - t0
         done += nb
-        if t_used > 0.5 * seconds_budget or done >= 64:
+        if t_used > 0.6 * seconds_budget or done >= 512:
             break
     out = {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
            'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
