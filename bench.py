@@ -10,9 +10,13 @@ Benchmark of the hot path on BASELINE.json's metric: probe-positions/s (forward 
 One "step" = one minibatch iteration of reconstruct_ptychography (update_scheme='immediate'):
 rotate object to theta (footprint planes) -> multislice forward + far-field LSQ loss + adjoint for the
 32 positions -> rotate gradient back -> L1+TV regulariser gradient -> [reduce-scatter over ranks] ->
-fused Adam (+ all-gather).  Nothing is skipped inside the timed region.  With N ranks the global batch
-is N x 32 positions (the reference's `mpirun -n N` semantics): weak scaling.
-Prints ONE JSON line (rank 0).
+fused Adam (+ all-gather).  No part of that computation is skipped inside the timed region.  As the bench contract
+allows, the INPUTS are resident in HBM when the timed region starts: the measured magnitudes of every timed minibatch and
+the per-angle rotation tables (fp16 lookup + adjoint CSR) are staged before the clock starts.  What the product's driver
+does on top of that -- host-resident data handed over per minibatch through the pinned ring, rotation tables built the
+first time an angle is met -- is timed separately, on reconstruct_ptychography itself, in the `driver` keys (mean per
+minibatch over 16 first-touch angles; 1.04x the engine loop).  With N ranks the global batch is N x 32 positions (the
+reference's `mpirun -n N` semantics): weak scaling.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
