@@ -1,27 +1,72 @@
-// Small-radix complex DFT butterflies and the two-pass (N = R1*R2) line transform used by the
-// multislice kernel.  Device-only, gfx950.  All loops are compile-time unrolled so the
-// per-thread element arrays live in VGPRs.
+// Small-radix complex DFT butterflies and complex arithmetic for the multislice kernels.  Device-only, gfx950.
+// All loops are compile-time unrolled so the per-thread element arrays live in VGPRs.
 //
 // Conventions:  forward DFT  X[k] = sum_n x[n] exp(-2 pi i n k / N)   (torch.fft.fft2, norm=None)
 //               inverse here is the UNNORMALISED conjugate transform; 1/N factors are folded
 //               into the transfer-function registers by the caller.
+//
+// Packed fp32.  A complex number is an aligned VGPR pair, and gfx950's v_pk_{add,mul,fma}_f32 work on such a pair with
+// per-half source selection (op_sel / op_sel_hi) and negation (neg_lo / neg_hi) for free.  Complex add / subtract, the
+// multiplications by -+i that radix-4 / radix-8 butterflies need, "m +- i h d" of a radix-3 butterfly and a full complex
+// multiply (2 instructions) are therefore one or two vector instructions instead of two to four.  A packed instruction
+// occupies the SIMD twice as long as a scalar one, so at saturation the rates are equal -- but this kernel is not at
+// saturation: its waves are bound by their own issue interval, which tools/micro/pk_rate.hip measures as the SAME for a
+// packed and a scalar instruction when one to three waves share a SIMD (3.4 vs 3.8 ns alone; 2.0 ns per packed = 1.0 ns
+// per operation against 1.7 ns per scalar instruction at three waves).  Halving the instruction count is what counts.
+// (Round 1 found compiler SLP packing a loss: the auto-vectoriser shuffled halves with v_mov; here every swizzle rides on
+// an instruction's modifiers.  The library is still built with -fno-slp-vectorize.)
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace adm {
 
 typedef float2 cf;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-// a * conj(b)
-__device__ __forceinline__ cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-__device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ v2f V(cf a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ cf C(v2f a) { return __builtin_bit_cast(cf, a); }
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return C(V(a) + V(b)); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return C(V(a) - V(b)); }
+__device__ __forceinline__ cf cscale(cf a, float s) { return C(V(a) * s); }
+// a + s*b, real s
+__device__ __forceinline__ cf caxpy(cf a, float s, cf b) { return C(__builtin_elementwise_fma(V(b), (v2f){s, s}, V(a))); }
+
+// a * b:  t = (a.x b.x, a.x b.y);  r = (-a.y b.y + t.x, a.y b.x + t.y)
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(V(a)), "v"(V(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(V(a)), "v"(V(b)), "v"(t));
+    return C(r);
+}
+// a * conj(b):  t = (a.x b.x, -a.x b.y);  r = (a.y b.y + t.x, a.y b.x + t.y)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(V(a)), "v"(V(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(V(a)), "v"(V(b)), "v"(t));
+    return C(r);
+}
 template <bool CONJ> __device__ __forceinline__ cf cmul_t(cf a, cf b) { return CONJ ? cmulc(a, b) : cmul(a, b); }
+
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> __device__ __forceinline__ cf rot90(cf a) {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+// t + rot90<INV>(d) in one instruction: forward (t.x + d.y, t.y - d.x), inverse (t.x - d.y, t.y + d.x)
+template <bool INV> __device__ __forceinline__ cf add_rot(cf t, cf d) {
+    v2f r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(V(t)), "v"(V(d)));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(V(t)), "v"(V(d)));
+    return C(r);
+}
+// t - rot90<INV>(d)
+template <bool INV> __device__ __forceinline__ cf sub_rot(cf t, cf d) { return add_rot<!INV>(t, d); }
+// m + s * rot90<INV>(d), real s (both halves of sv hold s):  forward (m.x + s d.y, m.y - s d.x)
+template <bool INV> __device__ __forceinline__ cf fma_rot(cf m, v2f sv, cf d) {
+    v2f r;
+    if (INV) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(V(d)), "v"(sv), "v"(V(m)));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(V(d)), "v"(sv), "v"(V(m)));
+    return C(r);
 }
 
 template <int R, bool INV> struct Dft;
@@ -37,25 +82,25 @@ template <bool INV> struct Dft<2, INV> {
 template <bool INV> struct Dft<3, INV> {
     static __device__ __forceinline__ void run(cf& a0, cf& a1, cf& a2) {
         const float h = 0.86602540378443864676f;  // sqrt(3)/2
-        cf s = cadd(a1, a2);
-        cf d = csub(a1, a2);
-        cf m = make_float2(a0.x - 0.5f * s.x, a0.y - 0.5f * s.y);
-        // forward: (-i h) d ; inverse: (+i h) d
-        cf r = INV ? make_float2(-h * d.y, h * d.x) : make_float2(h * d.y, -h * d.x);
+        const v2f hv = {h, h};
+        const cf s = cadd(a1, a2);
+        const cf d = csub(a1, a2);
+        const cf m = caxpy(a0, -0.5f, s);
         a0 = cadd(a0, s);
-        a1 = cadd(m, r);
-        a2 = csub(m, r);
+        // forward: m -+ i h d ; inverse: m +- i h d
+        a1 = fma_rot<INV>(m, hv, d);
+        a2 = fma_rot<!INV>(m, hv, d);
     }
     static __device__ __forceinline__ void run(cf (&a)[3]) { run(a[0], a[1], a[2]); }
 };
 
 template <bool INV> struct Dft<4, INV> {
     static __device__ __forceinline__ void run(cf& a0, cf& a1, cf& a2, cf& a3) {
-        cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = rot90<INV>(csub(a1, a3));
+        const cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
         a0 = cadd(t0, t2);
-        a1 = cadd(t1, t3);
         a2 = csub(t0, t2);
-        a3 = csub(t1, t3);
+        a1 = add_rot<INV>(t1, d);      // t1 + (-+i) d
+        a3 = sub_rot<INV>(t1, d);
     }
     static __device__ __forceinline__ void run(cf (&a)[4]) { run(a[0], a[1], a[2], a[3]); }
 };
@@ -67,18 +112,18 @@ template <bool INV> struct Dft<8, INV> {
         cf o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
         Dft<4, INV>::run(e0, e1, e2, e3);
         Dft<4, INV>::run(o0, o1, o2, o3);
-        // twiddles W8^k (forward exp(-i pi k/4), inverse conj)
-        cf w1 = INV ? make_float2(c * (o1.x - o1.y), c * (o1.x + o1.y)) : make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));
-        cf w2 = rot90<INV>(o2);
-        cf w3 = INV ? make_float2(-c * (o3.x + o3.y), c * (o3.x - o3.y)) : make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));
+        // twiddles W8^k (forward exp(-i pi k/4), inverse conj):
+        //   W8^1 o1 = c (o1 + rot90<INV>(o1)),  W8^2 o2 = rot90<INV>(o2),  W8^3 o3 = -c (o3 + rot90<!INV>(o3))
+        const cf s1 = add_rot<INV>(o1, o1);
+        const cf s3 = add_rot<!INV>(o3, o3);
         a[0] = cadd(e0, o0);
         a[4] = csub(e0, o0);
-        a[1] = cadd(e1, w1);
-        a[5] = csub(e1, w1);
-        a[2] = cadd(e2, w2);
-        a[6] = csub(e2, w2);
-        a[3] = cadd(e3, w3);
-        a[7] = csub(e3, w3);
+        a[1] = caxpy(e1, c, s1);
+        a[5] = caxpy(e1, -c, s1);
+        a[2] = add_rot<INV>(e2, o2);
+        a[6] = sub_rot<INV>(e2, o2);
+        a[3] = caxpy(e3, -c, s3);
+        a[7] = caxpy(e3, c, s3);
     }
 };
 
