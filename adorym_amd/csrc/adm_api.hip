@@ -247,6 +247,8 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->n_steps = (d.obj_z + d.binning - 1) / d.binning;
     p->h_dev = p->hfree_dev = p->twid_dev = nullptr;
     p->hs_dev = p->hfree_s_dev = p->twid_y_dev = nullptr;
+    p->trans_dev = nullptr;
+    p->trans_src = nullptr;
     p->generic = !tuned;
     {   // radix lists of the generic kernel's transforms: 8, 4, 2, 9, 3, 5, 7, then whatever primes remain
         auto factor = [](int n, int* r) {
@@ -318,6 +320,7 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->hfree_s_dev) adm_free(plan->ctx, plan->hfree_s_dev);
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
     if (plan->reg_partial) (void)hipFree(plan->reg_partial);
+    if (plan->trans_dev) (void)hipFree(plan->trans_dev);
     if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
     delete plan;
     return ADM_OK;
@@ -445,8 +448,16 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
     }
     const bool lean = plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
                       d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
-    if (lean) ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
-    else ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    if (lean) {
+        ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
+    } else {
+        // cached slice transmissions: only for the buffer they were computed from
+        if (plan->trans_dev && plan->trans_src == (const void*)obj_rot && d.unknown_type == 0 && d.binning == 1) {
+            p.obj_rot = plan->trans_dev;
+            p.pre_t = 1;
+        }
+        ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
+    }
     if (!per_position && grad_probe && want_grad)
         ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
     return ADM_OK;

@@ -39,6 +39,8 @@ struct adm_plan {
     float2* twid_y_dev;    // [Py] exp(-2 pi i j / Py)
     bool h_sym;            // H(ky, kx) == H(ky, N - kx) for the slice and detector kernels (every get_kernel() output)
     int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
+    float2* trans_dev;     // [Z][Yp][Xp] slice transmissions of the voxels of trans_src, or nullptr (adm_plan_set_transmission_cache)
+    const void* trans_src; // the obj_rot buffer trans_dev was last filled from (adm_rotate_fwd / adm_transmission_refresh)
 };
 
 namespace adm {
@@ -47,7 +49,7 @@ int fail(int code, const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
 
 struct MsParams {
-    const float2* obj_rot;     // [Z][Yp][Xp] (delta, beta)
+    const float2* obj_rot;     // [Z][Yp][Xp] (delta, beta); pre_t: the cached slice transmissions instead
     int want_grad;             // 0 = forward only
     const float2* probe;       // [P][P]
     float2* grad_probe;        // [P][P] or nullptr
@@ -71,6 +73,7 @@ struct MsParams {
     int loss_type;             // 0 LSQ on magnitudes, 1 Poisson
     float poisson_mult;
     int real_imag;             // unknown_type == 'real_imag'
+    int pre_t;                 // obj_rot holds exp(-k1 beta) (cos, sin)(-sigma k1 delta) per voxel (adm_plan_set_transmission_cache)
     const float* det_weight;   // [P][P] 0/1 weights of the detector pixels in the loss (beamstop), reference layout; or nullptr
     size_t probe_bstride;      // float2 elements between the probes of consecutive positions (0 = one shared probe set)
     size_t gprobe_bstride;     // same for grad_probe (per-position gradients when the probes are per position)

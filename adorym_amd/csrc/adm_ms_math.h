@@ -211,4 +211,14 @@ template <int R1, bool CONJ> __device__ __forceinline__ void modulate(cf (&a)[R1
     }
 }
 
+// The factor modulate<> multiplies with, for ONE voxel -- what adm_rotate_fwd stores per rotated-frame voxel when the
+// plan caches the slice transmissions.  Always the general sincos path: for |phi| <= pi/4 its reduction is the identity
+// (q = 0, r = fma(0, c, phi) = phi), so the value is bit-identical to either path of modulate<>.
+__device__ __forceinline__ float2 slice_transmission(float2 db, float k1, float sigma) {
+    float sn, cs;
+    sincos_fast(-sigma * k1 * db.x, sn, cs);
+    const float e = exp_fast(-k1 * db.y);
+    return make_float2(e * cs, e * sn);
+}
+
 }  // namespace adm

@@ -115,7 +115,6 @@ __device__ __forceinline__ void y_inv_p1(Ctx<N, R1, R2>& c) {
 
 // psi <- IFFT2( Hmul * FFT2(psi) ), psi in registers `a` (row role) on entry and exit.
 // CONJ: multiply by conj(H) (adjoint).  H already carries the 1/N^2 of the inverse.  The thread <-> (ky, kx)
-// map is static, so H is read from an LDS image with the same addressing as the field element it multiplies
 // map is static, so H is read from registers `hs` (the slice kernel, or the one-off detector-plane Fresnel kernel).
 //
 // `hook(P<i>)`, i = 0..3, runs at four points spread over the convolution (after the x passes, before and after the
@@ -242,7 +241,11 @@ __device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restri
     }
 }
 
-template <int N, int R1, int R2, bool BIN1, bool RI>
+// MODE 0: (delta, beta) slices, exp / sincos evaluated here; 1: real_imag (the slice IS the transmission, an unknown);
+// 2: (delta, beta) unknowns, but `tile_base` points at the slice transmissions adm_rotate_fwd cached per voxel
+//    (adm_plan_set_transmission_cache): the same numbers modulate<> would compute, evaluated once per voxel instead
+//    of once per covering probe position and sweep -- the slice loop then has no transcendental at all.
+template <int N, int R1, int R2, bool BIN1, int MODE>
 __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, float2* stash,
                                           const float2* tile_base, size_t slice_stride, bool do_grad) {
     using GE = Geo<N, R1, R2>;
@@ -254,13 +257,18 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
         ADM_STAMP_ON(blockIdx.x == 0 && step == 100);
         ADM_STAMP(0);
         if (c.act1) {
-            if (RI) {
+            if (MODE == 1) {
                 // the slice IS the complex transmission; its gradient needs the PRE-modulation field
                 if (do_grad) ws_store<R1>(stash + (size_t)step * R1 * GE::NT, GE::NT, tid, a);
 #pragma unroll
                 for (int k = 0; k < R1; ++k) a[k] = cmul(a[k], db[k]);
             } else {
-                modulate<R1, false>(a, db, p.k1, p.sigma);
+                if (MODE == 2) {
+#pragma unroll
+                    for (int k = 0; k < R1; ++k) a[k] = cmul(a[k], db[k]);
+                } else {
+                    modulate<R1, false>(a, db, p.k1, p.sigma);
+                }
                 ADM_STAMP(1);
                 if (do_grad) ws_store<R1>(stash + (size_t)step * R1 * GE::NT, GE::NT, tid, a);
             }
@@ -276,10 +284,11 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
 }
 
 // ACC: add to the tile gradient already stored by a previous probe mode instead of overwriting it
-template <int N, int R1, int R2, bool BIN1, bool ACC, bool RI>
+template <int N, int R1, int R2, bool BIN1, bool ACC, int MODE>
 __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, const float2* stash,
                                           float2* gtile, const float2* tile_base, size_t slice_stride) {
     using GE = Geo<N, R1, R2>;
+    constexpr bool RI = (MODE == 1);
     const float sk1 = p.sigma * p.k1;
     const int tid = threadIdx.x;
     ADM_STAMP_DECL;
@@ -311,7 +320,11 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
             }
             ws_store<R1>(grow, GE::NT, tid, g);
             ADM_STAMP(9);
-            if (!RI) modulate<R1, true>(a, db, p.k1, p.sigma);
+            if (MODE == 0) modulate<R1, true>(a, db, p.k1, p.sigma);
+            if (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < R1; ++k) a[k] = cmulc(a[k], db[k]);
+            }
             ADM_STAMP(10);
             if (step > 0) {
                 load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
@@ -370,7 +383,7 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
 
 // PP: one probe set per position (sub-pixel probe positions); a template parameter because even the two extra address
 // computations measurably perturb the schedule of the tuned default kernel (+3 %).
-template <int N, int R1, int R2, bool BIN1, bool MULTI, bool RI, bool PP>
+template <int N, int R1, int R2, bool BIN1, bool MULTI, int MODE, bool PP>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
@@ -428,7 +441,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     if (!MULTI) {
         // ================= single probe mode: everything stays in registers =================
         load_probe<N, R1, R2>(c, a, PP ? p.probe + (size_t)b * p.probe_bstride : p.probe);
-        fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
+        fwd_sweep<N, R1, R2, BIN1, MODE>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
         detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
         if (p.det_mode == ADM_DET_FARFIELD_) {
             if (c.act2) {
@@ -461,7 +474,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
-        rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+        rev_sweep<N, R1, R2, BIN1, false, MODE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
         add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr, p.gprobe_bstride != 0);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
@@ -475,7 +488,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         for (int k = 0; k < GE::G; ++k) inten[k] = 0.f;
         for (int m = 0; m < M; ++m) {
             load_probe<N, R1, R2>(c, a, p.probe + (PP ? (size_t)b * p.probe_bstride : 0) + (size_t)m * N * N);
-            fwd_sweep<N, R1, R2, BIN1, RI>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
+            fwd_sweep<N, R1, R2, BIN1, MODE>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
             detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
             float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
             if (far) {
@@ -536,8 +549,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
                 for (int k = 0; k < R1; ++k) a[k] = cscale(dq[(size_t)k * GE::NT], gf[k]);
             }
             detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
-            if (m == 0) rev_sweep<N, R1, R2, BIN1, false, RI>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
-            else rev_sweep<N, R1, R2, BIN1, true, RI>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
+            if (m == 0) rev_sweep<N, R1, R2, BIN1, false, MODE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+            else rev_sweep<N, R1, R2, BIN1, true, MODE>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
             add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride + (size_t)m * N * N : nullptr,
                                       p.gprobe_bstride != 0);
         }
@@ -554,17 +567,22 @@ namespace adm {
 template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int batch, hipStream_t st) {
     using GE = Geo<N, R1, R2>;
     const dim3 g(batch), t(GE::NT);
-#define ADM_LAUNCH(B1, MU, RI_, PP_) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, B1, MU, RI_, PP_>), g, t, 0, st, p)
+#define ADM_LAUNCH(B1, MU, MODE_, PP_) hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, B1, MU, MODE_, PP_>), g, t, 0, st, p)
     const bool multi = p.n_modes > 1;
-    if (p.probe_bstride) {          // per-position probes: binning == 1 only (checked by the caller)
-        if (p.real_imag) { if (multi) ADM_LAUNCH(true, true, true, true); else ADM_LAUNCH(true, false, true, true); }
-        else { if (multi) ADM_LAUNCH(true, true, false, true); else ADM_LAUNCH(true, false, false, true); }
-    } else if (p.real_imag) {       // binning == 1 is enforced at plan creation
-        if (multi) ADM_LAUNCH(true, true, true, false); else ADM_LAUNCH(true, false, true, false);
+    // binning == 1 is enforced for real_imag at plan creation, for per-position probes and the cached transmissions
+    // by the caller
+    if (p.probe_bstride) {
+        if (p.real_imag) { if (multi) ADM_LAUNCH(true, true, 1, true); else ADM_LAUNCH(true, false, 1, true); }
+        else if (p.pre_t) { if (multi) ADM_LAUNCH(true, true, 2, true); else ADM_LAUNCH(true, false, 2, true); }
+        else { if (multi) ADM_LAUNCH(true, true, 0, true); else ADM_LAUNCH(true, false, 0, true); }
+    } else if (p.real_imag) {
+        if (multi) ADM_LAUNCH(true, true, 1, false); else ADM_LAUNCH(true, false, 1, false);
+    } else if (p.pre_t) {
+        if (multi) ADM_LAUNCH(true, true, 2, false); else ADM_LAUNCH(true, false, 2, false);
     } else if (multi) {
-        if (p.binning == 1) ADM_LAUNCH(true, true, false, false); else ADM_LAUNCH(false, true, false, false);
+        if (p.binning == 1) ADM_LAUNCH(true, true, 0, false); else ADM_LAUNCH(false, true, 0, false);
     } else {
-        if (p.binning == 1) ADM_LAUNCH(true, false, false, false); else ADM_LAUNCH(false, false, false, false);
+        if (p.binning == 1) ADM_LAUNCH(true, false, 0, false); else ADM_LAUNCH(false, false, 0, false);
     }
 #undef ADM_LAUNCH
     return hipGetLastError();

@@ -55,8 +55,11 @@ __device__ __forceinline__ Bilin make_bilin(const uint16_t* coords, int xr, int 
     return b;
 }
 
+// trans != nullptr: the slice transmission of every gathered voxel is stored beside it (same layout), so that the
+// multislice kernel multiplies with a loaded number instead of evaluating exp / sincos per covering position and sweep.
 __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restrict__ obj, const uint16_t* __restrict__ coords,
-                                                         float2* __restrict__ rot, RotGeom g, int y_lo, int y_hi, int y_chunk) {
+                                                         float2* __restrict__ rot, float2* __restrict__ trans, float k1, float sigma,
+                                                         RotGeom g, int y_lo, int y_hi, int y_chunk) {
     const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
     const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (xr >= g.X || zr >= g.Z) return;
@@ -70,7 +73,22 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restric
         float2 r;
         r.x = v00.x * b.w00 + v01.x * b.w01 + v10.x * b.w10 + v11.x * b.w11;
         r.y = v00.y * b.w00 + v01.y * b.w01 + v10.y * b.w10 + v11.y * b.w11;
-        rot[((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr] = r;
+        const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
+        rot[o_rot] = r;
+        if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
+    }
+}
+
+// slice transmissions of rows [row_lo, row_hi) of every slice of a rotated-frame buffer (pads included): the cache's
+// initial fill (obj_rot == nullptr: vacuum, 1 + 0i) and adm_transmission_refresh
+__global__ __launch_bounds__(256) void transmission_kernel(const float2* __restrict__ rot, float2* __restrict__ trans, float k1,
+                                                           float sigma, int Z, int Yp, int Xp, int row_lo, int row_hi) {
+    const size_t per = (size_t)(row_hi - row_lo) * Xp;
+    const size_t n = per * Z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = i / per, r = i - z * per;
+        const size_t o = (z * Yp + row_lo) * Xp + r;
+        trans[o] = rot ? slice_transmission(rot[o], k1, sigma) : make_float2(1.f, 0.f);
     }
 }
 
@@ -700,10 +718,51 @@ extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* 
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
     const int y_chunk = 32;
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
-    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, (float2*)obj_rot, g,
-                       y_lo, y_hi, y_chunk);
+    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, (float2*)obj_rot,
+                       plan->trans_dev, d.k1, (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    if (plan->trans_dev) plan->trans_src = obj_rot;
+    return ADM_OK;
+}
+
+static int transmission_fill(adm_plan* plan, const float* obj_rot, int row_lo, int row_hi) {
+    const adm_plan_desc& d = plan->d;
+    const size_t n = (size_t)(row_hi - row_lo) * plan->Xp * d.obj_z;
+    hipLaunchKernelGGL(transmission_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, plan->ctx->stream,
+                       (const float2*)obj_rot, plan->trans_dev, d.k1, (float)d.sign_convention, d.obj_z, plan->Yp, plan->Xp, row_lo,
+                       row_hi);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
+}
+
+extern "C" int adm_plan_set_transmission_cache(adm_plan* plan, int on) {
+    if (!plan) return fail(ADM_ERR_INVALID, "adm_plan_set_transmission_cache: null plan");
+    const adm_plan_desc& d = plan->d;
+    if (!on) {
+        if (plan->trans_dev) {
+            ADM_HIP(hipStreamSynchronize(plan->ctx->main_stream));
+            ADM_HIP(hipFree(plan->trans_dev));
+        }
+        plan->trans_dev = nullptr;
+        plan->trans_src = nullptr;
+        return ADM_OK;
+    }
+    if (d.unknown_type != 0 || d.binning != 1)
+        return fail(ADM_ERR_UNSUPPORTED, "adm_plan_set_transmission_cache: needs unknown_type delta_beta and binning 1");
+    if (plan->trans_dev) return ADM_OK;
+    ADM_HIP(hipMalloc((void**)&plan->trans_dev, (size_t)d.obj_z * plan->Yp * plan->Xp * sizeof(float2)));
+    plan->trans_src = nullptr;
+    return transmission_fill(plan, nullptr, 0, plan->Yp);      // vacuum everywhere: the pads keep it forever
+}
+
+extern "C" int adm_transmission_refresh(adm_plan* plan, const float* obj_rot, int y_lo, int y_hi) {
+    if (!plan || !obj_rot) return fail(ADM_ERR_INVALID, "adm_transmission_refresh: null argument");
+    if (!plan->trans_dev) return fail(ADM_ERR_INVALID, "adm_transmission_refresh: the plan has no transmission cache");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_transmission_refresh: bad y range");
+    plan->trans_src = obj_rot;
+    if (y_lo == y_hi) return ADM_OK;
+    return transmission_fill(plan, obj_rot, d.pad_y0 + y_lo, d.pad_y0 + y_hi);
 }
 
 extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords, float* grad_obj, int y_lo, int y_hi) {

@@ -104,7 +104,7 @@ class MultisliceEngine(object):
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
                  n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta',
-                 beamstop=None, generic=False):
+                 beamstop=None, generic=False, transmission_cache=True):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -135,6 +135,10 @@ class MultisliceEngine(object):
                          poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
         if generic:
             self.plan.set_generic(True)       # the any-size kernel even where a tuned one exists (tests, A/B timing)
+        # slice transmissions cached per rotated-frame voxel by rotate() (include/adm.h: adm_plan_set_transmission_cache)
+        self.transmission_cache = bool(transmission_cache) and unknown_type == 'delta_beta' and binning == 1
+        if self.transmission_cache:
+            self.plan.set_transmission_cache(True)
         self.unknown_type = unknown_type
         self.loss_function_type = loss_function_type
         self.pads = pads

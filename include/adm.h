@@ -211,6 +211,16 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
  * H(ky,kx) == H(ky,N-kx), probe 64 or 72).  Batches of at least `min_batch` positions use the second where it applies;
  * 0 = never (the default: opt-in).  No reference counterpart: a tuning knob of this library. */
 int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch);
+/* Slice-transmission cache (delta_beta unknowns, binning 1).  The reference evaluates exp(-k1*beta) * (cos, sin)(-sigma*k1*delta)
+ * for every voxel of every tile it extracts (adorym/propagate.py:241 through wrappers.py:600-608), i.e. once per covering
+ * probe position -- up to ~40 times per voxel and angle in config 3 -- and autograd once more in the backward pass.  With the
+ * cache on, adm_rotate_fwd stores that factor per rotated-frame voxel (a plan-owned [Z][Yp][Xp] complex buffer, pads = 1+0i)
+ * beside obj_rot, and adm_multislice_fwd_adj[_pp] multiplies with the loaded number: bit-identical results (the same fp32
+ * expression, evaluated once), no transcendental in the slice loop.  The cache is used only for the obj_rot buffer it was
+ * last filled from; a caller that writes obj_rot by any other route than adm_rotate_fwd must call adm_transmission_refresh
+ * for the rows [y_lo, y_hi) (object coordinates) it changed.  Off by default at this level; adorym_amd's engine turns it on. */
+int adm_plan_set_transmission_cache(adm_plan* plan, int on);
+int adm_transmission_refresh(adm_plan* plan, const float* obj_rot, int y_lo, int y_hi);
 /* Probe sizes.  Any Py x Px with Py*Px <= 16384 whose field fits the LDS is accepted (the reference takes whatever
  * prj.shape[-2:] is, adorym/ptychography.py:313-317).  Square sizes in {8,12,16,18,24,27,32,36,64,72} run the tuned
  * register-resident kernels; every other size -- and every size after adm_plan_set_generic(plan, 1) -- runs the generic

@@ -347,3 +347,79 @@ def test_c2_sixteen_virtual_ranks_sum_vs_oracle(A, ctx):
 
 def c2(z):
     return np.stack([z.real, z.imag], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize('P,n_modes,theta,sign', [(72, 1, 0.6, 1), (64, 2, None, 1), (36, 1, 2.1, -1), (72, 1, None, 1)])
+def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign):
+    """adm_plan_set_transmission_cache: exp(-k1 beta)(cos, sin)(-sigma k1 delta) stored per rotated-frame voxel by
+    adm_rotate_fwd and loaded by the slice loop gives the SAME bits as evaluating it per position inside the loop (the
+    same fp32 expression, once per voxel): loss, prediction, object gradient, probe gradient.  Phases beyond pi/4 are
+    included so that both sincos paths of the in-loop modulator are compared.  Partial y ranges are rotated the way the
+    driver does it (footprint of the batch only), after a full rotation of ANOTHER object, so stale rows would show."""
+    r = cases.rng(77 + P + n_modes)
+    Y, X, S, B = P + 30, P + 41, 7, 9
+    pos = np.stack([r.integers(-6, Y - P + 6, B), r.integers(-6, X - P + 6, B)], 1)
+    k1 = 2 * np.pi * 1.0 / (1240. / cases.ENERGY_EV)
+    delta = r.uniform(0, 2.5 / k1, (Y, X, S))            # phases up to 2.5 rad: beyond the small-angle path
+    delta[:, : X // 2] *= 0.01                            # ... and a half that stays inside it
+    obj = np.stack([delta, r.uniform(0, 0.3 / k1, (Y, X, S))], -1).astype(np.float32)
+    other = np.stack([r.uniform(0, 1e-3, (Y, X, S)), r.uniform(0, 1e-4, (Y, X, S))], -1).astype(np.float32)
+    probe = r.standard_normal((n_modes, P, P, 2)).astype(np.float32)
+    meas = (np.abs(r.standard_normal((B, P, P))) * 10).astype(np.float32)
+    outs = []
+    for cache in (False, True):
+        eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B, n_probe_modes=n_modes,
+                                 sign_convention=sign, transmission_cache=cache)
+        assert eng.transmission_cache == cache
+        tab = A.RotationTable(ctx, (Y, X, S), np.float32(theta)) if theta is not None else None
+        coords = tab.coords if tab is not None else None
+        eng.rotate(ctx.array(other), coords)                               # every row holds something else first
+        eng.set_batch(pos, meas)
+        lo, hi = eng.y_footprint(pos)
+        eng.rotate(ctx.array(obj), coords, y_range=(lo, hi))
+        gp = ctx.zeros(probe.shape)
+        eng.multislice(ctx.array(probe), grad_probe=gp, want_pred=True)
+        g = ctx.zeros(obj.shape)
+        eng.rotate_adjoint(g, tab, y_range=(lo, hi))          # the table: deterministic gather (bare coords = float atomics)
+        outs.append((eng._loss.view(0, (B,)).get(), eng.pred(), eng.grad_rot.get(), g.get(), gp.get()))
+    for a, b in zip(*outs):
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_transmission_cache_tracks_its_source_buffer(A, ctx):
+    """The cache is used only for the obj_rot buffer adm_rotate_fwd last filled it from: a launch on ANOTHER rotated-frame
+    buffer silently takes the in-loop path (right answer), and adm_transmission_refresh adopts a buffer written by other
+    means.  Also: binning > 1 and real_imag plans refuse the cache."""
+    from adorym_amd import _lib
+    r = cases.rng(5)
+    P, Y, X, S, B = 16, 30, 34, 4, 3
+    pos = np.stack([r.integers(0, Y - P, B), r.integers(0, X - P, B)], 1)
+    obj = np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1).astype(np.float32)
+    obj2 = (obj * 3).astype(np.float32)
+    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
+    meas = (np.abs(r.standard_normal((B, P, P))) * 4).astype(np.float32)
+
+    def run(eng, rot_buf):
+        eng.set_batch(pos, meas)
+        lib = ctx.lib
+        assert lib.adm_multislice_fwd_adj(eng.plan.handle, rot_buf.ptr, probe.ptr, eng._cur_pos.ptr, B, eng._cur_target.ptr, 1, None,
+                                          None, eng._loss.ptr, 1.0, eng._ws.ptr, eng._ws.nbytes) == _lib.ADM_OK
+        return eng._loss.view(0, (B,)).get()
+
+    ref = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B, transmission_cache=False)
+    ref.rotate(ctx.array(obj2), None)
+    want2 = run(ref, ref.obj_rot)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
+    eng.rotate(ctx.array(obj), None)                      # cache <- obj
+    other = ctx.zeros(eng.plan.rot_shape)
+    other.set(ref.obj_rot.get())                          # a second rotated-frame buffer holding obj2, written by a plain copy
+    assert np.array_equal(run(eng, other), want2)         # not the cached buffer: in-loop path, obj2's answer
+    assert ctx.lib.adm_transmission_refresh(eng.plan.handle, other.ptr, 0, Y) == _lib.ADM_OK
+    assert np.array_equal(run(eng, other), want2)         # adopted: cached path, same bits
+    assert ctx.lib.adm_transmission_refresh(eng.plan.handle, other.ptr, 3, 2) == _lib.ADM_ERR_INVALID
+    for kw in (dict(binning=2), dict(unknown_type='real_imag')):
+        e2 = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B, **kw)
+        assert not e2.transmission_cache
+        assert ctx.lib.adm_plan_set_transmission_cache(e2.plan.handle, 1) == _lib.ADM_ERR_UNSUPPORTED
+    assert ctx.lib.adm_transmission_refresh(ref.plan.handle, other.ptr, 0, Y) == _lib.ADM_ERR_INVALID     # no cache on that plan

@@ -11,7 +11,8 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 fwd_only = len(sys.argv) > 3 and sys.argv[3] == 'fwd'
 cfg = W.c3_config()
 ctx = A.Context(0)
-eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'], max_batch=B)
+eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'], max_batch=B,
+                         transmission_cache=os.environ.get('ADM_TCACHE', '1') == '1')      # ADM_TCACHE=0: exp / sincos in the slice loop
 if os.environ.get('ADM_LEAN') is not None:      # 1: throughput kernel for every batch, 0: never
     eng.plan.set_lean_min_batch(1 if os.environ['ADM_LEAN'] == '1' else 0)
 Y, X, Z = cfg['obj_size']
