@@ -381,6 +381,13 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
     }
 }
 
+// position handled by workgroup `wg` of a launch of B: XCD k = wg % 8 owns positions [k*q + min(k, r), ...), q = B / 8, r = B % 8
+__device__ __forceinline__ int xcd_position(int wg, int B) {
+    const int k = wg & 7, slot = wg >> 3;
+    const int q = B >> 3, r = B & 7;
+    return k * q + min(k, r) + slot;
+}
+
 // PP: one probe set per position (sub-pixel probe positions); a template parameter because even the two extra address
 // computations measurably perturb the schedule of the tuned default kernel (+3 %).
 template <int N, int R1, int R2, bool BIN1, bool MULTI, int MODE, bool PP>
@@ -405,7 +412,10 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     c.row_p2 = c.line * GE::Q + tc2 * GE::ROW_P2_T;
     c.col_p1 = GE::posx(c.line) + c.t * GE::COL_P1_T;
     c.col_p2 = GE::posx(c.line) + tc2 * GE::COL_P2_T;
-    const int b = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md: speed only, never correctness), and
+    // consecutive positions of a scan overlap by ~90 % of a tile: XCD k takes the k-th CONTIGUOUS eighth of the batch, so
+    // that the tile slices its workgroups read in near lock-step are largely the same lines of that XCD's L2.
+    const int b = xcd_position(blockIdx.x, gridDim.x);
 
     // ---- static per-thread constants ----
 #pragma unroll

@@ -259,7 +259,8 @@ class PtychographyModel(ForwardModel):
         mb = B // self.batch_group
         gs = 2.0 / (mb * eng.n_det)     # each reference minibatch is a mean over ITS positions (and the kept detector pixels)
         if want_grad and shifts is None and B > eng.N_CU:
-            ctx.join()              # the overlapped launch uses the side stream itself
+            # no join here: the overlapped launch forks again, and the side stream is in order, so its overlap-adds queue
+            # behind the regulariser kernel while the first round of workgroups already runs beside it
             eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)
         else:
             eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,

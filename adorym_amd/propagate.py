@@ -316,6 +316,7 @@ class MultisliceEngine(object):
         B = self._B
         if B <= self.N_CU:
             self.multislice(probe, grad_probe=grad_probe, want_grad=True, want_pred=want_pred, grad_scale=grad_scale)
+            self.ctx.join()                   # side-stream work the caller queued before the launch (no-op if none)
             return
         Py, Px = self.probe_size
         if grad_scale is None:

@@ -146,8 +146,7 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         state.finish_update()
         check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * n_groups, cfg['alpha_b'] * n_groups,
                                        cfg['gamma'] * n_groups, state.grad.ptr, None))
-        ctx.end_fork()
-        ctx.join()                  # (the side work is short; the overlapped launch below forks again)
+        ctx.end_fork()              # no join: the overlapped launch forks again and the side stream is in order
         e0.record()
         eng.multislice_overlapped(probe, grad_scale=2.0 / (mb * Py * Px))     # full rounds | overlap-add beside the last round
         e1.record()
@@ -244,6 +243,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-per-angle', action='store_true', help="skip the secondary full-chip legs (per angle, virtual ranks, sweep)")
     ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
+    ap.add_argument('--legs', default='per_angle,vr8,vr16,sweep', help='which secondary full-chip legs to run (profiling aid)')
     ap.add_argument('--force-dist', action='store_true', help='use the multi-GPU (RCCL) code path even with one rank')
     ap.add_argument('--comm', choices=('rccl', 'torch'), default='rccl',
                     help="collectives through libadm's C ABI (default) or through torch.distributed's nccl backend")
@@ -420,14 +420,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         if world == 1 and not args.no_per_angle:
+            legs = args.legs.split(',')
             k_angle = -(-n_pos // B)
-            out['per_angle'] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle,
-                                                   {'update_scheme': 'per angle'})
+            if 'per_angle' in legs:
+                out['per_angle'] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle,
+                                                       {'update_scheme': 'per angle'})
             for R in (8, 16):
-                out['virtual_ranks_%d' % R] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, R,
-                                                                  {'update_scheme': 'immediate', 'virtual_ranks': R,
-                                                                   'semantics': 'global batch R x 32 of one angle, gradients summed (mpirun -n R)'})
-            out['kernel_sweep'] = kernel_sweep(ctx, eng, probe, cfg, targets)
+                if 'vr%d' % R in legs:
+                    out['virtual_ranks_%d' % R] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, R,
+                                                                      {'update_scheme': 'immediate', 'virtual_ranks': R,
+                                                                       'semantics': 'global batch R x 32 of one angle, gradients summed (mpirun -n R)'})
+            if 'sweep' in legs:
+                out['kernel_sweep'] = kernel_sweep(ctx, eng, probe, cfg, targets)
         if world == 1 and not args.no_driver:
             out['driver'] = driver_measure(cfg, 16, 'immediate')
             out['driver']['engine_loop_ms_per_step'] = ms_per_step
