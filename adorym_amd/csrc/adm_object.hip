@@ -343,16 +343,30 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     out[0] = (unsigned)cnt;
 }
 
-// One thread owns one padded pixel and TA_STEPS consecutive modulation steps (4: measured best of 2/4/8/16): for every covering tile it issues
-// TA_STEPS independent 8-B loads (stride = one step of that tile) before touching the accumulators, so a wave keeps
-// TA_STEPS x 64 loads in flight instead of one dependent load per iteration.
+// One thread owns one padded pixel and TA_STEPS consecutive modulation steps: for every covering tile it issues TA_STEPS
+// independent 8-B loads (stride = one step of that tile) before touching the accumulators (TA_CU > 1: of TA_CU tiles at a
+// time).  With the XCD-aware grid below the kernel is bound by how much of a fetched line its neighbours still find in
+// their L2, so FEWER steps per block are better: 256 positions take 0.76 / 0.87 / 1.01 ms at TA_STEPS 2 / 4 / 8 (round 1,
+// blockIdx = (x, y, z): 0.97 at 4, the best of 2/4/8/16 then); TA_CU 2-8 and an x loop inside the block change nothing.
 #ifndef TA_STEPS
-#define TA_STEPS 4
+#define TA_STEPS 2
+#endif
+#ifndef TA_CU
+#define TA_CU 1
 #endif
 __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
                                                               float2* __restrict__ grad_rot, TileGeom g) {
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
+    // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs, and the 72-144-byte runs a block reads from a
+    // tile row straddle 128-byte lines that its x / y neighbours read too.  XCD k takes the step chunks k, k + 8, ... and
+    // ALL pixel blocks of each, x fastest, so that neighbours share an L2 (with blockIdx = (x, y, z) every straddled
+    // line was fetched from HBM by two or three XCDs; FETCH_SIZE -12 %, time -10 % from the mapping alone).
+    const int nbx = (g.Xp + 31) / 32, nby = (g.nrows + 7) / 8;
+    const int idx = blockIdx.x >> 3;
+    const int zc = (blockIdx.x & 7) + 8 * (idx / (nbx * nby));
+    if (zc * TA_STEPS >= g.n_steps) return;
+    const int rem = idx % (nbx * nby);
+    const int x = (rem % nbx) * 32 + (threadIdx.x & 31);
+    const int r = (rem / nbx) * 8 + (threadIdx.x >> 5);
     if (x >= g.Xp || r >= g.nrows) return;
     const size_t cplane = (size_t)g.nrows * g.Xp;
     const unsigned* cv = cover + (size_t)r * g.Xp + x;
@@ -361,13 +375,27 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     const size_t slice_stride = (size_t)g.Yp * g.Xp;
     float2* out = grad_rot + (size_t)(g.row0 + r) * g.Xp + x;
     const bool add = (g.row0 + r >= g.add_lo) && (g.row0 + r < g.add_hi);
-    const int st0 = blockIdx.z * TA_STEPS;
+    const int st0 = zc * TA_STEPS;
     const int nst = min(TA_STEPS, g.n_steps - st0);
     float2 acc[TA_STEPS];
 #pragma unroll
     for (int i = 0; i < TA_STEPS; ++i) acc[i] = make_float2(0.f, 0.f);
     if (nst == TA_STEPS) {
-        for (int c = 0; c < cnt; ++c) {
+        int c = 0;
+        for (; c + TA_CU <= cnt; c += TA_CU) {         // TA_CU tiles x TA_STEPS steps in flight; added in list order
+            float2 v[TA_CU][TA_STEPS];
+#pragma unroll
+            for (int u = 0; u < TA_CU; ++u) {
+                const float2* src = gtile + (size_t)cv[(size_t)(1 + c + u) * cplane] + (size_t)st0 * step_stride;
+#pragma unroll
+                for (int i = 0; i < TA_STEPS; ++i) v[u][i] = src[(size_t)i * step_stride];
+            }
+#pragma unroll
+            for (int u = 0; u < TA_CU; ++u)
+#pragma unroll
+                for (int i = 0; i < TA_STEPS; ++i) { acc[i].x += v[u][i].x; acc[i].y += v[u][i].y; }
+        }
+        for (; c < cnt; ++c) {
             const float2* src = gtile + (size_t)cv[(size_t)(1 + c) * cplane] + (size_t)st0 * step_stride;
             float2 v[TA_STEPS];
 #pragma unroll
@@ -858,8 +886,9 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
     ADM_HIP(hipGetLastError());
-    grid.z = (plan->n_steps + TA_STEPS - 1) / TA_STEPS;
-    hipLaunchKernelGGL(tile_accumulate_kernel, grid, dim3(256), 0, st, gtile, (const unsigned*)cover, (float2*)grad_rot, g);
+    const unsigned nz8 = ((plan->n_steps + TA_STEPS - 1) / TA_STEPS + 7) / 8;      // step chunks per XCD
+    hipLaunchKernelGGL(tile_accumulate_kernel, dim3(8u * nz8 * grid.x * grid.y), dim3(256), 0, st, gtile, (const unsigned*)cover,
+                       (float2*)grad_rot, g);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, adorym_amd as A
 from adorym_amd import workloads as W
 cfg = W.c3_config(); ctx = A.Context(0)
