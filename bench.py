@@ -131,12 +131,17 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
     for j in range(n_groups):                # synthetic magnitudes: tile the ones generated for the main run
         tgt.view(j * mb * Py * Px, (mb, Py, Px)).copy_from(any_t)
     eng._reserve(B)
-    e0, e1 = ctx.event(), ctx.event()
+    e_pairs = [(ctx.event(), ctx.event()) for _ in range(2)]
     kern = []
+    prev = None
     ctx.sync()
     t0 = None
     for r in range(reps + 1):
+        e0, e1 = e_pairs[r & 1]
         if r == 1:
+            if prev is not None:
+                loss = eng.loss_result(prev[0])
+                prev = None
             ctx.sync()
             t0 = _t.perf_counter()
         it = r % len(tables)
@@ -152,9 +157,15 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         e1.record()
         eng.rotate_adjoint(state.grad, tables[it], None)
         state.exchange_and_update('adam', r, {'step_size': cfg['learning_rate']})
-        loss = eng.loss(last=mb)
-        if r >= 1:
-            kern.append(e0.elapsed_ms(e1))
+        # as in the main loop and the driver: the loss of step r is read back after step r+1 has been queued
+        token = eng.loss_async(last=mb)
+        if prev is not None:
+            loss = eng.loss_result(prev[0])
+            if prev[1] >= 1:
+                kern.append(e_pairs[prev[1] & 1][0].elapsed_ms(e_pairs[prev[1] & 1][1]))
+        prev = (token, r)
+    loss = eng.loss_result(prev[0])
+    kern.append(e_pairs[prev[1] & 1][0].elapsed_ms(e_pairs[prev[1] & 1][1]))
     ctx.sync()
     dt = (_t.perf_counter() - t0) / reps
     Y, X, Z = cfg['obj_size']
