@@ -26,7 +26,6 @@
 #include "adm_fft.h"
 #include "adm_ms_math.h"
 #include <type_traits>
-
 namespace adm {
 
 #ifdef ADM_STAMPS
@@ -117,11 +116,19 @@ __device__ __forceinline__ void y_inv_p1(Ctx<N, R1, R2>& c) {
 // CONJ: multiply by conj(H) (adjoint).  H already carries the 1/N^2 of the inverse.  The thread <-> (ky, kx)
 // map is static, so H is read from registers `hs` (the slice kernel, or the one-off detector-plane Fresnel kernel).
 //
-// `hook(P<i>)`, i = 0..3, runs at four points spread over the convolution (after the x passes, before and after the
-// spectral multiply, after the second barrier).  The sweeps issue their global loads / stores there, a few per point:
-// issued in one burst around the slice modulation, the 16-24 vector-memory instructions per thread of all 11 waves
-// queue up in the CU's address unit and that burst alone cost ~25 % of a slice step (tools/stamps.py, round 2).
+// `hook(P<i>)`, i = 0..3, runs at four points spread over the convolution (after the x passes, after the first barrier and
+// the first y pass, after the spectral multiply, after the second barrier).  The sweeps issue the NEXT step's global loads
+// there (Prefetch below), a few per point.  Issued in one burst beside the slice modulation and its stores, the 16
+// vector-memory instructions per thread of the 11 waves queue in the CU's single address / data path while the waves of a
+// SIMD take their turn by age, and the whole workgroup then waits at the first barrier for the youngest wave's burst:
+// 2.15 -> 1.81 ms at 32 positions, 2.95 -> 2.50 at 256, from the placement alone (same instructions, same registers).
+// Measured placements (kernel ms at 32 positions): everything before the propagation 2.15; everything at P0 / P1 / P2 / P3
+// 2.08 / 2.03 / 2.04 / 2.12; reverse loads over two points 1.91-1.93; over three (below) 1.81-1.83; stores moved too: no gain.
 template <int I> using P = std::integral_constant<int, I>;
+struct Prefetch {     // hook point at which each group of next-step loads is issued
+    static constexpr int FWD_DB0 = 0, FWD_DB1 = 2;                  // forward sweep: the two halves of the tile slice
+    static constexpr int REV_DB0 = 0, REV_DB1 = 1, REV_PSI = 2;     // reverse sweep: tile slice halves, stored wavefield
+};
 struct NoHook { template <class T> __device__ __forceinline__ void operator()(T) const {} };
 template <int N, int R1, int R2, bool CONJ, class Hook = NoHook>
 __device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], Hook hook = Hook()) {
@@ -217,13 +224,13 @@ __device__ __forceinline__ void block_loss(float lsum, float* red, float* out, i
 // sum of the (delta, beta) pairs of the slices of one modulation step for this thread's R1 pixels.
 // BIN1 (binning == 1): pure loads, so the caller can issue them one step ahead and let the
 // propagation hide their latency.
-template <int R1, int R2, bool BIN1>
+template <int R1, int R2, bool BIN1, int K0 = 0, int K1 = R1>
 __device__ __forceinline__ void load_db(float2 (&db)[R1], const float2* __restrict__ base, size_t slice_stride, int step,
                                         int binning, int Z) {
     if (BIN1) {
         const float2* q = base + (size_t)step * slice_stride;
 #pragma unroll
-        for (int k = 0; k < R1; ++k) db[k] = q[k * R2];
+        for (int k = K0; k < K1; ++k) db[k] = q[k * R2];
     } else {
         const int s_lo = step * binning;
         const int s_hi = min(s_lo + binning, Z);
@@ -273,11 +280,18 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
                 if (do_grad) ws_store<R1>(stash + (size_t)step * R1 * GE::NT, GE::NT, tid, a);
             }
             ADM_STAMP(2);
-            // next step's tile slice is requested before the propagation so its latency is hidden
-            if (step + 1 < p.n_steps) load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
         }
         ADM_STAMP(3);
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, hs);
+        // The next step's tile slice is requested DURING the propagation, half at a time at two of its hook points: early
+        // enough to land before the modulation, and not in one burst with the stores above (see Prefetch).
+        auto hook = [&](auto pt) {
+            constexpr int HP = decltype(pt)::value, H = BIN1 ? R1 / 2 : R1;
+            if (c.act1 && step + 1 < p.n_steps) {
+                if constexpr (HP == Prefetch::FWD_DB0) load_db<R1, R2, BIN1, 0, H>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
+                if constexpr (HP == Prefetch::FWD_DB1 && BIN1) load_db<R1, R2, BIN1, H, R1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
+            }
+        };
+        if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, hs, hook);
         ADM_STAMP(4);
     }
     ADM_STAMP_ON(false);
@@ -326,13 +340,17 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
                 for (int k = 0; k < R1; ++k) a[k] = cmulc(a[k], db[k]);
             }
             ADM_STAMP(10);
-            if (step > 0) {
-                load_db<R1, R2, BIN1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
-                ws_load<R1>(stash + (size_t)(step - 1) * R1 * GE::NT, GE::NT, tid, psi);
-            }
         }
         ADM_STAMP(11);
-        if (step > 0) convolve<N, R1, R2, true>(c, a, hs);
+        auto hook = [&](auto pt) {
+            constexpr int HP = decltype(pt)::value, H = BIN1 ? R1 / 2 : R1;
+            if (c.act1 && step > 0) {
+                if constexpr (HP == Prefetch::REV_DB0) load_db<R1, R2, BIN1, 0, H>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
+                if constexpr (HP == Prefetch::REV_DB1 && BIN1) load_db<R1, R2, BIN1, H, R1>(db, tile_base, slice_stride, step - 1, p.binning, p.Z);
+                if constexpr (HP == Prefetch::REV_PSI) ws_load<R1>(stash + (size_t)(step - 1) * R1 * GE::NT, GE::NT, tid, psi);
+            }
+        };
+        if (step > 0) convolve<N, R1, R2, true>(c, a, hs, hook);
         ADM_STAMP(12);
     }
     ADM_STAMP_ON(false);
