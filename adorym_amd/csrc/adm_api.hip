@@ -435,7 +435,10 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
         p.grad_probe = (float2*)((char*)workspace + ws_off_gprobe(plan, batch));
         p.gprobe_bstride = probe_elems;
     }
+    // cached slice transmissions: only for the buffer they were computed from (the two-per-CU kernel evaluates in the loop)
+    const bool use_t = plan->trans_dev && plan->trans_src == (const void*)obj_rot && d.unknown_type == 0 && d.binning == 1;
     if (plan->generic) {
+        if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
         if (per_position) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: per-position probes need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
         p.gen_py = d.probe_y; p.gen_px = d.probe_x;
         p.gen_nrx = plan->gen_nrx; p.gen_nry = plan->gen_nry;
@@ -451,11 +454,7 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
     if (lean) {
         ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
     } else {
-        // cached slice transmissions: only for the buffer they were computed from
-        if (plan->trans_dev && plan->trans_src == (const void*)obj_rot && d.unknown_type == 0 && d.binning == 1) {
-            p.obj_rot = plan->trans_dev;
-            p.pre_t = 1;
-        }
+        if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
         ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     }
     if (!per_position && grad_probe && want_grad)

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(1024) void ms_generic_kernel(MsParams p) {
                     if (do_grad) stash[(size_t)step * row + i] = a;      // pre-modulation field
                     a = cmul(a, db);
                 } else {
-                    a = cmul(a, gen_modulator(db, p.k1, p.sigma));
+                    a = cmul(a, p.pre_t ? db : gen_modulator(db, p.k1, p.sigma));      // pre_t: cached slice transmissions
                     if (do_grad) stash[(size_t)step * row + i] = a;      // post-modulation field
                 }
                 g.fld[i] = a;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(1024) void ms_generic_kernel(MsParams p) {
                 float2* gq = gtile + (size_t)step * row + i;
                 if (m > 0) { const float2 o = *gq; gr.x += o.x; gr.y += o.y; }
                 *gq = gr;
-                g.fld[i] = cmulc(a, RI ? db : gen_modulator(db, p.k1, p.sigma));
+                g.fld[i] = cmulc(a, (RI || p.pre_t) ? db : gen_modulator(db, p.k1, p.sigma));
             }
             __syncthreads();
             if (step > 0) gen_convolve<true>(g, p, p.gen_hs, v);

@@ -349,13 +349,15 @@ def c2(z):
     return np.stack([z.real, z.imag], -1).astype(np.float32)
 
 
-@pytest.mark.parametrize('P,n_modes,theta,sign', [(72, 1, 0.6, 1), (64, 2, None, 1), (36, 1, 2.1, -1), (72, 1, None, 1)])
-def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign):
+@pytest.mark.parametrize('P,n_modes,theta,sign,generic', [(72, 1, 0.6, 1, False), (64, 2, None, 1, False), (36, 1, 2.1, -1, False),
+                                                          (72, 1, None, 1, False), (72, 1, 0.6, 1, True), (20, 2, 1.3, 1, True)])
+def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign, generic):
     """adm_plan_set_transmission_cache: exp(-k1 beta)(cos, sin)(-sigma k1 delta) stored per rotated-frame voxel by
     adm_rotate_fwd and loaded by the slice loop gives the SAME bits as evaluating it per position inside the loop (the
     same fp32 expression, once per voxel): loss, prediction, object gradient, probe gradient.  Phases beyond pi/4 are
     included so that both sincos paths of the in-loop modulator are compared.  Partial y ranges are rotated the way the
-    driver does it (footprint of the batch only), after a full rotation of ANOTHER object, so stale rows would show."""
+    driver does it (footprint of the batch only), after a full rotation of ANOTHER object, so stale rows would show.
+    generic: the any-size kernel (adm_ms_generic.hip) reads the cache too."""
     r = cases.rng(77 + P + n_modes)
     Y, X, S, B = P + 30, P + 41, 7, 9
     pos = np.stack([r.integers(-6, Y - P + 6, B), r.integers(-6, X - P + 6, B)], 1)
@@ -369,7 +371,7 @@ def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign):
     outs = []
     for cache in (False, True):
         eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B, n_probe_modes=n_modes,
-                                 sign_convention=sign, transmission_cache=cache)
+                                 sign_convention=sign, transmission_cache=cache, generic=generic)
         assert eng.transmission_cache == cache
         tab = A.RotationTable(ctx, (Y, X, S), np.float32(theta)) if theta is not None else None
         coords = tab.coords if tab is not None else None
