@@ -216,6 +216,12 @@ class RcclComm(object):
         check(self.ctx.lib.adm_all_reduce(self.ctx.handle, dev.ptr, dev.size, 0))
         return dev
 
+    def broadcast(self, dev, root):
+        """In-place broadcast of a libadm device array (view) from rank ``root``."""
+        from ._lib import check
+        check(self.ctx.lib.adm_broadcast(self.ctx.handle, dev.ptr, dev.nbytes, int(root)))
+        return dev
+
     # ---- control plane (host) ----
     def barrier(self):
         if self.ctx is not None:

@@ -10,6 +10,8 @@ with  reduce_scatter(sum) -> fused Adam/GD + constraints on the owned shard -> a
 The element-wise kernels come from an ``ops`` object: HipOps (libadm; the product) -- tests inject a
 NumPy stand-in to exercise the sharding logic on CPU with the gloo backend.
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -97,6 +99,9 @@ class DataParallelObject(object):
             self.obj = ops.alloc(self.n_pad)
             self.grad = ops.alloc(self.n_pad)
         self.moments = [ops.alloc(self.per) for _ in range(n_moments)]   # ZeRO-1: only the owned shard
+        # in-place exchange only: gather the planes the next minibatches read first, the rest beside the next kernel
+        self.overlap_gather = self.inplace and hasattr(comm, 'broadcast') and os.environ.get('ADM_OVERLAP_GATHER', '1') == '1'
+        self._gather_pending = False
 
     # gradient exchange + update ------------------------------------------------------------
     def _apply(self, optimizer, i_batch, options, flags, mask, g, g_base, lo, hi):
@@ -117,11 +122,15 @@ class DataParallelObject(object):
     def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None, first=None):
         """optimizer: 'adam' | 'gd' | 'momentum'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict.
 
-        ``first=(lo, hi)`` (flat element range, single-rank runs): the part of the object the NEXT minibatch reads (its
-        y-planes).  Only that range is updated now; the rest of the (element-wise, order-independent) update is DEFERRED
-        until finish_update() -- which zero_grad() calls -- so that the caller can queue it on the context's side stream
-        after the next rotation, where it overlaps the next multislice kernel (which keeps only `minibatch` of the 256
-        CUs busy).  Same arithmetic, same result; nothing outside ``first`` may be read before finish_update()."""
+        ``first=(lo, hi)`` (flat element range): the part of the object the NEXT minibatch reads (its y-planes).  Nothing
+        outside ``first`` may be read before finish_update() -- which zero_grad() calls -- so that the caller can queue the
+        remainder on the context's side stream after the next rotation, where it overlaps the next multislice kernel (which
+        keeps only `minibatch` of the 256 CUs busy).  Same arithmetic, same result.
+          * one rank: only that range is updated now, the rest of the (element-wise, order-independent) update is deferred;
+          * several ranks, in-place RCCL exchange: every rank updates its whole shard (1/R of the object), then the part of
+            EVERY shard inside ``first`` is broadcast from its owner (a fraction of the object, from a few owners) and the full
+            all-gather is deferred to finish_update().  ``first`` must then be the SAME on every rank -- the union of the planes
+            the next minibatches of ALL ranks read -- because it shapes a collective."""
         self.finish_update()
         if self.inplace:
             self.comm.reduce_scatter_sum(self.grad, self.grad.view(self.lo, (self.per,)))
@@ -137,7 +146,14 @@ class DataParallelObject(object):
             self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, f_lo, f_hi)
         else:
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, self.hi)
-        if self.inplace:
+        f_lo, f_hi = (max(0, int(first[0])), min(self.n_pad, int(first[1]))) if first is not None else (0, self.n_pad)
+        if self.inplace and self.overlap_gather and (f_lo > 0 or f_hi < self.n):
+            for r in range(self.comm.size):
+                s_lo, s_hi = max(r * self.per, f_lo), min((r + 1) * self.per, f_hi)
+                if s_hi > s_lo:
+                    self.comm.broadcast(self.obj.view(s_lo, (s_hi - s_lo,)), r)
+            self._gather_pending = True
+        elif self.inplace:
             self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
         elif self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
@@ -145,6 +161,9 @@ class DataParallelObject(object):
 
     def finish_update(self):
         """Apply the part of the last update that exchange_and_update(first=...) deferred (on the current stream)."""
+        if self._gather_pending:            # a collective: every rank reaches this at the same point of its stream of calls
+            self._gather_pending = False
+            self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
         d = getattr(self, '_deferred', None)
         if d is not None:
             self._deferred = None

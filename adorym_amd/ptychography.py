@@ -808,11 +808,14 @@ def reconstruct_ptychography(
                         o['step_size'] = GDOptimizer.scheduled_step(i_opt_batch, o.get('step_size', 0.001), o.get('dynamic_rate', True),
                                                                     o.get('first_downrate_iteration', 92))
                     first = None
-                    if n_ranks == 1 and builtin_model and not is_multi_dist and i_batch + 1 < n_batch:
-                        # update the y-planes the next minibatch reads first; the rest of the element-wise update is queued
-                        # by that minibatch on the side stream (DataParallelObject.finish_update), beside its multislice kernel
+                    if (n_ranks == 1 or state.overlap_gather) and builtin_model and not is_multi_dist and i_batch + 1 < n_batch:
+                        # one rank: update the y-planes the next minibatch reads first; several ranks: gather the planes the
+                        # next minibatches of ALL ranks read first (the same range on every rank: it shapes a collective).
+                        # The rest -- of the element-wise update, or of the all-gather -- is queued by that minibatch on the
+                        # side stream (DataParallelObject.finish_update), beside its multislice kernel
+                        rank_batch(ind_list_rand, i_batch + 1, 0, minibatch_size, n_ranks)    # tops up a short last batch now
                         nxt = ind_list_rand[i_batch + 1]
-                        ny0, ny1 = engine.y_footprint(probe_pos_int[nxt[:minibatch_size, 1]])
+                        ny0, ny1 = engine.y_footprint(probe_pos_int[nxt[:n_ranks * minibatch_size, 1]])
                         if update_scheme == 'per angle' and fuse_per_angle:
                             ny0, ny1 = 0, this_obj_size[0]
                         plane = this_obj_size[1] * this_obj_size[2] * 2
@@ -857,8 +860,11 @@ def reconstruct_ptychography(
 
             # ---- intermediate output (ptychography.py:1231-1246; util.py:1958-2028, optimizers.py:1111-1160) ----
             if save_intermediate and ((save_intermediate_level == 'epoch' and i_batch == n_batch - 1) or save_intermediate_level == 'batch'):
-                if rank == 0 and is_last_batch_of_this_theta:
+                # finish_update() may hold a deferred collective (the rest of the all-gather): every rank calls it, on rank 0's
+                # condition (a global batch can straddle two angles, so `is_last_batch_of_this_theta` may differ between ranks)
+                if i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != ind_list_rand[i_batch][0, 0]:
                     state.finish_update()
+                if rank == 0 and is_last_batch_of_this_theta:
                     _write_intermediate(output_folder, obj.arr.get(), unknown_type, i_epoch, i_batch, save_history, opt_ls,
                                         probe_dev, optimizable_params, n_theta, is_multi_dist)
                 comm.barrier()

@@ -320,11 +320,12 @@ def main():
     # synthetic measurements: the forward model itself applied to a foam phantom ("data": "synthetic")
     truth = ctx.array(W.foam_object(cfg['obj_size'], seed=0))
     total = args.steps + args.warmup
-    plan_batches = []
+    plan_batches, plan_all = [], []
     for k in range(total):
         it = k % n_theta_used
-        start = ((k // n_theta_used) * world * B + rank * B) % (n_pos - B + 1)
-        plan_batches.append((it, np.arange(start, start + B)))
+        starts = [((k // n_theta_used) * world * B + r * B) % (n_pos - B + 1) for r in range(world)]
+        plan_batches.append((it, np.arange(starts[rank], starts[rank] + B)))
+        plan_all.append(np.concatenate([np.arange(s0, s0 + B) for s0 in starts]))      # what ALL ranks process in step k
     targets = {}
     for it, ind in plan_batches:
         key = (it, int(ind[0]))
@@ -378,9 +379,11 @@ def main():
         ctx.join()
         eng.rotate_adjoint(state.grad, tables[it], yr)
         # update the y-planes the next minibatch reads first; the rest of the Adam pass overlaps the next kernel
+        # (several ranks: the planes the next minibatches of ALL ranks read are gathered first, the rest of the all-gather
+        # runs on the side stream beside the next kernel -- the range shapes a collective, so it is the same on every rank)
         first = None
         if k + 1 < len(plan_batches):
-            ny0, ny1 = eng.y_footprint(pos_all[plan_batches[k + 1][1]])
+            ny0, ny1 = eng.y_footprint(pos_all[plan_all[k + 1]])
             first = (ny0 * X * Z * 2, ny1 * X * Z * 2)
         state.exchange_and_update('adam', k, opt_options, first=first)
         token = eng.loss_async()

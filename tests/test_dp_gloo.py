@@ -185,7 +185,7 @@ class HostOps(NumpyOps):
         NumpyOps.gd(self, x.a, g.a, g_base, lo, hi, *a)
 
 
-def _worker_inplace(rank, world, port, shape, seed, out_q):
+def _worker_inplace(rank, world, port, shape, seed, out_q, first=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch
@@ -203,6 +203,11 @@ def _worker_inplace(rank, world, port, shape, seed, out_q):
             self.dist.all_gather(parts, torch.from_numpy(shard_in.a.copy()))
             full_out.a[...] = torch.cat(parts).numpy()
 
+        def broadcast(self, dev, root):
+            t = torch.from_numpy(dev.a.copy())
+            self.dist.broadcast(t, src=root)
+            dev.a[...] = t.numpy()
+
     comm = GlooAsRccl()
     try:
         st = DataParallelObject(HostOps(), comm, shape)
@@ -214,7 +219,23 @@ def _worker_inplace(rank, world, port, shape, seed, out_q):
             g_all = [np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world)]
             st.zero_grad()
             st.grad.a[:n] += g_all[rank]
-            st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+            st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1, first=first)
+            if first is not None:
+                whole = first[0] <= 0 and first[1] >= n          # everything = the plain all-gather, nothing deferred
+                assert st.overlap_gather and st._gather_pending == (not whole)
+                # only the planes in `first` are current everywhere now; the rest of the gather is pending
+                early = np.array(st.obj.a[first[0]:first[1]])
+                other = 1 - rank
+                stale = np.array(st.obj.a[other * st.per:(other + 1) * st.per])      # the other rank's shard as we hold it
+        if first is not None:
+            st.finish_update()
+            assert not st._gather_pending
+            assert np.array_equal(early, st.obj.a[first[0]:first[1]])             # what was gathered first was already final
+            if not whole:
+                lo, hi = max(other * st.per, first[0]), min((other + 1) * st.per, first[1])
+                outside = np.ones(st.per, bool)
+                outside[max(0, lo - other * st.per):max(0, hi - other * st.per)] = False
+                assert not np.array_equal(stale[outside], st.obj.a[other * st.per:(other + 1) * st.per][outside])   # ... the rest was not
         seeds = comm.bcast_object(4242 if rank == 0 else None, root=0)
         comm.barrier()
         out_q.put((rank, np.array(st.obj.a[:n]), comm.max_over_ranks(rank), comm.sum_over_ranks(1.0), seeds))
@@ -222,14 +243,18 @@ def _worker_inplace(rank, world, port, shape, seed, out_q):
         comm.close()
 
 
-@pytest.mark.parametrize('shape', [(4, 5, 6, 2), (3, 3, 3, 2)])
-def test_inplace_exchange_of_the_rccl_backend_world2(shape):
+@pytest.mark.parametrize('shape,first', [((4, 5, 6, 2), None), ((3, 3, 3, 2), None), ((8, 5, 6, 2), (100, 300)), ((8, 5, 6, 2), (250, 400)),
+                                         ((3, 3, 3, 2), (0, 54))])
+def test_inplace_exchange_of_the_rccl_backend_world2(shape, first):
+    """first=(lo, hi): the planes the next minibatches read are broadcast from their owners right after the update and the
+    full all-gather is deferred to finish_update() (the driver queues it beside the next kernel); (0, n) = everything =
+    the plain all-gather."""
     import torch.multiprocessing as mp
     from oracle import adorym_oracle as O
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_inplace, args=(r, world, port, shape, 7, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_inplace, args=(r, world, port, shape, 7, q, first)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=120) for _ in procs]
     [p.join(60) for p in procs]

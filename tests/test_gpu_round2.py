@@ -175,7 +175,16 @@ def test_rccl_comm_world1_equals_local_bitwise(A, ctx):
                 st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
             st.zero_grad()
             st.grad.view(0, (n,)).set(grads[3])
-            st.exchange_and_update('gd', 0, {'step_size': 1e-5})
+            # first=: (RCCL) the named planes are broadcast from their owner now (adm_broadcast), the full all-gather is
+            # deferred to finish_update(), which the driver queues on the side stream beside the next kernel
+            st.exchange_and_update('gd', 0, {'step_size': 1e-5}, first=(84, 252))
+            if comm is rc:
+                assert st.overlap_gather and st._gather_pending
+            ctx.fork()
+            st.finish_update()
+            ctx.end_fork()
+            ctx.join()
+            assert not st._gather_pending
             out.append((st.obj.view(0, (n,)).get(), st.moments[0].get(), st.moments[1].get()))
         for a, b in zip(out[0], out[1]):
             assert np.array_equal(a[:n], b[:n])
