@@ -67,6 +67,8 @@ SIGNATURES = {
     'adm_all_gather': (_I, [_VP, _VP, _VP, _SZ]),
     'adm_all_reduce': (_I, [_VP, _VP, _SZ, _I]),
     'adm_broadcast': (_I, [_VP, _VP, _SZ, _I]),
+    'adm_comm_group_start': (_I, [_VP]),
+    'adm_comm_group_end': (_I, [_VP]),
     'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
     'adm_plan_destroy': (_I, [_VP]),
     'adm_plan_set_detector_mask': (_I, [_VP, _VP]),

@@ -222,6 +222,20 @@ class RcclComm(object):
         check(self.ctx.lib.adm_broadcast(self.ctx.handle, dev.ptr, dev.nbytes, int(root)))
         return dev
 
+    def group(self):
+        """Context manager: the collectives issued inside are launched as one operation (ncclGroupStart / End)."""
+        import contextlib
+        from ._lib import check
+
+        @contextlib.contextmanager
+        def _g():
+            check(self.ctx.lib.adm_comm_group_start(self.ctx.handle))
+            try:
+                yield
+            finally:
+                check(self.ctx.lib.adm_comm_group_end(self.ctx.handle))
+        return _g()
+
     # ---- control plane (host) ----
     def barrier(self):
         if self.ctx is not None:

@@ -32,6 +32,8 @@ struct Api {
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
 };
@@ -72,6 +74,8 @@ Api* api() {
     ADM_SYM(CommInitRank, "ncclCommInitRank")
     ADM_SYM(CommDestroy, "ncclCommDestroy")
     ADM_SYM(ReduceScatter, "ncclReduceScatter")
+    ADM_SYM(GroupStart, "ncclGroupStart")
+    ADM_SYM(GroupEnd, "ncclGroupEnd")
     ADM_SYM(AllGather, "ncclAllGather")
     ADM_SYM(AllReduce, "ncclAllReduce")
     ADM_SYM(Broadcast, "ncclBroadcast")
@@ -166,4 +170,21 @@ extern "C" int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root) {
     if (!buf) return fail(ADM_ERR_INVALID, "adm_broadcast: null argument");
     rc = api()->Broadcast(buf, buf, bytes, kUint8, root, ctx->comm, ctx->stream);
     return rc ? nccl_fail(rc, "ncclBroadcast") : ADM_OK;
+}
+
+// Several collectives of one communicator issued between the two calls are launched as ONE operation (ncclGroupStart /
+// ncclGroupEnd): the broadcasts of the object planes the next minibatches read, one per owning rank, run side by side
+// instead of one root at a time.
+extern "C" int adm_comm_group_start(adm_ctx* ctx) {
+    int rc = need(ctx, "adm_comm_group_start", true);
+    if (rc) return rc;
+    rc = api()->GroupStart();
+    return rc ? nccl_fail(rc, "ncclGroupStart") : ADM_OK;
+}
+
+extern "C" int adm_comm_group_end(adm_ctx* ctx) {
+    int rc = need(ctx, "adm_comm_group_end", true);
+    if (rc) return rc;
+    rc = api()->GroupEnd();
+    return rc ? nccl_fail(rc, "ncclGroupEnd") : ADM_OK;
 }

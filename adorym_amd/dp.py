@@ -148,10 +148,12 @@ class DataParallelObject(object):
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, self.hi)
         f_lo, f_hi = (max(0, int(first[0])), min(self.n_pad, int(first[1]))) if first is not None else (0, self.n_pad)
         if self.inplace and self.overlap_gather and (f_lo > 0 or f_hi < self.n):
-            for r in range(self.comm.size):
-                s_lo, s_hi = max(r * self.per, f_lo), min((r + 1) * self.per, f_hi)
-                if s_hi > s_lo:
-                    self.comm.broadcast(self.obj.view(s_lo, (s_hi - s_lo,)), r)
+            import contextlib
+            with (self.comm.group() if hasattr(self.comm, 'group') else contextlib.nullcontext()):   # one launch, all roots at once
+                for r in range(self.comm.size):
+                    s_lo, s_hi = max(r * self.per, f_lo), min((r + 1) * self.per, f_hi)
+                    if s_hi > s_lo:
+                        self.comm.broadcast(self.obj.view(s_lo, (s_hi - s_lo,)), r)
             self._gather_pending = True
         elif self.inplace:
             self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))

@@ -105,6 +105,9 @@ int adm_reduce_scatter(adm_ctx* ctx, const float* send, float* recv, size_t recv
 int adm_all_gather(adm_ctx* ctx, const float* send, float* recv, size_t send_count);
 int adm_all_reduce(adm_ctx* ctx, float* buf, size_t count, int op_max);
 int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root);
+/* Collectives issued between the two calls are launched together (ncclGroupStart / ncclGroupEnd). */
+int adm_comm_group_start(adm_ctx* ctx);
+int adm_comm_group_end(adm_ctx* ctx);
 
 /* ---- plan: static geometry + physics of one reconstruction ------------------------- */
 typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;

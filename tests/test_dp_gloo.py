@@ -203,6 +203,10 @@ def _worker_inplace(rank, world, port, shape, seed, out_q, first=None):
             self.dist.all_gather(parts, torch.from_numpy(shard_in.a.copy()))
             full_out.a[...] = torch.cat(parts).numpy()
 
+        def group(self):
+            import contextlib
+            return contextlib.nullcontext()      # gloo has no launch grouping; the calls simply run one after the other
+
         def broadcast(self, dev, root):
             t = torch.from_numpy(dev.a.copy())
             self.dist.broadcast(t, src=root)
