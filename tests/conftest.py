@@ -9,3 +9,20 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+import pytest
+
+
+@pytest.fixture(scope='session')
+def rccl_world1():
+    """ONE RcclComm (gloo control plane + RCCL behind the C ABI) at world size 1 for the whole session: tearing the process
+    group down and bringing it up again inside one process costs minutes, so the GPU tests that walk the multi-GPU code
+    path share it.  attach(ctx) gives every context its own RCCL communicator."""
+    import socket
+    from adorym_amd import comm as C
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    rc = C.RcclComm(device_index=0)
+    yield rc
+    rc.close()

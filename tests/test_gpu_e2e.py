@@ -208,3 +208,20 @@ def test_summary_intermediate_outputs_and_plugin_loss_methods(tmp_path):
     got = pm.get_regularization_value(ctx.array(x))
     assert abs(got - want) <= 1e-5 * abs(want)
     ctx.close()
+
+
+@pytest.mark.parametrize('extra', [dict(), dict(update_scheme='per angle'), dict(optimize_probe=True, probe_learning_rate=1e-3,
+                                                                                  save_intermediate=True, store_checkpoint=True,
+                                                                                  n_batch_per_checkpoint=3)])
+def test_driver_through_rccl_world1_equals_local_run_bitwise(tmp_path, extra, rccl_world1):
+    """The whole driver on the multi-GPU code path (RCCL behind the C ABI, in-place reduce-scatter, sharded Adam, the planes
+    the next minibatches read broadcast first and the full all-gather deferred to the side stream) at world size 1 gives
+    the local run's object, probe and loss log bit for bit -- every reader of the object (checkpoint, intermediate output,
+    regulariser, final output) sits behind finish_update()."""
+    kw = dict(n_epochs=2, optimizer='adam', learning_rate=1e-6, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)
+    kw.update(extra)
+    _, _, a = run(tmp_path / 'local', **kw)
+    _, _, b = run(tmp_path / 'rccl', comm=rccl_world1, **kw)
+    for k in ('delta', 'beta', 'probe_real', 'probe_imag'):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert np.array_equal(np.asarray(a['losses']), np.asarray(b['losses']))

@@ -147,21 +147,18 @@ def test_throughput_kernel_vs_latency_kernel_and_oracle(A, ctx, P, free_prop):
     assert rel(out[1][1], out[0][1]) < 2e-4
 
 
-def test_rccl_comm_world1_equals_local_bitwise(A, ctx):
+def test_rccl_comm_world1_equals_local_bitwise(A, ctx, rccl_world1):
     """The multi-GPU code path (adm_comm_init, in-place adm_reduce_scatter / adm_all_gather through RCCL, sharded update) at
     world size 1 gives bit for bit what the single-GPU path gives after 3 Adam steps and a GD step; the small-gradient
     all-reduce leaves a 1-rank buffer unchanged."""
-    import socket
     from adorym_amd import comm as C
     from adorym_amd.dp import DataParallelObject, HipOps
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     shape = (5, 6, 7, 2)
     r = cases.rng(9)
     n = int(np.prod(shape))
     x0 = (r.standard_normal(n) * 1e-3).astype(np.float32)
     grads = [r.standard_normal(n).astype(np.float32) for _ in range(4)]
-    rc = C.RcclComm(device_index=0).attach(ctx)
+    rc = rccl_world1.attach(ctx)
     try:
         assert (rc.rank, rc.size) == (0, 1) and ctx.lib.adm_comm_size(ctx.handle) == 1
         out = []
@@ -194,7 +191,9 @@ def test_rccl_comm_world1_equals_local_bitwise(A, ctx):
         assert rc.max_over_ranks(3.5) == 3.5 and rc.bcast_object({'a': 1}) == {'a': 1}
         rc.barrier()
     finally:
-        rc.close()
+        ctx.sync()
+        ctx.lib.adm_comm_destroy(ctx.handle)        # this context's communicator; the session's process group stays up
+        rc.ctx = None
 
 
 @pytest.mark.parametrize('lean', [0, 1])
