@@ -327,6 +327,9 @@ def main():
         plan_batches.append((it, np.arange(starts[rank], starts[rank] + B)))
         plan_all.append(np.concatenate([np.arange(s0, s0 + B) for s0 in starts]))      # what ALL ranks process in step k
     targets = {}
+    # (synthesised with the in-loop modulator, i.e. another template instance of the kernel, so that a rocprofv3 --stats
+    # summary of this command lists the forward-only synthesis launches separately from the measured forward+adjoint ones)
+    eng.plan.set_transmission_cache(False)
     for it, ind in plan_batches:
         key = (it, int(ind[0]))
         if key in targets:
@@ -339,6 +342,7 @@ def main():
         targets[key] = t
     truth.free()
     ctx.sync()
+    eng.plan.set_transmission_cache(eng.transmission_cache)
 
     opt_options = {'step_size': cfg['learning_rate']}
     # two sets of timing events / loss read-backs: step k's results are looked at after step k+1 has been queued, so the
