@@ -402,17 +402,19 @@ def test_config5_shape_driver_vs_reference(A, ctx, tmp_path):
     assert e < max(5e-3, 3 * e_ref), (e, e_ref)
 
 
-def test_overlapped_split_launch_matches_single_launch(A, ctx):
-    """A batch larger than the chip (B = 300 > 256 workgroups) launched as full rounds + overlap-add beside the short last
-    round (multislice_overlapped) gives the same tile-gradient sums and losses as one launch + one overlap-add."""
+@pytest.mark.parametrize('B', [300, 600])
+def test_overlapped_split_launch_matches_single_launch(A, ctx, B):
+    """A batch larger than the chip (B > 256 workgroups) launched as equal rounds (150 + 150, 200 + 200 + 200) with every
+    round's overlap-add beside the next round (multislice_overlapped) gives the same tile-gradient sums and losses as one
+    launch + one overlap-add."""
     r = cases.rng(314)
-    Y, X, S, P = 60, 64, 4, 16
-    pos = np.stack([r.integers(-6, Y - 8, 300), r.integers(-6, X - 8, 300)], 1)
-    pos[290:] = pos[:10]                                   # duplicates, like the padded minibatches of a fused angle
-    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=300)
+    Y, X, S, P = (60, 64, 4, 16) if B == 300 else (90, 96, 4, 16)     # (a pixel may be covered by at most 64 tiles of a launch)
+    pos = np.stack([r.integers(-6, Y - 8, B), r.integers(-6, X - 8, B)], 1)
+    pos[B - 10:] = pos[:10]                                # duplicates, like the padded minibatches of a fused angle
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
     obj = ctx.array(np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1).astype(np.float32))
     probe = ctx.array((r.standard_normal((1, P, P, 2))).astype(np.float32))
-    meas = (np.abs(r.standard_normal((300, P, P))) * 10).astype(np.float32)
+    meas = (np.abs(r.standard_normal((B, P, P))) * 10).astype(np.float32)
     out = []
     for overlapped in (False, True):
         eng.set_batch(pos, meas)
