@@ -882,7 +882,8 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)g.Yp * g.Xp * (ADM_MAXCOVER + 1));
     hipStream_t st = plan->ctx->stream;
-    ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    // (a batch of at most ADM_MAXCOVER positions cannot overflow a cover list: no flag to reset, one launch less per minibatch)
+    if (batch > ADM_MAXCOVER) ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
     ADM_HIP(hipGetLastError());
@@ -896,6 +897,10 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
 extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host) {
     if (!plan || !workspace || !overflow_host) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: null argument");
     if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: bad workspace");
+    if (batch <= ADM_MAXCOVER) {        // cannot overflow; the flag is not maintained for such batches
+        *overflow_host = 0;
+        return ADM_OK;
+    }
     char* ws = (char*)workspace;
     unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)plan->Yp * plan->Xp * (ADM_MAXCOVER + 1));
