@@ -59,7 +59,9 @@ SIGNATURES = {
     'adm_event_record': (_I, [_VP, _VP]),
     'adm_event_elapsed_ms': (_I, [_VP, _VP, _VP, C.POINTER(_F)]),
     'adm_comm_unique_id': (_I, [_VP]),
+    'adm_comm_available': (_I, []),
     'adm_comm_init': (_I, [_VP, _I, _I, _VP]),
+    'adm_comm_init_aux': (_I, [_VP, _VP]),
     'adm_comm_destroy': (_I, [_VP]),
     'adm_comm_rank': (_I, [_VP]),
     'adm_comm_size': (_I, [_VP]),

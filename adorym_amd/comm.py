@@ -6,17 +6,21 @@ and then applies the identical optimiser step on every rank.  Here, one process 
     reduce_scatter(sum) of the object gradient  ->  fused Adam on the owned shard (moments are
     sharded, ZeRO-1 style)  ->  all_gather of the updated object shards
 
-over RCCL/xGMI through ``torch.distributed`` (backend "nccl" is RCCL on ROCm).  torch is plumbing
-only: it owns the process group and the buffers that the collectives touch; every kernel is libadm's
-and runs on the same HIP stream (the context is created on torch's current stream).
-
-Backends:
-  LocalComm            1 rank, no torch import;
-  RcclComm             the product's multi-GPU backend: collectives through libadm's C ABI (adm_reduce_scatter / adm_all_gather /
-                       adm_all_reduce: RCCL, dlopen'ed) on the context's own stream and on libadm's own device buffers; a
-                       torch.distributed *gloo* group is only the rendezvous / control plane (unique id, seeds, barriers);
-  TorchComm('nccl')    the same collectives through torch.distributed (kept as an alternative);
-  TorchComm('gloo')    host buffers, for CPU tests of the sharding logic.
+Backends (all expose the same methods to adorym_amd/dp.py and the driver):
+  LocalComm            1 rank, no torch import: the identity collectives of adorym/pseudo.py;
+  RcclComm             the product's multi-GPU backend.  Data plane: RCCL over xGMI behind libadm's C ABI
+                       (adm_reduce_scatter / adm_all_gather / adm_all_reduce / adm_broadcast, librccl dlopen'ed), enqueued on
+                       the context's own streams, IN PLACE on libadm's own device buffers -- two communicators, one per
+                       stream (main; side stream for the deferred part of the object all-gather).  Control plane: a
+                       torch.distributed *gloo* group, used only for the rendezvous (unique ids), seeds, barriers and the
+                       resume agreement.  No torch tensor ever touches the data path;
+  HostStagedComm       validation backend (ADM_COMM=host): the same in-place contract on the same libadm buffers, but every
+                       collective is staged through host memory (adm_d2h -> gloo -> adm_h2d).  It exists so that the PRODUCT
+                       -- driver, HIP kernels, sharded optimiser, two-part gather -- can run at world size > 1 with several
+                       ranks on ONE GPU, where RCCL refuses duplicate devices.  Slow by construction; never the default;
+  TorchComm('nccl')    the same collectives through torch.distributed tensors (kept as the fallback bench.py agrees on, on
+                       all ranks together, if the C-ABI communicator cannot come up);
+  TorchComm('gloo')    host buffers, for CPU tests of the sharding logic with a NumPy stand-in for the kernels.
 """
 import os
 import numpy as np
@@ -180,17 +184,47 @@ class RcclComm(object):
         self.ctx = None
 
     def attach(self, ctx):
-        """Create the RCCL communicator of this rank on ``ctx`` (collective over all ranks)."""
+        """Create the RCCL communicators of this rank on ``ctx`` (collective over all ranks).  Failure-symmetric: every
+        step that can fail on one rank only is followed by an agreement over the gloo group, so either every rank returns
+        with working communicators or every rank raises the same RuntimeError (callers such as bench.py then fall back
+        TOGETHER).  Order: (1) each rank probes its own librccl (adm_comm_available) -> agree; (2) rank 0 creates the
+        unique ids and ALWAYS broadcasts (None on failure) -> all ranks see the same outcome; (3) adm_comm_init (+ the
+        side-stream communicator) -> agree, and tear down on disagreement."""
         import ctypes as C
         from ._lib import check
         if self.ctx is ctx:
             return self
-        uid = C.create_string_buffer(128)
+        lib = ctx.lib
+        why = ''
+        try:
+            check(lib.adm_comm_available())
+            ok = 1.0
+        except Exception as e:      # librccl missing / lacks a symbol: the most likely failure, identical on all ranks
+            ok, why = 0.0, repr(e)
+        if self.sum_over_ranks(ok) < self.size:
+            raise RuntimeError('RCCL is not usable on every rank (this rank: %s)' % (why or 'ok'))
+        ids = None
         if self.rank == 0:
-            check(ctx.lib.adm_comm_unique_id(uid))
-        raw = self.bcast_object(bytes(uid.raw), root=0)
-        uid = C.create_string_buffer(raw, 128)
-        check(ctx.lib.adm_comm_init(ctx.handle, self.rank, self.size, uid))
+            try:
+                bufs = [C.create_string_buffer(128) for _ in range(2)]
+                for b_ in bufs:
+                    check(lib.adm_comm_unique_id(b_))
+                ids = [bytes(b_.raw) for b_ in bufs]
+            except Exception as e:
+                why = repr(e)
+        ids = self.bcast_object(ids, root=0)
+        if ids is None:
+            raise RuntimeError('rank 0 could not create the RCCL unique ids (%s)' % (why or 'see rank 0'))
+        try:
+            check(lib.adm_comm_init(ctx.handle, self.rank, self.size, C.create_string_buffer(ids[0], 128)))
+            if os.environ.get('ADM_COMM_AUX', '1') == '1':
+                check(lib.adm_comm_init_aux(ctx.handle, C.create_string_buffer(ids[1], 128)))
+            ok = 1.0
+        except Exception as e:
+            ok, why = 0.0, repr(e)
+        if self.sum_over_ranks(ok) < self.size:
+            lib.adm_comm_destroy(ctx.handle)
+            raise RuntimeError('RCCL communicator creation failed on some rank (this rank: %s)' % (why or 'ok'))
         self.ctx = ctx
         return self
 
@@ -270,9 +304,68 @@ class RcclComm(object):
             self.dist.destroy_process_group()
 
 
+class HostStagedComm(RcclComm):
+    """VALIDATION backend: RcclComm's interface and in-place buffer contract with every device collective staged through
+    host memory -- blocking adm_d2h, a gloo collective on the host copy, blocking adm_h2d -- so that several ranks can share
+    ONE GPU (RCCL refuses two ranks on one device).  The driver, the HIP kernels, the sharded optimiser and the two-part
+    gather of DataParallelObject run unchanged; only the transport differs.  A collective issued between Context.fork()
+    and end_fork() stages through the side stream, like RcclComm's would run on it.  Selected with ADM_COMM=host."""
+    backend = 'host'
+
+    def attach(self, ctx):
+        self.ctx = ctx
+        return self
+
+    def _sum(self, host):
+        t = self.torch.from_numpy(host)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return host
+
+    def reduce_scatter_sum(self, full, shard_out):
+        n = shard_out.size
+        host = self._sum(full.view(0, (n * self.size,)).get())
+        shard_out.set(host[self.rank * n:(self.rank + 1) * n])
+
+    def all_gather(self, full_out, shard_in):
+        mine = self.torch.from_numpy(shard_in.get())
+        parts = [self.torch.empty_like(mine) for _ in range(self.size)]
+        self.dist.all_gather(parts, mine)
+        full_out.view(0, (shard_in.size * self.size,)).set(self.torch.cat(parts).numpy())
+
+    def all_reduce_device(self, dev):
+        dev.set(self._sum(dev.get()))
+        return dev
+
+    def broadcast(self, dev, root):
+        t = self.torch.from_numpy(dev.get())
+        self.dist.broadcast(t, src=int(root))
+        if self.rank != int(root):
+            dev.set(t.numpy())
+        return dev
+
+    def group(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+            self.ctx = None
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
 def from_env():
-    """LocalComm unless launched under torch.distributed.run with WORLD_SIZE > 1 (then RCCL through the C ABI;
-    ADM_COMM=torch selects the torch.distributed collectives instead)."""
+    """LocalComm unless launched under torch.distributed.run with WORLD_SIZE > 1; then ADM_COMM selects the data plane:
+    'rccl' (default: RCCL through the C ABI), 'torch' (torch.distributed's nccl backend), 'host' (validation: staged
+    through host memory, several ranks may share a GPU)."""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
-        return TorchComm('nccl') if os.environ.get('ADM_COMM', 'rccl') == 'torch' else RcclComm()
+        kind = os.environ.get('ADM_COMM', 'rccl')
+        if kind == 'torch':
+            return TorchComm('nccl')
+        if kind == 'host':
+            import torch
+            n_dev = max(1, torch.cuda.device_count())       # counting devices does not initialise the GPU
+            return HostStagedComm(device_index=int(os.environ.get('LOCAL_RANK', '0')) % n_dev)
+        return RcclComm()
     return LocalComm()

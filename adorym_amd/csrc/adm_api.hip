@@ -45,6 +45,7 @@ extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
     c->main_stream = c->stream;
     c->join_pending = false;
     c->comm = nullptr;
+    c->comm_aux = nullptr;
     c->comm_rank = 0;
     c->comm_size = 1;
     hipError_t e2 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);

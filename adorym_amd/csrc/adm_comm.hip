@@ -1,5 +1,6 @@
-// Collectives of the data-parallel mode behind the C ABI: RCCL over xGMI, one communicator per context, every call
-// enqueued on the context's stream (ordered with the kernels, no host synchronisation).
+// Collectives of the data-parallel mode behind the C ABI: RCCL over xGMI, one communicator per context stream (main, and
+// optionally the side stream: adm_comm_init_aux), every call enqueued on the context's current stream (ordered with the
+// kernels, no host synchronisation).
 //
 // Replaces the reference's mpi4py object collectives on the hot path:
 //   gradient.arr = comm.allreduce(gradient.arr)            adorym/ptychography.py:1113-1114  -> adm_reduce_scatter (+ adm_all_gather
@@ -13,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include "adm_common.h"
 
@@ -38,11 +40,17 @@ struct Api {
     std::string err;
 };
 
+void load_api(Api& a);
+
+// One-time dlopen / dlsym, safe against a first call from two threads at once (the driver runs a checkpoint writer thread).
 Api* api() {
     static Api a;
-    static bool tried = false;
-    if (tried) return &a;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { load_api(a); });
+    return &a;
+}
+
+void load_api(Api& a) {
     // The RCCL copy must sit on the HIP/HSA runtime this process already uses: a process that imported PyTorch first
     // runs on the runtime PyTorch ships (and must use its librccl), one that loaded libadm first runs on ROCm's.  Mixing
     // them gives "no ROCm-capable device" inside ncclCommInitRank (RCCL dlopens libhsa-runtime64 next to itself).  So:
@@ -64,12 +72,13 @@ Api* api() {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (int i = 0; !a.lib && i < 3; ++i) a.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!a.lib) {
-        a.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
-        return &a;
+        const char* why = dlerror();
+        a.err = std::string("cannot load librccl: ") + (why ? why : "?");
+        return;
     }
 #define ADM_SYM(field, name)                                                     \
     a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name));          \
-    if (!a.field) { a.err = std::string("librccl lacks ") + name; return &a; }
+    if (!a.field) { a.err = std::string("librccl lacks ") + name; return; }
     ADM_SYM(GetUniqueId, "ncclGetUniqueId")
     ADM_SYM(CommInitRank, "ncclCommInitRank")
     ADM_SYM(CommDestroy, "ncclCommDestroy")
@@ -81,7 +90,12 @@ Api* api() {
     ADM_SYM(Broadcast, "ncclBroadcast")
     ADM_SYM(GetErrorString, "ncclGetErrorString")
 #undef ADM_SYM
-    return &a;
+}
+
+// The communicator a collective issued NOW belongs to: work queued between adm_ctx_fork and adm_ctx_end_fork goes to the
+// side stream and uses the side communicator when there is one, so that every communicator only ever sees one stream.
+Comm comm_for(adm_ctx* ctx) {
+    return (ctx->stream == ctx->aux_stream && ctx->comm_aux) ? ctx->comm_aux : ctx->comm;
 }
 
 int nccl_fail(int rc, const char* what) {
@@ -129,10 +143,46 @@ extern "C" int adm_comm_init(adm_ctx* ctx, int rank, int nranks, const void* uni
     return ADM_OK;
 }
 
+// A second communicator over the same ranks for the collectives queued on the context's SIDE stream (the deferred part of
+// the object all-gather runs there, beside the next multislice kernel, while the main stream goes on to the next
+// reduce-scatter).  RCCL orders the operations of ONE communicator in the order they were issued, whatever streams they
+// were given; with its own communicator the side-stream gather neither waits for nor delays main-stream collectives, and
+// no communicator is ever driven from two streams.  Collective over all ranks, like adm_comm_init, with its own unique id.
+extern "C" int adm_comm_init_aux(adm_ctx* ctx, const void* unique_id128) {
+    int rc = need(ctx, "adm_comm_init_aux", true);
+    if (rc) return rc;
+    if (!unique_id128) return fail(ADM_ERR_INVALID, "adm_comm_init_aux: null argument");
+    if (ctx->comm_aux) return fail(ADM_ERR_INVALID, "adm_comm_init_aux: this context already has a side-stream communicator");
+    ADM_HIP(hipSetDevice(ctx->device));
+    UniqueId id;
+    std::memcpy(id.internal, unique_id128, sizeof(id.internal));
+    Comm c = nullptr;
+    rc = api()->CommInitRank(&c, ctx->comm_size, id, ctx->comm_rank);
+    if (rc) return nccl_fail(rc, "ncclCommInitRank (side stream)");
+    ctx->comm_aux = c;
+    return ADM_OK;
+}
+
+// 0 if librccl and every entry point libadm uses could be resolved in THIS process (no communicator needed, no GPU work):
+// lets every rank test its own installation before any rank enters a collective rendezvous.
+extern "C" int adm_comm_available(void) {
+    Api* a = api();
+    if (!a->err.empty()) return fail(ADM_ERR_UNSUPPORTED, "adm_comm_available: " + a->err);
+    return ADM_OK;
+}
+
 extern "C" int adm_comm_destroy(adm_ctx* ctx) {
-    if (!ctx || !ctx->comm) return ADM_OK;
+    if (!ctx || (!ctx->comm && !ctx->comm_aux)) return ADM_OK;
+    // a deferred all-gather may still be in flight on the side stream (e.g. when the caller unwinds after an exception)
+    (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->main_stream);
-    const int rc = api()->CommDestroy(ctx->comm);
+    int rc = 0;
+    if (ctx->comm_aux) rc = api()->CommDestroy(ctx->comm_aux);
+    ctx->comm_aux = nullptr;
+    if (ctx->comm) {
+        const int rc2 = api()->CommDestroy(ctx->comm);
+        if (!rc) rc = rc2;
+    }
     ctx->comm = nullptr;
     return rc ? nccl_fail(rc, "ncclCommDestroy") : ADM_OK;
 }
@@ -144,7 +194,7 @@ extern "C" int adm_reduce_scatter(adm_ctx* ctx, const float* send, float* recv, 
     int rc = need(ctx, "adm_reduce_scatter", true);
     if (rc) return rc;
     if (!send || !recv) return fail(ADM_ERR_INVALID, "adm_reduce_scatter: null argument");
-    rc = api()->ReduceScatter(send, recv, recv_count, kFloat32, kSum, ctx->comm, ctx->stream);
+    rc = api()->ReduceScatter(send, recv, recv_count, kFloat32, kSum, comm_for(ctx), ctx->stream);
     return rc ? nccl_fail(rc, "ncclReduceScatter") : ADM_OK;
 }
 
@@ -152,7 +202,7 @@ extern "C" int adm_all_gather(adm_ctx* ctx, const float* send, float* recv, size
     int rc = need(ctx, "adm_all_gather", true);
     if (rc) return rc;
     if (!send || !recv) return fail(ADM_ERR_INVALID, "adm_all_gather: null argument");
-    rc = api()->AllGather(send, recv, send_count, kFloat32, ctx->comm, ctx->stream);
+    rc = api()->AllGather(send, recv, send_count, kFloat32, comm_for(ctx), ctx->stream);
     return rc ? nccl_fail(rc, "ncclAllGather") : ADM_OK;
 }
 
@@ -160,7 +210,7 @@ extern "C" int adm_all_reduce(adm_ctx* ctx, float* buf, size_t count, int op_max
     int rc = need(ctx, "adm_all_reduce", true);
     if (rc) return rc;
     if (!buf) return fail(ADM_ERR_INVALID, "adm_all_reduce: null argument");
-    rc = api()->AllReduce(buf, buf, count, kFloat32, op_max ? kMax : kSum, ctx->comm, ctx->stream);
+    rc = api()->AllReduce(buf, buf, count, kFloat32, op_max ? kMax : kSum, comm_for(ctx), ctx->stream);
     return rc ? nccl_fail(rc, "ncclAllReduce") : ADM_OK;
 }
 
@@ -168,7 +218,7 @@ extern "C" int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root) {
     int rc = need(ctx, "adm_broadcast", true);
     if (rc) return rc;
     if (!buf) return fail(ADM_ERR_INVALID, "adm_broadcast: null argument");
-    rc = api()->Broadcast(buf, buf, bytes, kUint8, root, ctx->comm, ctx->stream);
+    rc = api()->Broadcast(buf, buf, bytes, kUint8, root, comm_for(ctx), ctx->stream);
     return rc ? nccl_fail(rc, "ncclBroadcast") : ADM_OK;
 }
 

@@ -18,6 +18,7 @@ struct adm_ctx {
     bool owns_stream;
     bool join_pending;
     void* comm;              // ncclComm_t of adm_comm_init (adm_comm.hip) or nullptr
+    void* comm_aux;          // ncclComm_t of adm_comm_init_aux: collectives queued on the side stream, or nullptr
     int comm_rank, comm_size;
 };
 

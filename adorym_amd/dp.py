@@ -81,9 +81,10 @@ class DataParallelObject(object):
         self.hi = min(self.lo + self.per, self.n)
         self._keep = []
         self.dist = R > 1 or getattr(comm, 'backend', 'local') != 'local'
-        # RcclComm works on libadm's own buffers, in place: the reduced shard lands in its slot of the gradient buffer and the
-        # updated shard is gathered from its slot of the object (no staging copies, no torch tensors)
-        self.inplace = self.dist and getattr(comm, 'backend', '') == 'rccl'
+        # RcclComm (and its host-staged validation twin) work on libadm's own buffers, in place: the reduced shard lands in
+        # its slot of the gradient buffer and the updated shard is gathered from its slot of the object (no staging copies,
+        # no torch tensors)
+        self.inplace = self.dist and getattr(comm, 'backend', '') in ('rccl', 'host')
         if self.inplace:
             self.obj = ops.alloc(self.n_pad)
             self.grad = ops.alloc(self.n_pad)
@@ -99,8 +100,15 @@ class DataParallelObject(object):
             self.obj = ops.alloc(self.n_pad)
             self.grad = ops.alloc(self.n_pad)
         self.moments = [ops.alloc(self.per) for _ in range(n_moments)]   # ZeRO-1: only the owned shard
-        # in-place exchange only: gather the planes the next minibatches read first, the rest beside the next kernel
-        self.overlap_gather = self.inplace and hasattr(comm, 'broadcast') and os.environ.get('ADM_OVERLAP_GATHER', '1') == '1'
+        # In-place exchange only: gather the planes the next minibatches read first, the rest beside the next kernel.
+        # With more than one rank this two-part gather is OPT-IN (ADM_OVERLAP_GATHER=1, or bench.py after its own
+        # equality check of the two paths on the running job): its gain depends on RCCL's kernel finding CUs beside the
+        # multislice launch, which only a multi-GPU run can show; the plain all-gather is the default there.
+        default = '1' if R == 1 else '0'
+        self.overlap_gather = self.inplace and hasattr(comm, 'broadcast') and os.environ.get('ADM_OVERLAP_GATHER', default) == '1'
+        # ADM_DEBUG_POISON=1: between exchange_and_update(first=...) and finish_update() the planes of OTHER ranks' shards
+        # outside `first` are stale by contract; fill them with NaN so that a reader that skipped finish_update() shows up
+        self.poison = os.environ.get('ADM_DEBUG_POISON', '0') == '1'
         self._gather_pending = False
 
     # gradient exchange + update ------------------------------------------------------------
@@ -154,12 +162,24 @@ class DataParallelObject(object):
                     s_lo, s_hi = max(r * self.per, f_lo), min((r + 1) * self.per, f_hi)
                     if s_hi > s_lo:
                         self.comm.broadcast(self.obj.view(s_lo, (s_hi - s_lo,)), r)
+            if self.poison:
+                self._poison_stale(f_lo, f_hi)
             self._gather_pending = True
         elif self.inplace:
             self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
         elif self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
+
+    def _poison_stale(self, f_lo, f_hi):
+        """Debug aid: NaN-fill what the contract of exchange_and_update(first=...) calls stale (other ranks' shards outside
+        ``first``); the deferred all-gather of finish_update() overwrites it."""
+        for r in range(self.comm.size):
+            if r == self.comm.rank:
+                continue
+            for a, b in ((r * self.per, min((r + 1) * self.per, f_lo)), (max(r * self.per, f_hi), (r + 1) * self.per)):
+                if b > a:
+                    check(self.ops.ctx.lib.adm_memset(self.ops.ctx.handle, self.obj.ptr + 4 * a, 0xFF, 4 * (b - a)))
 
     def finish_update(self):
         """Apply the part of the last update that exchange_and_update(first=...) deferred (on the current stream)."""

@@ -723,7 +723,13 @@ def reconstruct_ptychography(
             t00 = time.time()
             this_i_theta, this_ind_batch = rank_batch(ind_list_rand, i_batch, rank, minibatch_size, n_ranks)
             this_pos_batch = probe_pos_int[this_ind_batch]
-            is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != this_i_theta
+            # ONE decision for all ranks, taken on the angle the global batch starts with (rank 0's share).  The reference
+            # compares with each rank's own angle (adorym/ptychography.py:910): when a global batch straddles two angles its
+            # ranks then disagree, their optimiser counters i_opt_batch drift apart (:1266-1271) and the replicated objects
+            # stop being identical (golden F14 'immediate' records it; oracle.reconstruct(rank_local_counters=True) restates
+            # it).  Here the object is ONE sharded copy, so the step counter must be the same on every shard; the two rules
+            # coincide whenever no global batch straddles angles (always in 'per angle' mode).
+            is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != ind_list_rand[i_batch][0, 0]
             print_flush('  Current rank is processing angle ID {}.'.format(this_i_theta), sto_rank, rank, **stdout_options)
 
             # 'per angle': the minibatches of one angle see the same object, so they are fused into ONE launch
@@ -860,9 +866,9 @@ def reconstruct_ptychography(
 
             # ---- intermediate output (ptychography.py:1231-1246; util.py:1958-2028, optimizers.py:1111-1160) ----
             if save_intermediate and ((save_intermediate_level == 'epoch' and i_batch == n_batch - 1) or save_intermediate_level == 'batch'):
-                # finish_update() may hold a deferred collective (the rest of the all-gather): every rank calls it, on rank 0's
-                # condition (a global batch can straddle two angles, so `is_last_batch_of_this_theta` may differ between ranks)
-                if i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != ind_list_rand[i_batch][0, 0]:
+                # finish_update() may hold a deferred collective (the rest of the all-gather): every rank calls it (the
+                # condition is the same on all ranks)
+                if is_last_batch_of_this_theta:
                     state.finish_update()
                 if rank == 0 and is_last_batch_of_this_theta:
                     _write_intermediate(output_folder, obj.arr.get(), unknown_type, i_epoch, i_batch, save_history, opt_ls,

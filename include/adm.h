@@ -97,7 +97,16 @@ int adm_event_sync(adm_ctx* ctx, void* ev);                                     
  * adm_reduce_scatter: recv[0..recv_count) = sum over ranks of send[rank*recv_count ...]; send holds nranks*recv_count.
  * adm_all_gather:     recv[r*send_count ...] = rank r's send[0..send_count).  adm_all_reduce: in place, sum (op_max = 0) or max. */
 int adm_comm_unique_id(void* out128);
+/* 0 if librccl and all entry points libadm needs resolve in this process; no communicator, no GPU work.  Every rank
+ * checks its own installation with it BEFORE any rank enters the rendezvous of adm_comm_init (a rank that fails there
+ * would leave the others waiting).  No reference counterpart (mpi4py either imports or the run is serial,
+ * adorym/ptychography.py:45-50). */
+int adm_comm_available(void);
 int adm_comm_init(adm_ctx* ctx, int rank, int nranks, const void* unique_id128);
+/* Optional second communicator over the same ranks (own unique id, collective like adm_comm_init) for collectives issued
+ * between adm_ctx_fork and adm_ctx_end_fork, i.e. on the side stream: the deferred part of the object all-gather that
+ * runs beside the next multislice kernel.  Each communicator then only ever sees one stream. */
+int adm_comm_init_aux(adm_ctx* ctx, const void* unique_id128);
 int adm_comm_destroy(adm_ctx* ctx);
 int adm_comm_rank(adm_ctx* ctx);
 int adm_comm_size(adm_ctx* ctx);

@@ -790,17 +790,33 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                 update_scheme='immediate', optimizer_batch_number_increment='angle',
                 non_negativity=False, object_type='normal', mask=None, dtype='float64',
                 n_ranks=1, two_d_mode=False, raw_data_type='magnitude', gd_options=None,
-                return_trace=False):
+                return_trace=False, optimize_probe=False, probe_learning_rate=1e-5, rank_local_counters=False):
     """
     Control flow of reconstruct_ptychography (ptychography.py:783-1295) restricted to
-    distribution_mode=None, shared probe, fixed probe, AD path.  ``n_ranks>1`` emulates
-    `mpirun -n R`: per-rank gradients (each with its own regulariser term, forward_model.py:138)
-    are summed (ptychography.py:1113-1114).
+    distribution_mode=None, shared probe, AD path.  ``n_ranks>1`` emulates `mpirun -n R`: per-rank
+    gradients (each with its own regulariser term, forward_model.py:138) are summed (ptychography.py:1113-1114),
+    and so are the probe gradients (optimizers.py:1022-1032).
+
+    Every rank of the reference holds its OWN replica of the object, the optimiser moments and the step counter
+    i_opt_batch, and decides `is_last_batch_of_this_theta` with the angle of ITS share of the global batch
+    (ptychography.py:904-910, 1266-1271).  When a global batch straddles two angles the ranks' counters drift apart, the
+    Adam bias corrections differ and the replicas are no longer identical (rank 0's is the one written out).
+    ``rank_local_counters=True`` restates exactly that (pinned against golden F14 'immediate'); the default keeps ONE
+    counter for all ranks -- rank 0's view of the global batch -- which is what a sharded (single-copy) update can do and
+    what adorym_amd does; the two coincide whenever no global batch straddles angles (pinned: F14 'immediate6*',
+    'perangle', 'probe6').  Returns rank 0's object.
     """
     dt = np.dtype(dtype)
-    obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
-    m = np.zeros_like(obj)
-    v = np.zeros_like(obj)
+    n_rep = n_ranks if rank_local_counters else 1
+    obj0 = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
+    objs = [obj0.copy() for _ in range(n_rep)]
+    ms = [np.zeros_like(obj0) for _ in range(n_rep)]
+    vs = [np.zeros_like(obj0) for _ in range(n_rep)]
+    probe = np.asarray(probe)
+    pst0 = np.stack([probe.real, probe.imag], -1).astype(dt)            # [..., 2] like the reference's stacked probe
+    psts = [pst0.copy() for _ in range(n_rep)]
+    pms = [np.zeros_like(pst0) for _ in range(n_rep)]
+    pvs = [np.zeros_like(pst0) for _ in range(n_rep)]
     n_theta = len(theta_ls)
     n_pos = len(probe_pos)
     probe_pos_int = np.round(np.asarray(probe_pos)).astype(int)
@@ -812,12 +828,19 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
         batches = epoch_task_list(i_epoch, n_theta, n_pos, minibatch_size, n_ranks, update_scheme,
                                   two_d_mode=two_d_mode)
         n_batch = len(batches)
-        i_opt_batch = 0   # starting_epoch * n_batch + starting_batch (ptychography.py:848), no checkpoint
+        i_opt = [0] * n_rep   # starting_epoch * n_batch + starting_batch (ptychography.py:848), no checkpoint
         grad_acc = None
+        gp_acc = None
         for i_batch in range(n_batch):
             g_sum = None
+            gp_sum = None
+            thetas = []
             for rank in range(n_ranks):
+                rep = rank if rank_local_counters else 0
+                obj = objs[rep]
+                pc = psts[rep][..., 0] + 1j * psts[rep][..., 1]
                 i_theta, ind = rank_batch(batches, i_batch, rank, minibatch_size, n_ranks)
+                thetas.append(i_theta)
                 coords = None
                 if not two_d_mode:
                     if i_theta not in tables:
@@ -825,8 +848,8 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                     coords = tables[i_theta]
                 pos = probe_pos_int[ind]
                 meas = np.abs(prj[i_theta, ind])
-                loss, pred, g, _ = forward_adjoint_object(obj, coords, probe, pos, meas, phys, dt,
-                                                          raw_data_type=raw_data_type)
+                loss, pred, g, gp = forward_adjoint_object(obj, coords, pc, pos, meas, phys, dt,
+                                                           raw_data_type=raw_data_type)
                 if alpha_d not in (None, 0) or alpha_b not in (None, 0):
                     rv, rg = l1_value_grad(obj, alpha_d, alpha_b)
                     loss += rv; g = g + rg
@@ -836,29 +859,43 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                 if rank == 0:
                     loss_rank0 = float(loss)
                 g_sum = g if g_sum is None else g_sum + g
+                gp = np.stack([gp.real, gp.imag], -1).reshape(pst0.shape).astype(dt)
+                gp_sum = gp if gp_sum is None else gp_sum + gp
             if first_grad is None:
                 first_grad = g_sum.copy()
             grad_acc = g_sum if grad_acc is None else grad_acc + g_sum
-            cur_theta = int(batches[i_batch][0, 0])
-            last_of_theta = i_batch == n_batch - 1 or int(batches[i_batch + 1][0, 0]) != cur_theta
-            if not (update_scheme == 'per angle' and not last_of_theta):
-                if optimizer == 'adam':
-                    obj, m, v = adam_step(obj, grad_acc.astype(dt), m, v, i_opt_batch, step_size=learning_rate)
+            gp_acc = gp_sum if gp_acc is None else gp_acc + gp_sum
+            logged = False
+            for rep in range(n_rep):
+                cur_theta = thetas[rep] if rank_local_counters else int(batches[i_batch][0, 0])
+                last_of_theta = i_batch == n_batch - 1 or int(batches[i_batch + 1][0, 0]) != cur_theta
+                if not (update_scheme == 'per angle' and not last_of_theta):
+                    if optimizer == 'adam':
+                        objs[rep], ms[rep], vs[rep] = adam_step(objs[rep], grad_acc.astype(dt), ms[rep], vs[rep], i_opt[rep],
+                                                                step_size=learning_rate)
+                    else:
+                        objs[rep] = gd_step(objs[rep], grad_acc.astype(dt), i_opt[rep], step_size=learning_rate, **gd_options)
+                    objs[rep] = apply_constraints(objs[rep], non_negativity, object_type, mask)
+                    if optimize_probe:
+                        psts[rep], pms[rep], pvs[rep] = adam_step(psts[rep], gp_acc.astype(dt), pms[rep], pvs[rep], i_opt[rep],
+                                                                  step_size=probe_learning_rate)
+                    # the convergence log is only written when the loop body is not cut short by the
+                    # 'per angle' `continue` (ptychography.py:1095-1099 vs :1261)
+                    logged = logged or rep == 0
+                if optimizer_batch_number_increment == 'angle':
+                    if last_of_theta:
+                        i_opt[rep] += 1
                 else:
-                    obj = gd_step(obj, grad_acc.astype(dt), i_opt_batch, step_size=learning_rate, **gd_options)
-                obj = apply_constraints(obj, non_negativity, object_type, mask)
-                grad_acc = None
-                # the convergence log is only written when the loop body is not cut short by the
-                # 'per angle' `continue` (ptychography.py:1095-1099 vs :1261)
+                    i_opt[rep] += 1
+            if logged:
                 losses.append(loss_rank0)
-            if optimizer_batch_number_increment == 'angle':
-                if last_of_theta:
-                    i_opt_batch += 1
-            else:
-                i_opt_batch += 1
+                grad_acc = None
+                gp_acc = None
     if return_trace:
-        return obj, losses, first_grad
-    return obj
+        if optimize_probe:
+            return objs[0], losses, first_grad, psts[0][..., 0] + 1j * psts[0][..., 1]
+        return objs[0], losses, first_grad
+    return objs[0]
 
 
 def reconstruct_2d(prj, obj_init, probes, probe_pos, phys, n_epochs=1, minibatch_size=1, learning_rate=1e-3,

@@ -125,6 +125,18 @@ def e2e_inputs():
                 probe_mag=mag, probe_phase=ph)
 
 
+# ---------------------------------------------------------------- F14: the reference driver at world size 2 (config 4's exchange)
+# name: (scan positions used, keyword arguments).  9 positions, minibatch 3, 2 ranks: a global batch of 6 can straddle two
+# angles and the reference's per-rank optimiser counters drift apart ('immediate' records that); with 6 positions they cannot.
+W2_RUNS = {
+    'immediate':      (9, dict(n_epochs=1, optimizer='adam', learning_rate=1e-6)),
+    'immediate6':     (6, dict(n_epochs=2, optimizer='adam', learning_rate=1e-6)),
+    'immediate6_reg': (6, dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)),
+    'perangle':       (9, dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, update_scheme='per angle')),
+    'probe6':         (6, dict(n_epochs=2, optimizer='adam', learning_rate=1e-6, optimize_probe=True, probe_learning_rate=1e-3)),
+}
+
+
 # ---------------------------------------------------------------- F11: config-1-shaped 2-D ptychography (f2 row)
 C1MINI = dict(Y=40, X=44, P=16, M=2, energy_ev=8801.121930115722, psize_cm=1.32789376566526e-06, minibatch_size=5, n_dp_batch=2)
 

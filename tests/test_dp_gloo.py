@@ -188,6 +188,8 @@ class HostOps(NumpyOps):
 def _worker_inplace(rank, world, port, shape, seed, out_q, first=None):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if first is not None:
+        os.environ['ADM_OVERLAP_GATHER'] = '1'      # the two-part gather is opt-in at world size > 1
     import torch
     from adorym_amd.comm import RcclComm
     from adorym_amd.dp import DataParallelObject

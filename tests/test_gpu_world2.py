@@ -1,0 +1,237 @@
+"""BASELINE config 4's exchange step with the PRODUCT at world size 2 on ONE GPU: two fresh processes, both on device 0,
+each running adorym_amd.reconstruct_ptychography with the real HIP kernels, the sharded optimiser and the two-part gather of
+adorym_amd/dp.py; only the transport of the collectives differs from the multi-GPU product (HostStagedComm: device -> host ->
+gloo -> device, because RCCL refuses two ranks on one device -- tools/rccl_two_ranks_one_gpu.py).
+
+Checked against golden F14 = the REFERENCE driver run as two processes (tests/golden/gen_f14_world2.py), i.e.
+adorym/ptychography.py:786,846,905-909 (rank split), :1113-1114 (summed gradients), forward_model.py:138-139 (one regulariser
+term per rank), optimizers.py:1022-1032 (summed probe gradients), and against the fp64 oracle's 2-rank run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _params(n_use, extra, tmp):
+    g6 = np.load(os.path.join(G, 'F6_e2e.npz'))
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    p = dict(fname=g6['prj'].astype(np.float32)[:, :n_use], obj_size=[E['N']] * 3, probe_pos=inp['probe_pos'][:n_use], theta_st=0,
+             theta_end=2 * np.pi, n_theta=E['n_theta'], energy_ev=E['energy_ev'], psize_cm=E['psize_cm'], free_prop_cm='inf',
+             minibatch_size=E['minibatch_size'], initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='supplied',
+             probe_initial=[inp['probe_mag'], inp['probe_phase']], gamma=0, alpha_d=0, alpha_b=0, save_path=tmp, output_folder='out',
+             store_checkpoint=False, use_checkpoint=False, return_state=True)
+    p.update(extra)
+    return p
+
+
+def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate):
+    """One rank: a fresh process that has not touched the GPU before."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      ADM_COMM='host')
+    os.environ.update(env)
+    try:
+        import adorym_amd as A
+        from adorym_amd import comm as C, differentiator as DF
+        seen = []
+        orig = DF.Differentiator.get_gradients
+
+        def rec(self, **kw):
+            seen.append((int(kw['this_i_theta']), np.array(kw['this_ind_batch'])))
+            return orig(self, **kw)
+
+        DF.Differentiator.get_gradients = rec
+        comm = C.from_env()
+        assert isinstance(comm, C.HostStagedComm) and comm.size == world and comm.device_index == 0
+        params = _params(n_use, extra, tmp)
+        theta_ls = None
+        if emulate:
+            params['n_theta'] = 1
+            params['fname'] = params['fname'][:1]
+        st = A.reconstruct_ptychography(comm=comm, **params)
+        out = dict(rank=rank, delta=st['delta'], beta=st['beta'], losses=np.array(st['losses']), probe=st['probe_real'] + 1j * st['probe_imag'],
+                   theta=np.array([s_[0] for s_ in seen]), ind=[s_[1] for s_ in seen])
+        if emulate and rank == 0:
+            out['emulated'] = _serial_two_rank_update(A, params, seen, world)
+        comm.close()
+        q.put(out)
+    except Exception as e:       # report instead of leaving the parent waiting for the queue
+        import traceback
+        q.put(dict(rank=rank, error='%r\n%s' % (e, traceback.format_exc())))
+
+
+def _serial_two_rank_update(A, params, seen, world):
+    """The first (and only) update of a 2-rank run restated on ONE context with the same kernels: every rank's gradient
+    buffer = its regulariser term + its minibatch's back-rotated gradient, the buffers summed in rank order in fp32 (what the
+    reduce-scatter does for two ranks), one full-range Adam step.  Must equal the 2-rank result bit for bit."""
+    from adorym_amd.dp import HipOps
+    from adorym_amd._lib import check
+    from adorym_amd.util import epoch_task_list, rank_batch
+    E = cases.E2E
+    ctx = A.Context(0)
+    size = params['obj_size']
+    pos = np.round(params['probe_pos']).astype(int)
+    eng = A.MultisliceEngine(ctx, size, (E['P'], E['P']), pos, E['energy_ev'], E['psize_cm'], free_prop_cm='inf', max_batch=E['minibatch_size'])
+    init = np.stack(params['initial_guess'], -1).astype(np.float32)
+    obj = ctx.array(init)
+    probe = ctx.array(np.stack([params['probe_initial'][0] * np.cos(params['probe_initial'][1]),
+                                params['probe_initial'][0] * np.sin(params['probe_initial'][1])], -1)[None], np.float32)
+    table = A.RotationTable(ctx, size, np.linspace(0, 2 * np.pi, 1, dtype='float32')[0])
+    batches = epoch_task_list(0, 1, len(pos), E['minibatch_size'], world)
+    assert len(batches) == 1
+    total = None
+    for r in range(world):
+        _, ind = rank_batch(batches, 0, r, E['minibatch_size'], world)
+        g = ctx.empty(init.shape)
+        if params['gamma'] or params['alpha_d']:
+            check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, params['alpha_d'], params['alpha_b'], params['gamma'], g.ptr, None))
+        else:
+            g.zero_()
+        eng.loss_and_grad(obj, g, table, probe, pos[ind], np.abs(params['fname'][0, ind]))
+        total = g.get() if total is None else total + g.get()
+    gsum = ctx.array(total)
+    n = init.size
+    m, v = ctx.zeros((n,)), ctx.zeros((n,))
+    HipOps(ctx).adam(obj, gsum, 0, m, v, 0, 0, n, 0, params['learning_rate'], 0.9, 0.999, 1e-7, 0, None)
+    return obj.get()
+
+
+def run_world2(tmp_path, n_use, extra, env=None, emulate=False):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n_use, extra, str(tmp_path), env or {}, q, emulate)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in procs]
+    [p.join(120) for p in procs]
+    for r in res:
+        assert 'error' not in r, r['error']
+    return sorted(res, key=lambda r: r['rank'])
+
+
+def _golden(run):
+    g = np.load(os.path.join(G, 'F14_world2.npz'))
+    x64 = np.stack([g['delta_%s_64' % run], g['beta_%s_64' % run]], -1).astype(np.float64)
+    x32 = np.stack([g['delta_%s_32' % run], g['beta_%s_32' % run]], -1).astype(np.float64)
+    return g, x64, x32
+
+
+def _grouped(theta, ind):
+    """Per-angle sorted index sets, in order (the product fuses the minibatches of an angle in 'per angle' mode)."""
+    out = []
+    for t, i in zip(theta, ind):
+        if out and out[-1][0] == t:
+            out[-1][1].extend(int(v) for v in i)
+        else:
+            out.append([int(t), [int(v) for v in i]])
+    return [(t, sorted(v)) for t, v in out]
+
+
+@pytest.mark.parametrize('run', ['immediate6', 'immediate6_reg', 'perangle', 'probe6'])
+def test_world2_driver_matches_reference_two_rank_run(tmp_path, run):
+    n_use, extra = cases.W2_RUNS[run]
+    res = run_world2(tmp_path, n_use, extra)
+    g, x64, x32 = _golden(run)
+    x0 = np.stack(cases.e2e_inputs()['guess'], -1)
+    upd = np.linalg.norm(x64 - x0)
+    e_ref = np.linalg.norm(x32 - x64)
+    for r in res:
+        k = r['rank']
+        # (a) the rank's share of every global batch is the reference's (adorym/ptychography.py:897-908)
+        assert _grouped(r['theta'], r['ind']) == _grouped(g['r%d_theta_%s_64' % (k, run)], g['r%d_ind_%s_64' % (k, run)])
+        # (b) summed gradient -> sharded Adam -> gathered object, against the reference's fp64 run under the 3x rule
+        x = np.stack([r['delta'], r['beta']], -1).astype(np.float64)
+        e_us = np.linalg.norm(x - x64)
+        print('%s rank %d: |x-x64|/|update| = %.2e (reference fp32: %.2e)' % (run, k, e_us / upd, e_ref / upd))
+        assert np.sqrt(np.mean((x[..., 0] - x64[..., 0]) ** 2)) < 1e-5
+        if run == 'immediate6_reg':     # sign() gradients of L1 / TV: a handful of voxels flip in any fp32 implementation
+            d = np.abs(x - x64)
+            assert (d > 1e-6).mean() < 1e-3 and d.max() < 1e-4
+        else:
+            assert e_us <= 3 * e_ref + 1e-4 * upd, (e_us, e_ref, upd)
+        # every rank logs ITS OWN minibatch's loss (adorym/ptychography.py:1261)
+        assert np.allclose(r['losses'], g['r%d_losses_%s_64' % (k, run)], rtol=2e-4)
+    # the replicas are one object: every rank holds the same bits after the gather
+    assert np.array_equal(res[0]['delta'], res[1]['delta']) and np.array_equal(res[0]['beta'], res[1]['beta'])
+    if run == 'probe6':
+        pg = g['probe_mag_probe6_64'] * np.exp(1j * g['probe_phase_probe6_64'])
+        p32 = g['probe_mag_probe6_32'] * np.exp(1j * g['probe_phase_probe6_32'])
+        assert np.array_equal(res[0]['probe'], res[1]['probe'])
+        assert np.abs(res[0]['probe'][0] - pg).max() <= 3 * np.abs(p32 - pg).max() + 1e-6
+        assert np.abs(pg - cases.e2e_inputs()['probe_mag'] * np.exp(1j * cases.e2e_inputs()['probe_phase'])).max() > 1e-3
+
+
+def test_world2_straddling_batches_use_one_counter(tmp_path):
+    """9 positions: global batches straddle angles.  The reference's ranks then count optimiser steps differently and their
+    replicas drift apart (golden F14 'immediate', restated by the oracle's rank_local_counters=True); the product keeps ONE
+    counter (one sharded object), which the oracle restates with rank_local_counters=False.  Compared with that fp64 run
+    under the 3x rule, with the reference's own fp32-vs-fp64 distance of this very run as the yardstick."""
+    from oracle import adorym_oracle as O           # checker only
+    n_use, extra = cases.W2_RUNS['immediate']
+    res = run_world2(tmp_path, n_use, extra)
+    g, x64_ref, x32_ref = _golden('immediate')
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    phys = O.Physics((E['P'], E['P']), E['energy_ev'], E['psize_cm'], free_prop_cm='inf')
+    g6 = np.load(os.path.join(G, 'F6_e2e.npz'))
+    probe = inp['probe_mag'] * np.exp(1j * inp['probe_phase'])
+    x64, losses, _ = O.reconstruct(g6['prj'].astype(np.float32).astype(np.float64), inp['guess'], probe, inp['probe_pos'], inp['theta_ls'],
+                                   phys, minibatch_size=E['minibatch_size'], n_ranks=2, return_trace=True, n_epochs=1, learning_rate=1e-6)
+    upd = np.linalg.norm(x64 - np.stack(inp['guess'], -1))
+    e_ref = np.linalg.norm(x32_ref - x64_ref)
+    for r in res:
+        k = r['rank']
+        assert np.array_equal(r['theta'], g['r%d_theta_immediate_64' % k])
+        assert np.array_equal(np.stack(r['ind']), g['r%d_ind_immediate_64' % k])
+        x = np.stack([r['delta'], r['beta']], -1).astype(np.float64)
+        e_us = np.linalg.norm(x - x64)
+        print('straddling, rank %d: |x-x64|/|update| = %.2e (reference fp32 vs its fp64: %.2e)' % (k, e_us / upd, e_ref / upd))
+        assert e_us <= 3 * e_ref + 1e-4 * upd
+    assert np.allclose(res[0]['losses'], losses, rtol=2e-4)
+    assert np.array_equal(res[0]['delta'], res[1]['delta']) and np.array_equal(res[0]['beta'], res[1]['beta'])
+
+
+@pytest.mark.parametrize('run', ['immediate6', 'perangle', 'probe6'])
+def test_world2_two_part_gather_is_bitwise_the_plain_gather(tmp_path, run):
+    """ADM_OVERLAP_GATHER=1: the planes the next minibatches read are broadcast from their owners, the rest of the
+    all-gather is deferred to the side stream of the next minibatch.  With ADM_DEBUG_POISON=1 everything the contract calls
+    stale is NaN until finish_update(): any reader that skipped it would poison the result.  Bitwise equal to the plain
+    all-gather run, losses included."""
+    n_use, extra = cases.W2_RUNS[run]
+    plain = run_world2(tmp_path / 'a', n_use, extra, env={'ADM_OVERLAP_GATHER': '0'})
+    over = run_world2(tmp_path / 'b', n_use, extra, env={'ADM_OVERLAP_GATHER': '1', 'ADM_DEBUG_POISON': '1'})
+    for a, b in zip(plain, over):
+        assert np.all(np.isfinite(b['delta']))
+        assert np.array_equal(a['delta'], b['delta']) and np.array_equal(a['beta'], b['beta'])
+        assert np.array_equal(a['losses'], b['losses'])
+        assert np.array_equal(a['probe'], b['probe'])
+
+
+@pytest.mark.parametrize('reg', [False, True])
+def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg):
+    """One angle, 6 positions, one global batch: the 2-rank update against the same arithmetic on ONE context -- per-rank
+    gradient buffers (each with its own regulariser term: the R-fold weight of adorym/forward_model.py:138-139), summed in
+    rank order, one full-range Adam step.  Bit for bit: the exchange adds nothing but the sum."""
+    extra = dict(n_epochs=1, optimizer='adam', learning_rate=1e-6)
+    if reg:
+        extra.update(gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)
+    res = run_world2(tmp_path, 6, extra, emulate=True)
+    emu = res[0]['emulated']
+    for r in res:
+        assert np.array_equal(r['delta'], emu[..., 0]) and np.array_equal(r['beta'], emu[..., 1])

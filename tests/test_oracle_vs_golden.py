@@ -234,6 +234,62 @@ def test_f6_end_to_end_fp32_within_3x_reference():
     assert e_us <= 3 * e_ref + 1e-12, (e_us, e_ref)
 
 
+# ------------------------------------------------------------------ F14: the reference driver at world size 2
+def _w2(run, dtype, **kw):
+    g, g6 = load('F14_world2'), load('F6_e2e')
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    n, args = cases.W2_RUNS[run]
+    args = dict(args)
+    phys = O.Physics((E['P'], E['P']), E['energy_ev'], E['psize_cm'], free_prop_cm='inf')
+    probe = inp['probe_mag'] * np.exp(1j * inp['probe_phase'])
+    res = O.reconstruct(g6['prj'].astype(np.float64)[:, :n], inp['guess'], probe, inp['probe_pos'][:n], inp['theta_ls'], phys,
+                        minibatch_size=E['minibatch_size'], dtype=dtype, return_trace=True, n_ranks=2, **args, **kw)
+    return g, inp, probe, res
+
+
+@pytest.mark.parametrize('run', list(cases.W2_RUNS))
+def test_f14_world2_driver_fp64(run):
+    """`mpirun -n 2` of the REFERENCE (two processes, stand-in mpi4py transport: tests/golden/gen_f14_world2.py): summed
+    gradients, per-rank regulariser terms, summed probe gradients, final object of rank 0, rank 0's loss log.  The
+    reference's per-rank counters are restated exactly (rank_local_counters=True) -- including the replica drift of the
+    straddling run -- and the single-counter rule the product uses is shown to coincide wherever no batch straddles."""
+    for rl in (True, False):
+        g, inp, probe, res = _w2(run, 'float64', rank_local_counters=rl)
+        obj, losses = res[0], res[1]
+        x64 = np.stack([g['delta_%s_64' % run], g['beta_%s_64' % run]], -1)
+        upd = np.linalg.norm(x64 - np.stack(inp['guess'], -1))
+        err = np.linalg.norm(obj - x64) / upd
+        if run == 'immediate' and not rl:
+            # the one place the two rules differ: bounded by the reference's own fp32-vs-fp64 distance on this run
+            x32 = np.stack([g['delta_%s_32' % run], g['beta_%s_32' % run]], -1)
+            assert 1e-6 < err < np.linalg.norm(x32 - x64) / upd
+            continue
+        assert err < 1e-11, (run, rl, err)
+        assert np.allclose(losses, g['r0_losses_%s_64' % run], rtol=1e-11, atol=0)
+        if 'first_grad_sum_%s_64' % run in g.files:
+            assert rel(res[2], g['first_grad_sum_%s_64' % run]) < 1e-11
+        if run == 'probe6':
+            pg = g['probe_mag_probe6_64'] * np.exp(1j * g['probe_phase_probe6_64'])
+            assert np.abs(res[3] - pg).max() < 1e-11 and np.abs(pg - probe).max() > 1e-3      # equal, and it moved
+
+
+def test_f14_world2_task_split_both_ranks():
+    """(i_theta, ind_batch) seen by BOTH ranks of the reference's 2-rank runs (adorym/ptychography.py:897-908)."""
+    g = load('F14_world2')
+    E = cases.E2E
+    for run, (n, args) in cases.W2_RUNS.items():
+        for rank in (0, 1):
+            th, ind = [], []
+            for e in range(args['n_epochs']):
+                b = O.epoch_task_list(e, E['n_theta'], n, E['minibatch_size'], 2, args.get('update_scheme', 'immediate'))
+                for k in range(len(b)):
+                    t, i = O.rank_batch(b, k, rank, E['minibatch_size'], 2)
+                    th.append(t); ind.append(i)
+            assert np.array_equal(np.array(th), g['r%d_theta_%s_64' % (rank, run)])
+            assert np.array_equal(np.stack(ind), g['r%d_ind_%s_64' % (rank, run)])
+
+
 # ------------------------------------------------------------------ F9 (variants: Poisson, Momentum, reweighted L1)
 @pytest.mark.parametrize('rdt', ['magnitude', 'intensity'])
 @pytest.mark.parametrize('pm', [1.0, 50.0])
