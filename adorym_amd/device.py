@@ -143,6 +143,39 @@ class Event(object):
         check(self.ctx.lib.adm_event_elapsed_ms(self.ctx.handle, self.handle, end.handle, C.byref(ms)))
         return ms.value
 
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None) and self.ctx.handle:
+                self.ctx.lib.adm_event_destroy(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class PhaseClock(object):
+    """HIP-event stopwatch for named phases queued on the context's streams: start(name) / stop(name) record events on the
+    stream the context is enqueuing on at that moment (main, or the side stream inside fork()/end_fork()); totals() blocks
+    on the recorded events and returns {name: (total ms, count)}.  Costs two event records per phase; nothing when unused."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._open = {}
+        self._pairs = []
+
+    def start(self, name):
+        self._open[name] = Event(self.ctx).record()
+
+    def stop(self, name):
+        self._pairs.append((name, self._open.pop(name), Event(self.ctx).record()))
+
+    def totals(self):
+        out = {}
+        for name, e0, e1 in self._pairs:
+            t, n = out.get(name, (0.0, 0))
+            out[name] = (t + e0.elapsed_ms(e1), n + 1)
+        self._pairs = []
+        return out
+
 
 class PinnedArray(object):
     """Page-locked host array (NumPy view) for asynchronous device-to-host copies."""

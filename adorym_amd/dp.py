@@ -110,6 +110,15 @@ class DataParallelObject(object):
         # outside `first` are stale by contract; fill them with NaN so that a reader that skipped finish_update() shows up
         self.poison = os.environ.get('ADM_DEBUG_POISON', '0') == '1'
         self._gather_pending = False
+        self.clock = None           # a device.PhaseClock while a caller (bench.py) wants per-phase device times
+
+    def _tic(self, name):
+        if self.clock is not None:
+            self.clock.start(name)
+
+    def _toc(self, name):
+        if self.clock is not None:
+            self.clock.stop(name)
 
     # gradient exchange + update ------------------------------------------------------------
     def _apply(self, optimizer, i_batch, options, flags, mask, g, g_base, lo, hi):
@@ -140,6 +149,7 @@ class DataParallelObject(object):
             all-gather is deferred to finish_update().  ``first`` must then be the SAME on every rank -- the union of the planes
             the next minibatches of ALL ranks read -- because it shapes a collective."""
         self.finish_update()
+        self._tic('reduce_scatter')
         if self.inplace:
             self.comm.reduce_scatter_sum(self.grad, self.grad.view(self.lo, (self.per,)))
             g, g_base = self.grad, 0
@@ -148,13 +158,17 @@ class DataParallelObject(object):
             g, g_base = self.gshard, self.lo
         else:
             g, g_base = self.grad, 0
+        self._toc('reduce_scatter')
+        self._tic('update')
         if first is not None and not self.dist and self.hi > self.lo:
             f_lo, f_hi = max(self.lo, int(first[0])), min(self.hi, int(first[1]))
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, f_lo, f_hi)
             self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, f_lo, f_hi)
         else:
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, self.lo, self.hi)
+        self._toc('update')
         f_lo, f_hi = (max(0, int(first[0])), min(self.n_pad, int(first[1]))) if first is not None else (0, self.n_pad)
+        self._tic('first_gather')
         if self.inplace and self.overlap_gather and (f_lo > 0 or f_hi < self.n):
             import contextlib
             with (self.comm.group() if hasattr(self.comm, 'group') else contextlib.nullcontext()):   # one launch, all roots at once
@@ -170,6 +184,7 @@ class DataParallelObject(object):
         elif self.dist:
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
+        self._toc('first_gather')
 
     def _poison_stale(self, f_lo, f_hi):
         """Debug aid: NaN-fill what the contract of exchange_and_update(first=...) calls stale (other ranks' shards outside
@@ -185,7 +200,9 @@ class DataParallelObject(object):
         """Apply the part of the last update that exchange_and_update(first=...) deferred (on the current stream)."""
         if self._gather_pending:            # a collective: every rank reaches this at the same point of its stream of calls
             self._gather_pending = False
+            self._tic('deferred_gather')
             self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
+            self._toc('deferred_gather')
         d = getattr(self, '_deferred', None)
         if d is not None:
             self._deferred = None

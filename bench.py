@@ -38,9 +38,48 @@ def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
     return 4 * (3 * B * Py * Px * S * 2 + B * Py * Px + 2 * (2 * V))
 
 
-def cpu_baseline(cfg, seconds_budget=20.0):
-    """The pinned NumPy oracle (fp32, the reference's dtype) timed on this host: forward + hand adjoint
-    of the multislice chain for a bounded sample of probe positions (rotation excluded => favours the CPU)."""
+KERNEL_SOURCES = ('adm_multislice.hip', 'adm_fft.h', 'adm_ms_math.h', 'adm_common.h')
+
+
+def kernel_sources_sha():
+    """Identity of the multislice kernel's sources (what a PMC pass was taken on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, 'adorym_amd', 'csrc', f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def read_traffic(B):
+    """roofline.traffic = HBM bytes of one multislice launch from the PMC passes (tools/pmc_sq.sh + tools/traffic_update.py ->
+    profiles/traffic_latest.json).  Counters cannot be collected inside this run (rocprofv3 wraps the process), so the file is
+    used only if it was taken on THESE kernel sources and this batch size; otherwise traffic is null and the reason is stated."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    src = {'file': 'profiles/traffic_latest.json', 'kernel_sources_sha': kernel_sources_sha()}
+    try:
+        j = json.load(open(tpath))
+    except Exception as e:
+        src['unused_because'] = 'unreadable: %r' % (e,)
+        return None, src
+    src.update({k: j.get(k) for k in ('pmc_kernel_sources_sha', 'pmc_batch', 'command', 'source')})
+    if j.get('pmc_kernel_sources_sha') != src['kernel_sources_sha']:
+        src['unused_because'] = 'the PMC passes were taken on other kernel sources (stale)'
+        return None, src
+    if j.get('pmc_batch') != B:
+        src['unused_because'] = 'the PMC passes were taken at another batch size'
+        return None, src
+    return j.get('ms_fwd_adj_kernel_hbm_bytes_per_launch'), src
+
+
+def cpu_baseline(cfg, seconds_budget=12.0):
+    """The pinned NumPy oracle (fp32, the reference's dtype) timed on this host's cores: forward + hand adjoint of the
+    multislice chain for a bounded sample of probe positions (rotation excluded => favours the CPU).
+      value / cores            the port on ALL host cores: a pool of single-threaded worker processes over whole positions
+                               (oracle/cpu_pool_bench.py, run as a child process: a fresh interpreter without the GPU);
+      one_core                 the same on one core;
+      reference_structured     the reference's own op structure on PyTorch-CPU autograd (oracle/torch_structured.py), best of a
+                               thread sweep -- the "what the reference does on a CPU" figure."""
+    import subprocess
     from oracle import adorym_oracle as O
     P = cfg['probe_size'][0]
     S = cfg['obj_size'][2]
@@ -57,12 +96,23 @@ def cpu_baseline(cfg, seconds_budget=20.0):
         O.forward_adjoint_tiles(tiles, probe, meas, phys, 'float32')
         t_used += time.perf_counter() - t0
         done += nb
-        if t_used > 0.6 * seconds_budget or done >= 512:
+        if t_used > 0.4 * seconds_budget or done >= 512:
             break
-    out = {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
-           'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
-                     '(oracle/adorym_oracle.py), rotation and optimiser excluded, %.1f s of CPU work, host has %d cores'
-                     % (done, P, S, t_used, os.cpu_count())}
+    one = {'value': done / t_used, 'unit': 'probe-positions/s', 'cores': 1, 'positions': done, 'seconds': t_used}
+    n_cpu = os.cpu_count() or 1
+    out = None
+    try:
+        txt = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'cpu_pool_bench.py'), str(n_cpu), str(seconds_budget)],
+                             capture_output=True, text=True, timeout=300).stdout.strip().split('\n')[-1]
+        pool = json.loads(txt)
+        out = {'value': pool['value'], 'unit': 'probe-positions/s', 'cores': pool['cores'], 'kind': 'port',
+               'sample': '%d positions, P=%d, S=%d slices, fwd + hand adjoint of the multislice chain in fp32 NumPy/pocketfft '
+                         '(oracle/adorym_oracle.py) on a pool of %d single-threaded worker processes, rotation and optimiser excluded, '
+                         '%.1f s wall; host has %d cores' % (pool['positions'], P, S, pool['cores'], pool['seconds'], n_cpu)}
+    except Exception as e:
+        out = {'value': one['value'], 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
+               'sample': '%d positions on one core (the all-core pool failed: %r)' % (done, e)}
+    out['one_core'] = one
     try:
         out['reference_structured'] = cpu_baseline_torch(cfg, phys, probe)
     except Exception as e:      # a reported extra, never fatal for the bench line
@@ -70,24 +120,51 @@ def cpu_baseline(cfg, seconds_budget=20.0):
     return out
 
 
-def cpu_baseline_torch(cfg, phys, probe, nb=2):
-    """Second flavour (SURVEY.md 8d ii): the reference's own op structure -- PyTorch-CPU tensors, separate re/im,
-    strided slice selects, torch.autograd.grad -- restated in oracle/torch_structured.py and timed on all host cores
-    for one bounded minibatch of the same workload (full 256^3 object, tile gather + fwd + autograd backward)."""
+def cpu_baseline_torch(cfg, phys, probe, budget_s=75.0):
+    """Second flavour (SURVEY.md 8d ii): the reference's own op structure -- PyTorch-CPU tensors, separate re/im, strided slice
+    selects, torch.autograd.grad -- restated in oracle/torch_structured.py (timed within 15 % of the imported reference in the
+    build container: oracle/time_vs_reference.py).  A minibatch of B = 4 positions of config 3 (full 256^3 object: tile gather +
+    forward + autograd backward; the size SURVEY / BASELINE.md quote the reference at) is timed for torch thread counts
+    8 ... host cores, the best is reported with its thread count, then -- time permitting -- a larger minibatch at that count."""
     import torch
     from oracle import torch_structured as T
     Y, X, Z = cfg['obj_size']
     r = np.random.default_rng(1)
     obj = np.stack([r.normal(8.7e-7, 1e-7, (Y, X, Z)), r.normal(5.1e-8, 1e-8, (Y, X, Z))], -1).astype(np.float32)
-    pos = cfg['probe_pos'][:nb].astype(int)
-    meas = np.abs(r.standard_normal((nb,) + tuple(cfg['probe_size']))).astype(np.float32)
-    T.loss_and_grad(obj[:, :, :4], pos, probe, phys.h, phys.k1, meas)          # warm-up (thread pool, FFT plans)
-    t0 = time.perf_counter()
-    T.loss_and_grad(obj, pos, probe, phys.h, phys.k1, meas)
-    dt = time.perf_counter() - t0
-    return {'value': nb / dt, 'unit': 'probe-positions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d positions of config 3 (256^3 object, P=72, 256 slices): tile gather + fwd + torch.autograd backward, fp32, '
-                      'reference op structure (oracle/torch_structured.py), %.1f s, torch %s' % (nb, dt, torch.__version__)}
+    n_cpu = os.cpu_count() or 1
+    keep = torch.get_num_threads()
+    t_start = time.perf_counter()
+
+    def run(nb, threads):
+        torch.set_num_threads(threads)
+        pos = cfg['probe_pos'][200:200 + nb].astype(int)
+        meas = np.abs(np.random.default_rng(2).standard_normal((nb,) + tuple(cfg['probe_size']))).astype(np.float32)
+        t0 = time.perf_counter()
+        T.loss_and_grad(obj, pos, probe, phys.h, phys.k1, meas)
+        return time.perf_counter() - t0
+
+    T.loss_and_grad(obj[:, :, :4], cfg['probe_pos'][200:202].astype(int), probe, phys.h, phys.k1,
+                    np.ones((2,) + tuple(cfg['probe_size']), np.float32))          # warm-up (thread pool, FFT plans)
+    sweep = []
+    for th in [t for t in (8, 16, 32, 64, 128) if t <= max(8, n_cpu)]:
+        if sweep and time.perf_counter() - t_start > 0.55 * budget_s:
+            break
+        dt = run(4, min(th, n_cpu))
+        sweep.append({'threads': min(th, n_cpu), 'positions': 4, 'seconds': dt, 'positions_per_s': 4 / dt})
+    best = max(sweep, key=lambda q: q['positions_per_s'])
+    out = {'value': best['positions_per_s'], 'unit': 'probe-positions/s', 'cores': best['threads'], 'kind': 'port', 'thread_sweep': sweep,
+           'sample': '4 positions of config 3 (256^3 object, P=72, 256 slices): tile gather + fwd + torch.autograd backward, fp32, '
+                     'reference op structure (oracle/torch_structured.py), %.1f s at the best of the thread counts tried, torch %s'
+                     % (best['seconds'], torch.__version__)}
+    left = budget_s - (time.perf_counter() - t_start)
+    nb = int(min(32, 0.8 * left * best['positions_per_s']))
+    if nb >= 8:
+        dt = run(nb, best['threads'])
+        out['larger_minibatch'] = {'threads': best['threads'], 'positions': nb, 'seconds': dt, 'positions_per_s': nb / dt}
+        if nb / dt > out['value']:
+            out['value'] = nb / dt
+    torch.set_num_threads(keep)
+    return out
 
 
 def cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize):
@@ -256,8 +333,15 @@ def main():
     ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
     ap.add_argument('--legs', default='per_angle,vr8,vr16,sweep', help='which secondary full-chip legs to run (profiling aid)')
     ap.add_argument('--force-dist', action='store_true', help='use the multi-GPU (RCCL) code path even with one rank')
-    ap.add_argument('--comm', choices=('rccl', 'torch'), default='rccl',
-                    help="collectives through libadm's C ABI (default) or through torch.distributed's nccl backend")
+    ap.add_argument('--comm', choices=('rccl', 'torch', 'host'), default=os.environ.get('ADM_COMM', 'rccl'),
+                    help="collectives through libadm's C ABI (default), through torch.distributed's nccl backend, or staged through "
+                         "host memory (validation: the ranks may then share one GPU)")
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help="weak: every rank runs --minibatch positions per step (global batch N x 32, the reference's `mpirun -n N`); "
+                         "strong: ONE minibatch of --minibatch positions split over the ranks (N x 32/N)")
+    ap.add_argument('--overlap-gather', choices=('auto', '0', '1'), default='auto',
+                    help='N > 1: two-part object gather (planes the next minibatches read first, rest beside the next kernel); '
+                         'auto = check it bitwise against the plain all-gather on the running job, time both, keep the faster')
     args = ap.parse_args()
 
     import torch
@@ -271,35 +355,47 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.comm == 'host':
+        local_rank %= max(1, torch.cuda.device_count())     # validation transport: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if not use_dist:
         comm = C.LocalComm()
     elif args.comm == 'torch':
         comm = C.TorchComm('nccl', device_index=local_rank)
+    elif args.comm == 'host':
+        comm = C.HostStagedComm(device_index=local_rank)
     else:
         comm = C.RcclComm(device_index=local_rank)
     rank = comm.rank
     # libadm kernels and the RCCL collectives share one stream: the context's own (RcclComm) or torch's (TorchComm)
     ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
+    comm_note = None
     if hasattr(comm, 'attach'):
-        # all ranks agree on whether the C-ABI communicator came up; if it did not on any of them, every rank falls back
-        # to torch.distributed's nccl backend (same collectives, torch tensors as buffers) instead of failing the run
+        # RcclComm.attach either succeeds on every rank or raises on every rank (two-phase agreement inside); if it raises,
+        # every rank falls back TOGETHER to torch.distributed's nccl backend (same collectives, torch tensors as buffers)
         try:
             comm.attach(ctx)
-            ok = 1.0
         except Exception as e:
-            sys.stderr.write('bench.py: rank %d: RCCL through the C ABI failed (%r)\n' % (rank, e))
-            ok = 0.0
-        if comm.sum_over_ranks(ok) < world:
+            comm_note = 'RCCL through the C ABI failed (%r): fell back to torch.distributed nccl' % (e,)
+            sys.stderr.write('bench.py: rank %d: %s\n' % (rank, comm_note))
             comm.ctx = None
             comm.close()                        # leaves the gloo group; TorchComm opens an nccl one on the same rendezvous
             ctx.close()
             comm = C.TorchComm('nccl', device_index=local_rank)
             ctx = A.Context(local_rank, stream=comm.stream_handle())
+    # the communicator really spans N ranks (a silent 1-rank communicator would make every collective the identity)
+    abi_size = int(ctx.lib.adm_comm_size(ctx.handle))
+    if use_dist and comm.size != world:
+        raise SystemExit('bench.py: communicator has %d ranks, expected %d' % (comm.size, world))
+    if getattr(comm, 'backend', '') == 'rccl' and abi_size != world:
+        raise SystemExit('bench.py: adm_comm_size() = %d, expected %d' % (abi_size, world))
 
     cfg = W.c3_config()
-    B = args.minibatch
+    B_global = args.minibatch * world if args.scaling == 'weak' else args.minibatch
+    if args.scaling == 'strong' and args.minibatch % world:
+        raise SystemExit('bench.py: --scaling strong needs --minibatch divisible by the number of ranks')
+    B = B_global // world                      # positions per rank and step
     Y, X, Z = cfg['obj_size']
     Py, Px = cfg['probe_size']
     eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'],
@@ -307,7 +403,15 @@ def main():
     ops = HipOps(ctx)
     state = DataParallelObject(ops, comm, (Y, X, Z, 2))
     # reference-default Gaussian random initial guess (throughput is data independent)
-    state.obj.view(0, (Y, X, Z, 2)).set(W.random_guess((Y, X, Z), seed=1))
+    obj0 = ctx.array(W.random_guess((Y, X, Z), seed=1).reshape(-1))
+
+    def reset_state():
+        state.finish_update()
+        state.obj.view(0, (obj0.size,)).copy_from(obj0)
+        for m_ in state.moments:
+            m_.zero_()
+
+    reset_state()
     probe = ctx.array(W.probe_array(cfg))
     n_theta_used = max(2, min(8, args.steps + args.warmup))
     thetas = np.linspace(cfg['theta_st'], cfg['theta_end'], cfg['n_theta'], dtype='float32')[:: cfg['n_theta'] // n_theta_used][:n_theta_used]
@@ -323,9 +427,11 @@ def main():
     plan_batches, plan_all = [], []
     for k in range(total):
         it = k % n_theta_used
-        starts = [((k // n_theta_used) * world * B + r * B) % (n_pos - B + 1) for r in range(world)]
-        plan_batches.append((it, np.arange(starts[rank], starts[rank] + B)))
-        plan_all.append(np.concatenate([np.arange(s0, s0 + B) for s0 in starts]))      # what ALL ranks process in step k
+        # the global batch of step k = B_global consecutive scan positions of one angle, rank r takes the r-th slice of B
+        # (adorym/ptychography.py:905-909)
+        g0 = ((k // n_theta_used) * B_global) % (n_pos - B_global + 1)
+        plan_batches.append((it, np.arange(g0 + rank * B, g0 + (rank + 1) * B)))
+        plan_all.append(np.arange(g0, g0 + B_global))      # what ALL ranks process in step k
     targets = {}
     # (synthesised with the in-loop modulator, i.e. another template instance of the kernel, so that a rocprofv3 --stats
     # summary of this command lists the forward-only synthesis launches separately from the measured forward+adjoint ones)
@@ -394,9 +500,45 @@ def main():
         resolve()                       # the PREVIOUS step's kernel time and loss
         pending[0] = (token, evs)
 
+    # ---- N > 1: the two-part gather is checked against the plain all-gather ON THIS JOB before it is used -------------
+    gather = {'overlap_gather': bool(state.overlap_gather), 'checked': False}
+    if use_dist and state.inplace and hasattr(comm, 'broadcast') and args.overlap_gather != 'auto':
+        state.overlap_gather = args.overlap_gather == '1'
+        gather['overlap_gather'] = state.overlap_gather
+    if use_dist and state.inplace and hasattr(comm, 'broadcast') and args.overlap_gather == 'auto' and len(plan_batches) >= 3:
+        n_chk = min(3, len(plan_batches))
+        res, ms = {}, {}
+        for mode in (False, True):
+            reset_state()
+            state.overlap_gather, state.poison = mode, mode      # poison: stale planes are NaN until finish_update()
+            for k in range(n_chk):
+                step(k, False)
+            resolve()
+            state.finish_update()
+            ctx.sync()
+            res[mode] = state.obj.view(0, (state.n,)).get()
+            state.poison = False
+            comm.barrier()
+            t_ = time.perf_counter()
+            for k in range(n_chk):
+                step(k, False)
+            resolve()
+            state.finish_update()
+            comm.barrier()
+            ms[mode] = comm.max_over_ranks(1e3 * (time.perf_counter() - t_) / n_chk)
+        same = bool(np.array_equal(res[False], res[True])) and bool(np.all(np.isfinite(res[True])))
+        same_all = comm.sum_over_ranks(1.0 if same else 0.0) >= world
+        del res
+        state.overlap_gather = bool(same_all and ms[True] < 0.99 * ms[False])
+        gather = {'overlap_gather': state.overlap_gather, 'checked': True, 'bitwise_equal_to_plain_on_all_ranks': bool(same_all),
+                  'plain_ms_per_step': ms[False], 'two_part_ms_per_step': ms[True], 'check_steps': n_chk}
+        reset_state()
+
     for k in range(args.warmup):
         step(k, False)
     resolve()
+    from adorym_amd.device import PhaseClock
+    state.clock = PhaseClock(ctx)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -406,34 +548,38 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     dt = comm.max_over_ranks(time.perf_counter() - t0)
+    state.finish_update()
+    phases = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()}
+    state.clock = None
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
-        value = world * B * args.steps / dt
+        value = B_global * args.steps / dt
         kern_ms = ms_kernel_total[0] / args.steps
         alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get('ms_fwd_adj_kernel_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_source = read_traffic(B)
         out = {
             'metric': 'probe-positions/sec (fwd+grad), 256^3 multislice ptycho', 'value': value, 'unit': 'probe-positions/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'object': [Y, X, Z], 'probe': [Py, Px], 'slices': Z,
-                       'minibatch_per_gpu': B, 'global_batch': world * B, 'update_scheme': 'immediate', 'optimizer': 'adam',
+                       'minibatch_per_gpu': B, 'global_batch': B_global, 'update_scheme': 'immediate', 'optimizer': 'adam',
                        'regularizers': 'L1+TV', 'far_field': True, 'parallelism': 'dp%d' % world,
                        'collectives': getattr(comm, 'backend', 'local'),
                        'step': 'rotate_fwd + multislice fwd/loss/adjoint + rotate_adj + reg_grad + (reduce_scatter) + adam (+all_gather)'},
             'roofline': {'bound': 'hbm', 'kernel': 'ms_fwd_adj_kernel<72,8,9>', 'achieved': achieved, 'peak': PEAK_HBM_GBS,
-                         'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS, 'traffic': traffic,
+                         'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': alg, 'kernel_ms': kern_ms,
                          'whole_step_frac': alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
             'loss_last': loss_box[0],
+            # device time per step of the exchange's phases (HIP events on the stream each phase is queued on; rank 0):
+            # where an N-GPU step's time goes beyond the multislice kernel
+            'phases_ms': {'kernel_ms': kern_ms, 'reduce_scatter_ms': phases.get('reduce_scatter', 0.0), 'update_ms': phases.get('update', 0.0),
+                          'first_gather_ms': phases.get('first_gather', 0.0), 'deferred_gather_ms': phases.get('deferred_gather', 0.0)},
+            'comm': {'backend': getattr(comm, 'backend', 'local'), 'size': comm.size, 'adm_comm_size': abi_size, 'expected': world,
+                     'side_stream_communicator': getattr(comm, 'backend', '') == 'rccl' and os.environ.get('ADM_COMM_AUX', '1') == '1',
+                     'gather': gather, 'note': comm_note},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
