@@ -250,6 +250,8 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->hs_dev = p->hfree_s_dev = p->twid_y_dev = nullptr;
     p->trans_dev = nullptr;
     p->trans_src = nullptr;
+    p->cover_ws = p->cover_pos = nullptr;
+    p->cover_batch = p->cover_row0 = p->cover_nrows = 0;
     p->generic = !tuned;
     {   // radix lists of the generic kernel's transforms: 8, 4, 2, 9, 3, 5, 7, then whatever primes remain
         auto factor = [](int n, int* r) {

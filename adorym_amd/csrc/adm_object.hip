@@ -846,14 +846,11 @@ extern "C" int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t 
     return adm_tile_grad_accumulate_part(plan, workspace, workspace_bytes, pos, batch, pos_host, grad_rot, 0, 0, 0);
 }
 
-extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
-                                            const int32_t* pos_host, float* grad_rot, int win_y_lo, int win_y_hi, int add) {
-    if (!plan || !workspace || !pos || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: null argument");
-    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: batch must be positive");
-    if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: workspace too small");
+// Geometry of the overlap-add of one (part of a) batch; shared by the cover build and the accumulate so that both see the
+// same window.  Returns 0 or a negative status.
+static int tile_geom(adm_plan* plan, int batch, const int32_t* pos_host, int win_y_lo, int win_y_hi, int add, TileGeom& g) {
     const adm_plan_desc& d = plan->d;
     const int N = d.probe_x;
-    TileGeom g;
     g.Yp = plan->Yp; g.Xp = plan->Xp; g.pad_y0 = d.pad_y0; g.pad_x0 = d.pad_x0; g.Py = d.probe_y; g.Px = d.probe_x;
     g.pixel_major = plan->generic ? 1 : 0;
     g.row_elems = (int)ms_row_elems(plan);
@@ -877,8 +874,11 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     if (g.row0 < 0 || g.row0 + g.nrows > g.Yp) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: a position lies outside the padded frame");
     const size_t per = (size_t)plan->n_steps * g.row_elems;
     if ((size_t)batch * per >= 0xFFFFFFFFull) return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate: batch too large for 32-bit tile offsets");
+    return ADM_OK;
+}
+
+static int cover_build(adm_plan* plan, void* workspace, const int32_t* pos, int batch, const TileGeom& g) {
     char* ws = (char*)workspace;
-    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
     unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)g.Yp * g.Xp * (ADM_MAXCOVER + 1));
     hipStream_t st = plan->ctx->stream;
@@ -887,6 +887,47 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
     ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+// The cover lists depend on the positions only, not on the tile gradients: building them EARLY -- on the side stream, beside the
+// multislice launch -- takes a launch and its dependency gap off the chain that follows the kernel.  The plan remembers what
+// was built (workspace, positions, batch, window); the next adm_tile_grad_accumulate[_part] with the same arguments skips its
+// own build.  The caller orders the two (adm_ctx_join before the accumulate when the build was queued on the side stream).
+extern "C" int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                    const int32_t* pos_host, int win_y_lo, int win_y_hi, int add) {
+    if (!plan || !workspace || !pos || !pos_host) return fail(ADM_ERR_INVALID, "adm_tile_cover_build: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_tile_cover_build: batch must be positive");
+    if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_cover_build: workspace too small");
+    TileGeom g;
+    int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
+    if (rc) return rc;
+    rc = cover_build(plan, workspace, pos, batch, g);
+    if (rc) return rc;
+    plan->cover_ws = workspace; plan->cover_pos = pos; plan->cover_batch = batch; plan->cover_row0 = g.row0; plan->cover_nrows = g.nrows;
+    return ADM_OK;
+}
+
+extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                            const int32_t* pos_host, float* grad_rot, int win_y_lo, int win_y_hi, int add) {
+    if (!plan || !workspace || !pos || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: null argument");
+    if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: batch must be positive");
+    if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate: workspace too small");
+    TileGeom g;
+    int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
+    if (rc) return rc;
+    const bool prebuilt = plan->cover_ws == workspace && plan->cover_pos == pos && plan->cover_batch == batch &&
+                          plan->cover_row0 == g.row0 && plan->cover_nrows == g.nrows;
+    plan->cover_ws = nullptr;            // one use: the position buffer may be rewritten before the next launch
+    if (!prebuilt) {
+        rc = cover_build(plan, workspace, pos, batch, g);
+        if (rc) return rc;
+    }
+    char* ws = (char*)workspace;
+    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
+    unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
+    hipStream_t st = plan->ctx->stream;
+    dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     const unsigned nz8 = ((plan->n_steps + TA_STEPS - 1) / TA_STEPS + 7) / 8;      // step chunks per XCD
     hipLaunchKernelGGL(tile_accumulate_kernel, dim3(8u * nz8 * grid.x * grid.y), dim3(256), 0, st, gtile, (const unsigned*)cover,
                        (float2*)grad_rot, g);

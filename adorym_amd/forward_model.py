@@ -246,6 +246,10 @@ class PtychographyModel(ForwardModel):
             # first minibatch of an angle: its rotation-adjoint tables are built here, on the side stream beside the
             # multislice kernel (0.4 ms of emit + sort), not on the main stream when the back-rotation asks for them
             coords.csr(eng.plan)
+        B = len(np.asarray(this_pos_batch).reshape(-1, 2))
+        early_cover = want_grad and B <= eng.N_CU
+        if early_cover:
+            eng.build_cover()       # the overlap-add's cover lists only need the positions: built beside the kernel
         ctx.end_fork()
         gp = None
         if want_probe_grad:
@@ -260,7 +264,6 @@ class PtychographyModel(ForwardModel):
             if getattr(self, '_grad_shift_dev', None) is None or self._grad_shift_dev.shape != shifts.shape:
                 self._grad_shift_dev = self.device.empty(shifts.shape)
             gsh = self._grad_shift_dev.zero_()
-        B = len(np.asarray(this_pos_batch).reshape(-1, 2))
         mb = B // self.batch_group
         gs = 2.0 / (mb * eng.n_det)     # each reference minibatch is a mean over ITS positions (and the kept detector pixels)
         if want_grad and shifts is None and B > eng.N_CU:
@@ -270,9 +273,9 @@ class PtychographyModel(ForwardModel):
         else:
             eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
                            shift_index=idx, grad_shifts=gsh, accumulate=False)
+            ctx.join()              # (the side stream's work is a fraction of the kernel's time: the join does not wait)
             if want_grad:
                 eng.accumulate_tiles()
-            ctx.join()
         self._last_mb = mb
         if want_grad:
             eng.rotate_adjoint(grad_obj, coords, yr)

@@ -298,6 +298,14 @@ class MultisliceEngine(object):
             raise RuntimeError('tile overlap-add: a pixel is covered by %d tiles of this launch (limit %d); use a smaller '
                                'minibatch_size' % (cache[key], self.MAX_COVER))
 
+    def build_cover(self):
+        """Queue the cover lists of the overlap-add of the batch given to set_batch() NOW (they depend on the positions only):
+        called inside Context.fork()/end_fork(), they are built beside the multislice launch and accumulate_tiles() -- after
+        Context.join() -- skips its own build: one launch and one dependency gap less behind the kernel."""
+        self._check_cover(self._pos_host)
+        check(self.ctx.lib.adm_tile_cover_build(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
+                                                self._pos_host.ctypes.data, 0, 0, 0))
+
     def accumulate_tiles(self):
         """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
         self._check_cover(self._pos_host)
@@ -384,8 +392,12 @@ class MultisliceEngine(object):
         self._loss_slot ^= 1
         k = self._loss_slot
         B = self._B
+        # on the side stream (it waits for everything queued so far): the copy and its dependency gaps stay off the main
+        # stream, whose next kernel is the next minibatch's rotation
+        self.ctx.fork()
         self._loss_pinned[k].copy_from_async(self._loss, 4 * B)
         self._loss_events[k].record()
+        self.ctx.end_fork()
         return (k, B, last)
 
     def loss_result(self, token):

@@ -478,6 +478,7 @@ def main():
         state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
         check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
                                        state.grad.ptr, None))      # initialises the gradient buffer: no separate zero fill
+        eng.build_cover()           # cover lists of the overlap-add: positions only, built beside the kernel
         ctx.end_fork()
         evs = ev_ms[k & 1] if timed else None
         if timed:
@@ -485,8 +486,8 @@ def main():
         eng.multislice(probe, accumulate=False)
         if timed:
             evs[1].record()
-        eng.accumulate_tiles()
         ctx.join()
+        eng.accumulate_tiles()
         eng.rotate_adjoint(state.grad, tables[it], yr)
         # update the y-planes the next minibatch reads first; the rest of the Adam pass overlaps the next kernel
         # (several ranks: the planes the next minibatches of ALL ranks read are gathered first, the rest of the all-gather

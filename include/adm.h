@@ -278,6 +278,13 @@ int adm_tile_grad_accumulate(adm_plan* plan, void* workspace, size_t workspace_b
  * reaches).  Later parts: add = 1, their tiles are accumulated into what is there (win_* ignored). */
 int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                                   const int32_t* pos_host, float* grad_rot, int win_y_lo, int win_y_hi, int add);
+/* The cover lists of the overlap-add (which tiles reach which padded pixel) depend on the positions only.  Building them early --
+ * e.g. between adm_ctx_fork and adm_ctx_end_fork, beside the multislice launch -- takes one launch and its dependency gap off the
+ * chain behind the kernel: the next adm_tile_grad_accumulate[_part] with the same workspace / pos / batch / window finds them built
+ * and skips its own build (one use).  Same arguments as adm_tile_grad_accumulate_part without grad_rot.  Ordering between the
+ * two calls is the caller's (adm_ctx_join).  No reference counterpart: autograd's index bookkeeping (adorym/forward_model.py:313-331). */
+int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                         const int32_t* pos_host, int win_y_lo, int win_y_hi, int add);
 /* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
  * (the overlap-add then dropped contributions; use smaller batches). */
 int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);
