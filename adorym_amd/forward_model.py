@@ -236,6 +236,7 @@ class PtychographyModel(ForwardModel):
         yr = eng.y_footprint(this_pos_batch)
         eng.rotate(obj, coords, yr)
         ctx.fork()
+        eng.flush_loss_copy()       # the previous minibatch's loss read-back: on the side stream, beside this kernel
         if side_hook is not None:
             side_hook()
         # init_grad: grad_obj is uninitialised -- the regulariser kernel writes it (one pass) or it is zero-filled

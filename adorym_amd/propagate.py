@@ -174,7 +174,11 @@ class MultisliceEngine(object):
         self._pos = DeviceArray(self.ctx, (batch, 2), np.int32)
         self._target = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
         self._pred = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
-        self._loss = DeviceArray(self.ctx, (batch,), np.float32)
+        # two buffers, written alternately by successive launches: the read-back of launch k can then be queued LATER (beside
+        # launch k+1, see loss_async) without racing with the kernel that overwrites the sums
+        self._loss_pair = [DeviceArray(self.ctx, (batch,), np.float32) for _ in range(2)]
+        self._loss = self._loss_pair[0]
+        self._deferred_loss = None
         # pinned staging for the per-minibatch uploads (targets, positions): asynchronous, the host never drains the stream
         self._ring = UploadRing(self.ctx, batch * Py * Px * 4, n_slots=4)
         self.max_batch = batch
@@ -247,6 +251,7 @@ class MultisliceEngine(object):
         if grad_scale is None:
             grad_scale = 2.0 / (B * self.n_det)       # d mean((pred-target)^2) / d pred
         lib = self.ctx.lib
+        self._next_loss_buffer()
         if shifts is None:
             check(lib.adm_multislice_fwd_adj(
                 self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
@@ -340,6 +345,7 @@ class MultisliceEngine(object):
             need = self.plan.workspace_bytes(self.N_CU)
             self._ws_parts = [DeviceArray(self.ctx, (need,), np.uint8) for _ in parts]
         lib, h = self.ctx.lib, self.plan.handle
+        self._next_loss_buffer()
         gp = grad_probe.ptr if grad_probe is not None else None
         pr = self._pred.ptr if want_pred else None
         y_lo = int(self._pos_host[:, 0].min())
@@ -381,27 +387,52 @@ class MultisliceEngine(object):
             sums = sums[B - last:]
         return float(sums.sum() / (len(sums) * self.n_det))
 
+    def _next_loss_buffer(self):
+        """Switch to the other loss buffer for the launch about to be queued; a read-back still deferred from the launch that
+        wrote it last is queued first (on the current stream), so no sum is ever overwritten before it was copied."""
+        nxt = self._loss_pair[1] if self._loss is self._loss_pair[0] else self._loss_pair[0]
+        d = self._deferred_loss
+        if d is not None and d[3] is nxt:
+            self.flush_loss_copy()
+        self._loss = nxt
+
     def loss_async(self, last=None):
-        """Queue the read-back of the per-position loss sums of the batch just launched and return a token for
-        loss_result(); the host is not blocked, so the next minibatch can be queued first."""
+        """Register the read-back of the per-position loss sums of the batch just launched and return a token for
+        loss_result(); the host is not blocked, so the next minibatch can be queued first.  The copy itself is DEFERRED to
+        the next flush_loss_copy() -- the drivers call it inside the side-stream region of the next minibatch, where the copy
+        and its dependency gaps cost the main stream nothing (on the main stream it sat between the optimiser kernel and the
+        next rotation: ~11 us per minibatch) -- or to loss_result(), whichever comes first."""
         from .device import PinnedArray, Event
         if getattr(self, '_loss_pinned', None) is None or self._loss_pinned[0].shape[0] < self.max_batch:
             self._loss_pinned = [PinnedArray(self.ctx, (self.max_batch,)) for _ in range(2)]
             self._loss_events = [Event(self.ctx) for _ in range(2)]
             self._loss_slot = 0
+        if self._deferred_loss is not None:
+            self.flush_loss_copy()
         self._loss_slot ^= 1
-        k = self._loss_slot
-        B = self._B
-        # on the side stream (it waits for everything queued so far): the copy and its dependency gaps stay off the main
-        # stream, whose next kernel is the next minibatch's rotation
-        self.ctx.fork()
-        self._loss_pinned[k].copy_from_async(self._loss, 4 * B)
-        self._loss_events[k].record()
-        self.ctx.end_fork()
-        return (k, B, last)
+        token = [self._loss_slot, self._B, last, self._loss]
+        self._deferred_loss = token
+        return token
+
+    def flush_loss_copy(self):
+        """Queue the deferred loss read-back, if any, on the stream the context is enqueuing on right now."""
+        token = self._deferred_loss
+        self._deferred_loss = None
+        if token is not None and token[3] is not None:
+            k, B = token[0], token[1]
+            self._loss_pinned[k].copy_from_async(token[3], 4 * B)
+            self._loss_events[k].record()
+            token[3] = None
 
     def loss_result(self, token):
-        k, B, last = token
+        k, B, last = token[0], token[1], token[2]
+        if token[3] is not None:            # nobody flushed it yet: queue the copy now
+            if self._deferred_loss is token:
+                self.flush_loss_copy()
+            else:
+                self._loss_pinned[k].copy_from_async(token[3], 4 * B)
+                self._loss_events[k].record()
+                token[3] = None
         self._loss_events[k].synchronize()
         sums = self._loss_pinned[k].array[:B].astype(np.float64)
         if last is not None:

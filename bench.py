@@ -225,6 +225,7 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         eng.set_batch(pos, tgt)
         eng.rotate(state.obj, tables[it], None)
         ctx.fork()
+        eng.flush_loss_copy()
         state.finish_update()
         check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * n_groups, cfg['alpha_b'] * n_groups,
                                        cfg['gamma'] * n_groups, state.grad.ptr, None))
@@ -475,6 +476,7 @@ def main():
         yr = eng.y_footprint(pos)
         eng.rotate(state.obj, tables[it], yr)
         ctx.fork()
+        eng.flush_loss_copy()       # the previous step's loss read-back, off the main stream
         state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
         check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
                                        state.grad.ptr, None))      # initialises the gradient buffer: no separate zero fill
@@ -539,7 +541,8 @@ def main():
         step(k, False)
     resolve()
     from adorym_amd.device import PhaseClock
-    state.clock = PhaseClock(ctx)
+    if use_dist:        # (one GPU: nothing to explain, and the event records would sit between the kernels of the step's tail)
+        state.clock = PhaseClock(ctx)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -550,7 +553,7 @@ def main():
     torch.cuda.synchronize()
     dt = comm.max_over_ranks(time.perf_counter() - t0)
     state.finish_update()
-    phases = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()}
+    phases = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()} if state.clock is not None else {}
     state.clock = None
 
     if rank == 0:
