@@ -513,13 +513,17 @@ __global__ __launch_bounds__(1024) void reg_value_reduce_kernel(const float* __r
 // real_imag branches (adorym/regularizers.py:38-45, 105-110): the regularised quantities are u = re^2 + im^2 (TV),
 // |o| = sqrt(u) (L1, about its mean) and phi = atan2(im, re) (TV and L1); chain rule back to (re, im).
 // stats[0] = sum |o|, stats[1] = sum sgn(|o| - mean|o|) (filled by the two pre-passes when alpha_d != 0).
-__global__ __launch_bounds__(256) void ri_stats_kernel(const float2* __restrict__ x, size_t V, float* stats, int pass) {
+// wgt (reweighted L1, adorym/regularizers.py:73-82): the sign sum of pass 1 is weighted with wm = w_re^2 + w_im^2 per voxel.
+__global__ __launch_bounds__(256) void ri_stats_kernel(const float2* __restrict__ x, size_t V, float* stats, int pass,
+                                                       const float2* __restrict__ wgt = nullptr) {
     float acc = 0.f;
     const float mean = pass ? stats[0] / (float)V : 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x) {
         const float2 o = x[i];
         const float om = sqrtf(o.x * o.x + o.y * o.y);
-        acc += pass ? sgn(om - mean) : om;
+        float wm = 1.f;
+        if (wgt && pass) { const float2 w = wgt[i]; wm = w.x * w.x + w.y * w.y; }
+        acc += pass ? wm * sgn(om - mean) : om;
     }
     __shared__ float red[4];
 #pragma unroll
@@ -586,6 +590,52 @@ __global__ __launch_bounds__(256) void reg_grad_ri_kernel(const float2* __restri
             gi += gamma * invV * (gu * 2.f * o.y + gp * o.x / u);
         }
         float2 gv = set ? make_float2(0.f, 0.f) : g[i];
+        gv.x += gr;
+        gv.y += gi;
+        g[i] = gv;
+    }
+    if (reg_value) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = val;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reg_value, red[0] + red[1] + red[2] + red[3]);
+    }
+}
+
+// Reweighted L1 for complex-transmission unknowns (adorym/regularizers.py:73-82): with wm = w_re^2 + w_im^2 (constants),
+//   alpha_d * mean(wm * | |o| - mean|o| |) + alpha_b * mean(wm * |atan2(im, re)|);   stats as in reg_grad_ri_kernel, the
+// sign sum weighted.  g += gradient w.r.t. (re, im); value added to *reg_value.
+__global__ __launch_bounds__(256) void reg_grad_ri_weighted_kernel(const float2* __restrict__ x, const float2* __restrict__ wgt,
+                                                                   float2* __restrict__ g, size_t V, float a_d, float a_b,
+                                                                   const float* __restrict__ stats, float* reg_value) {
+    const float invV = 1.0f / (float)V;
+    float val = 0.f;
+    const float mean_om = (a_d != 0.f) ? stats[0] * invV : 0.f;
+    const float mean_sg = (a_d != 0.f) ? stats[1] * invV : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 o = x[i];
+        const float2 w = wgt[i];
+        const float wm = w.x * w.x + w.y * w.y;
+        const float u = o.x * o.x + o.y * o.y;
+        float gr = 0.f, gi = 0.f;
+        if (a_d != 0.f) {
+            const float om = sqrtf(u);
+            const float dev = om - mean_om;
+            const float gom = a_d * (wm * sgn(dev) - mean_sg) * invV;
+            gr += gom * o.x / om;
+            gi += gom * o.y / om;
+            val += a_d * wm * fabsf(dev) * invV;
+        }
+        if (a_b != 0.f) {
+            const float ph = atan2f(o.y, o.x);
+            const float gph = a_b * wm * sgn(ph) * invV;
+            gr += -gph * o.y / u;
+            gi += gph * o.x / u;
+            val += a_b * wm * fabsf(ph) * invV;
+        }
+        float2 gv = g[i];
         gv.x += gr;
         gv.y += gi;
         g[i] = gv;
@@ -961,8 +1011,8 @@ static int reg_grad_impl(adm_plan* plan, const float* obj, float alpha_d, float 
             ADM_HIP(hipMemsetAsync(plan->reg_stats, 0, 2 * sizeof(float), st));
             int nb = stream_grid(V);
             if (nb > 1024) nb = 1024;
-            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 0);
-            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 1);
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 0, (const float2*)nullptr);
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 1, (const float2*)nullptr);
         }
         hipLaunchKernelGGL(reg_grad_ri_kernel, dim3(stream_grid(V)), dim3(256), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y,
                            d.obj_x, d.obj_z, alpha_d, alpha_b, gamma, (const float*)plan->reg_stats, reg_value, set ? 1 : 0);
@@ -1060,6 +1110,22 @@ extern "C" int adm_reg_grad_weighted(adm_plan* plan, const float* obj, const flo
     if (!plan || !obj || !weight || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad_weighted: null argument");
     const adm_plan_desc& d = plan->d;
     const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
+    if (d.unknown_type == 1) {          // real_imag (adorym/regularizers.py:73-82)
+        const size_t V = n / 2;
+        hipStream_t st = plan->ctx->stream;
+        if (alpha_d != 0.f) {
+            if (!plan->reg_stats) ADM_HIP(hipMalloc((void**)&plan->reg_stats, 2 * sizeof(float)));
+            ADM_HIP(hipMemsetAsync(plan->reg_stats, 0, 2 * sizeof(float), st));
+            int nb = stream_grid(V);
+            if (nb > 1024) nb = 1024;
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 0, (const float2*)weight);
+            hipLaunchKernelGGL(ri_stats_kernel, dim3(nb), dim3(256), 0, st, (const float2*)obj, V, plan->reg_stats, 1, (const float2*)weight);
+        }
+        hipLaunchKernelGGL(reg_grad_ri_weighted_kernel, dim3(stream_grid(V)), dim3(256), 0, st, (const float2*)obj, (const float2*)weight,
+                           (float2*)grad_obj, V, alpha_d, alpha_b, (const float*)plan->reg_stats, reg_value);
+        ADM_HIP(hipGetLastError());
+        return ADM_OK;
+    }
     hipLaunchKernelGGL(reg_grad_weighted_kernel, dim3(stream_grid(n)), dim3(256), 0, plan->ctx->stream, obj, weight, grad_obj, n,
                        alpha_d, alpha_b, 1.0f / (float)(n / 2), reg_value);
     ADM_HIP(hipGetLastError());

@@ -209,6 +209,36 @@ class PtychographyModel(ForwardModel):
             return None
         return cv['rotation_tables'](int(this_i_theta))
 
+    # ------------------------------------------------------------------ rotate_out_of_loop (adorym/ptychography.py:917-947, 1063-1078)
+    def rotate_outside(self, obj, this_i_theta):
+        """obj.rotate_array(coords(theta), apply_to_arr_rot=False) of the reference: the WHOLE object is rotated to the angle
+        outside the differentiated block.  Fills the engine's slice-major rotated buffer (what the multislice kernel reads,
+        with its transmission cache) and ``arr_rot``, the same voxels in the object's own layout [Y,X,Z,2] (what the
+        regularisers see and what the driver passes as ``obj``, like the reference's obj.arr_rot)."""
+        eng = self.engine
+        eng.rotate(obj, self.common_vars['rotation_tables'](int(this_i_theta)), None)
+        if getattr(self, 'arr_rot', None) is None or self.arr_rot.shape != obj.shape:
+            self.arr_rot = self.device.empty(obj.shape)
+        self.arr_rot.zero_()
+        check(self.device.lib.adm_rotate_adj(eng.plan.handle, eng.obj_rot.ptr, None, self.arr_rot.ptr, 0, eng.obj_size[0]))
+        return self.arr_rot
+
+    def resample_gradient(self, grad, this_i_theta):
+        """gradient.rotate_array(coords(-theta), overwrite_arr=True): the accumulated gradient buffer, which is in the rotated
+        frame, is resampled with the lookup table of -theta -- a bilinear interpolation like the forward rotation, not its
+        transpose -- and overwritten.  Through a cache-less twin of the plan so that the slice-transmission cache of the
+        rotated object stays valid; the engine's rotated-gradient buffer is free at this point and serves as scratch."""
+        eng = self.engine
+        key = int(this_i_theta)
+        inv = self.__dict__.setdefault('_inv_tables', {})
+        if key not in inv:
+            inv[key] = RotationTable(self.device, eng.obj_size, -self.common_vars['theta_ls'][key])
+        aux = eng.cacheless_plan()
+        lib = self.device.lib
+        check(lib.adm_rotate_fwd(aux.handle, grad.ptr, inv[key].ptr, eng.grad_rot.ptr, 0, eng.obj_size[0]))
+        grad.zero_()
+        check(lib.adm_rotate_adj(aux.handle, eng.grad_rot.ptr, None, grad.ptr, 0, eng.obj_size[0]))
+
     def _probe(self, probe_real, probe_imag):
         """probe_real/imag: host arrays [n_modes,Py,Px] or a DeviceArray [n_modes,Py,Px,2] passed as probe_real."""
         if isinstance(probe_real, DeviceArray):
@@ -234,7 +264,11 @@ class PtychographyModel(ForwardModel):
         coords = self._coords(this_i_theta)
         eng.set_batch(this_pos_batch, target)
         yr = eng.y_footprint(this_pos_batch)
-        eng.rotate(obj, coords, yr)
+        rool = bool(self.rotate_out_of_loop) and not self.common_vars.get('two_d_mode')
+        if not (rool and obj is getattr(self, 'arr_rot', None)):
+            # (rotate_out_of_loop: ``obj`` IS the rotated object; the driver hands over arr_rot, whose slice-major twin the
+            # engine already holds from rotate_outside(); any other array is loaded as it is, coords = None)
+            eng.rotate(obj, coords, yr)
         ctx.fork()
         eng.flush_loss_copy()       # the previous minibatch's loss read-back: on the side stream, beside this kernel
         if side_hook is not None:

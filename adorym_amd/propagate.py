@@ -183,6 +183,16 @@ class MultisliceEngine(object):
         self._ring = UploadRing(self.ctx, batch * Py * Px * 4, n_slots=4)
         self.max_batch = batch
 
+    def cacheless_plan(self):
+        """A twin of the plan (same geometry) without the slice-transmission cache: rotations of arrays other than the object
+        (the gradient resampling of rotate_out_of_loop) go through it and leave the cache of ``obj_rot`` alone."""
+        if getattr(self, '_aux_plan', None) is None:
+            d = self.plan.desc
+            self._aux_plan = Plan(self.ctx, self.obj_size, self.probe_size, self.pads, d.k1, self.plan._h[0] + 1j * self.plan._h[1],
+                                  binning=d.binning, n_modes=d.n_modes, sign_convention=d.sign_convention, det_mode=_lib.DET_NONE,
+                                  unknown_type=self.unknown_type)
+        return self._aux_plan
+
     def y_footprint(self, pos_batch):
         pos = np.round(np.asarray(pos_batch)).astype(int).reshape(-1, 2)
         lo = max(0, int(pos[:, 0].min()))

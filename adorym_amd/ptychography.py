@@ -262,7 +262,6 @@ def reconstruct_ptychography(
         raise ValueError("unknown_type must be 'delta_beta' or 'real_imag'")
     if unknown_type == 'real_imag':
         # accelerated subset for complex-transmission unknowns: no masks / object-type constraints / binning yet
-        _not_implemented(reweighted_l1, "reweighted L1 with unknown_type='real_imag'")
         _not_implemented(finite_support_mask_path is not None, "finite support mask with unknown_type='real_imag'")
         _not_implemented(object_type != 'normal', "object_type='%s' with unknown_type='real_imag'" % object_type)
         _not_implemented(binning != 1, "binning > 1 with unknown_type='real_imag'")
@@ -490,7 +489,6 @@ def reconstruct_ptychography(
                        minibatch_size=minibatch_size, n_probe_modes=n_probe_modes, beamstop=beamstop,
                        optimize_probe_defocusing=False, optimize_probe_pos_offset=False, optimize_prj_pos_offset=False,
                        optimize_all_probe_pos=optimize_all_probe_pos, optimize_tilt=False, output_folder=output_folder, debug=debug)
-    _not_implemented(rotate_out_of_loop, 'rotate_out_of_loop')
     fm_args = dict(loss_function_type=loss_function_type, distribution_mode=distribution_mode, device=ctx,
                    common_vars_dict=common_vars, raw_data_type=raw_data_type, run_bfloat16=run_bfloat16, run_float64=run_float64)
     if forward_model == 'auto':
@@ -498,6 +496,10 @@ def reconstruct_ptychography(
     else:
         forward_model = forward_model(**fm_args)
     builtin_model = type(forward_model) in (PtychographyModel, MultiDistModel)
+    rool = bool(rotate_out_of_loop) and not two_d_mode and not is_multi_dist
+    if rool:
+        _not_implemented(not isinstance(forward_model, PtychographyModel), 'rotate_out_of_loop with a user-defined forward model')
+        fuse_per_angle = False
     print_flush('Forward model: {}.'.format(type(forward_model).__name__), sto_rank, rank, **stdout_options)
 
     if regularizers is None:
@@ -698,6 +700,7 @@ def reconstruct_ptychography(
         i_opt_batch = starting_epoch * n_batch + starting_batch      # (:848), re-evaluated every epoch like the reference
         initialize_gradients = True
         pending_ind = []
+        current_i_theta = -1                                         # (:855)
 
         for i_batch in range(starting_batch, n_batch):
             starting_batch = 0
@@ -735,6 +738,14 @@ def reconstruct_ptychography(
             # 'per angle': the minibatches of one angle see the same object, so they are fused into ONE launch
             # (identical sums; all CUs busy instead of `minibatch_size` of them).  The reference evaluates them
             # one by one and only logs the last (ptychography.py:1095-1099 `continue`).
+            # ---- rotate_out_of_loop (ptychography.py:917-947): the object is rotated to the angle OUTSIDE the differentiated
+            # block, once per change of angle -- the minibatches of the same angle that follow an 'immediate' update keep seeing
+            # the object as it was rotated when the angle began, exactly like the reference ----
+            if rool and this_i_theta != current_i_theta:
+                state.finish_update()           # the whole object is read
+                forward_model.rotate_outside(obj.arr, this_i_theta)
+            current_i_theta = this_i_theta
+
             if update_scheme == 'per angle' and fuse_per_angle:
                 pending_ind.append(this_ind_batch)
                 if not is_last_batch_of_this_theta:
@@ -772,7 +783,7 @@ def reconstruct_ptychography(
             grad_func_args = {}
             for arg in forward_model.argument_ls:
                 if arg == 'obj':
-                    grad_func_args[arg] = obj.arr
+                    grad_func_args[arg] = forward_model.arr_rot if rool else obj.arr     # (:1009-1013)
                 elif arg == 'this_i_theta':
                     grad_func_args[arg] = this_i_theta
                 elif arg == 'this_pos_batch':
@@ -788,6 +799,12 @@ def reconstruct_ptychography(
             print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
             if initialize_gradients:
                 initialize_gradients = False
+            if rool:
+                # (:1066-1078) the gradient buffer is in the rotated frame: resample it with the -theta table, after EVERY
+                # minibatch and on everything accumulated so far.  In 'per angle' mode earlier contributions are therefore
+                # resampled again (the reference's TODO at :1075 says they should not be); kept literally -- golden F15
+                # pins it -- and the minibatches of an angle are not fused into one launch in this mode for that reason.
+                forward_model.resample_gradient(gradient.arr, this_i_theta)
             if optimize_probe:
                 gpd = grads[opt_probe.index_in_grad_returns]       # interleaved (real, imag) device array
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, probe_grad_dev.ptr, gpd.ptr, 1.0, gpd.size))
@@ -814,7 +831,7 @@ def reconstruct_ptychography(
                         o['step_size'] = GDOptimizer.scheduled_step(i_opt_batch, o.get('step_size', 0.001), o.get('dynamic_rate', True),
                                                                     o.get('first_downrate_iteration', 92))
                     first = None
-                    if (n_ranks == 1 or state.overlap_gather) and builtin_model and not is_multi_dist and i_batch + 1 < n_batch:
+                    if (n_ranks == 1 or state.overlap_gather) and builtin_model and not is_multi_dist and i_batch + 1 < n_batch and not rool:
                         # one rank: update the y-planes the next minibatch reads first; several ranks: gather the planes the
                         # next minibatches of ALL ranks read first (the same range on every rank: it shapes a collective).
                         # The rest -- of the element-wise update, or of the all-gather -- is queued by that minibatch on the

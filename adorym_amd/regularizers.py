@@ -42,12 +42,12 @@ class TVRegularizer(Regularizer):
 
 class ReweightedL1Regularizer(Regularizer):
     """alpha_d*mean(w_d|delta|) + alpha_b*mean(w_b|beta|) with weights refreshed by the driver
-    (adorym/regularizers.py:49-84, adorym/ptychography.py:995-1000).  ``weight_l1`` is a device array [Y,X,Z,2]."""
+    (adorym/regularizers.py:49-84, adorym/ptychography.py:995-1000); for unknown_type='real_imag', with
+    wm = w_re^2 + w_im^2: alpha_d*mean(wm*| |o| - mean|o| |) + alpha_b*mean(wm*|arg o|) (regularizers.py:73-82).
+    ``weight_l1`` is a device array [Y,X,Z,2]; the arithmetic is adm_reg_grad_weighted's."""
 
     def __init__(self, alpha_d, alpha_b, unknown_type='delta_beta'):
         super(ReweightedL1Regularizer, self).__init__(unknown_type)
-        if unknown_type != 'delta_beta':
-            raise NotImplementedError("reweighted L1 with unknown_type='real_imag' is outside the accelerated path")
         self.alpha_d = alpha_d
         self.alpha_b = alpha_b
         self.weight_l1 = None

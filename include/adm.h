@@ -322,7 +322,9 @@ int adm_momentum_step(adm_ctx* ctx, float* x, const float* g, float* v, size_t l
                       int flags, const float* mask);
 /* Reweighted L1 (adorym/regularizers.py:49-84).  adm_rwl1_update: weight = max(obj) / (|obj| + 1e-4*mean(obj)) over both
  * channels jointly (adorym/ptychography.py:995-1000); scratch = device float[2*1024+2].  adm_reg_grad_weighted:
- * grad_obj += alpha_c * weight * sign(obj) / V, reg_value += alpha_d*mean(w_d|delta|) + alpha_b*mean(w_b|beta|). */
+ * grad_obj += alpha_c * weight * sign(obj) / V, reg_value += alpha_d*mean(w_d|delta|) + alpha_b*mean(w_b|beta|).
+ * Plans with unknown_type 'real_imag' evaluate the reference's real_imag branch instead (regularizers.py:73-82): with
+ * wm = w_re^2 + w_im^2, alpha_d*mean(wm*| |o| - mean|o| |) + alpha_b*mean(wm*|atan2(im, re)|), gradient w.r.t. (re, im). */
 int adm_rwl1_update(adm_plan* plan, const float* obj, float* weight, float* scratch);
 int adm_reg_grad_weighted(adm_plan* plan, const float* obj, const float* weight, float alpha_d, float alpha_b, float* grad_obj,
                           float* reg_value);

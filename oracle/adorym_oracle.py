@@ -639,6 +639,33 @@ def reweighted_l1_value_grad(obj, weight, alpha_d, alpha_b):
     return val, g
 
 
+def reweighted_l1_value_grad_ri(obj, weight, alpha_d, alpha_b):
+    """ReweightedL1Regularizer.get_value for unknown_type='real_imag' (regularizers.py:73-82): with wm = w_re^2 + w_im^2,
+    alpha_d * mean(wm * | |o| - mean|o| |) + alpha_b * mean(wm * |atan2(im, re)|); the weights are constants (no_grad).
+    Gradient w.r.t. (re, im) by the chain rule, sign(0) = 0 like torch's abs."""
+    r, i = obj[..., 0], obj[..., 1]
+    V = r.size
+    wm = weight[..., 0] ** 2 + weight[..., 1] ** 2
+    val = 0.
+    g = np.zeros_like(obj)
+    u = r ** 2 + i ** 2
+    if alpha_d not in (None, 0):
+        om = np.sqrt(u)
+        dev = om - om.mean()
+        val += alpha_d * np.mean(wm * np.abs(dev))
+        s = wm * np.sign(dev)
+        gom = alpha_d * (s - s.mean()) / V
+        g[..., 0] += gom * r / om
+        g[..., 1] += gom * i / om
+    if alpha_b not in (None, 0):
+        ph = np.arctan2(i, r)
+        val += alpha_b * np.mean(wm * np.abs(ph))
+        gph = alpha_b * wm * np.sign(ph) / V
+        g[..., 0] += -gph * i / u
+        g[..., 1] += gph * r / u
+    return val, g
+
+
 def gd_step_size(i_batch, step_size, dynamic_rate=True, first_downrate_iteration=92):
     """GDOptimizer.apply_gradient schedule (optimizers.py:452-460)."""
     if dynamic_rate:
@@ -790,7 +817,8 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                 update_scheme='immediate', optimizer_batch_number_increment='angle',
                 non_negativity=False, object_type='normal', mask=None, dtype='float64',
                 n_ranks=1, two_d_mode=False, raw_data_type='magnitude', gd_options=None,
-                return_trace=False, optimize_probe=False, probe_learning_rate=1e-5, rank_local_counters=False):
+                return_trace=False, optimize_probe=False, probe_learning_rate=1e-5, rank_local_counters=False,
+                rotate_out_of_loop=False):
     """
     Control flow of reconstruct_ptychography (ptychography.py:783-1295) restricted to
     distribution_mode=None, shared probe, AD path.  ``n_ranks>1`` emulates `mpirun -n R`: per-rank
@@ -805,6 +833,14 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
     counter for all ranks -- rank 0's view of the global batch -- which is what a sharded (single-copy) update can do and
     what adorym_amd does; the two coincide whenever no global batch straddles angles (pinned: F14 'immediate6*',
     'perangle', 'probe6').  Returns rank 0's object.
+
+    ``rotate_out_of_loop`` (ptychography.py:917-947, 1011, 1063-1078; forward_model.py:266-271): the object is rotated to
+    the angle OUTSIDE the differentiated block, once per change of angle (so the minibatches of one angle that follow an
+    'immediate' update still see the object as it was when the angle began); loss, regularisers and gradient are taken
+    w.r.t. that rotated array; the ACCUMULATED gradient buffer is then resampled with the lookup table of -theta
+    (gradient.rotate_array(..., overwrite_arr=True): an interpolation, not the transpose of the forward gather) after
+    every minibatch -- in 'per angle' mode what was accumulated earlier is therefore resampled again with each further
+    minibatch (the reference's own TODO at :1075); restated literally.  Golden F15.
     """
     dt = np.dtype(dtype)
     n_rep = n_ranks if rank_local_counters else 1
@@ -831,6 +867,8 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
         i_opt = [0] * n_rep   # starting_epoch * n_batch + starting_batch (ptychography.py:848), no checkpoint
         grad_acc = None
         gp_acc = None
+        current_theta = [-1] * n_rep        # ptychography.py:855
+        arr_rot = [None] * n_rep
         for i_batch in range(n_batch):
             g_sum = None
             gp_sum = None
@@ -848,6 +886,11 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                     coords = tables[i_theta]
                 pos = probe_pos_int[ind]
                 meas = np.abs(prj[i_theta, ind])
+                if rotate_out_of_loop and not two_d_mode:
+                    if i_theta != current_theta[rep]:
+                        arr_rot[rep] = rotate_fwd(obj, coords, dt)
+                        current_theta[rep] = i_theta
+                    obj, coords = arr_rot[rep], None
                 loss, pred, g, gp = forward_adjoint_object(obj, coords, pc, pos, meas, phys, dt,
                                                            raw_data_type=raw_data_type)
                 if alpha_d not in (None, 0) or alpha_b not in (None, 0):
@@ -865,6 +908,13 @@ def reconstruct(prj, obj_init, probe, probe_pos, theta_ls, phys, n_epochs=1, min
                 first_grad = g_sum.copy()
             grad_acc = g_sum if grad_acc is None else grad_acc + g_sum
             gp_acc = gp_sum if gp_acc is None else gp_acc + gp_sum
+            if rotate_out_of_loop and not two_d_mode:
+                if n_ranks != 1:
+                    raise NotImplementedError('rotate_out_of_loop is restated for one rank')
+                key = ('inv', thetas[0])
+                if key not in tables:
+                    tables[key] = rotation_coords(obj0.shape[:3], -theta_ls[thetas[0]], dt)
+                grad_acc = rotate_fwd(grad_acc, tables[key], dt)        # ptychography.py:1069-1078
             logged = False
             for rep in range(n_rep):
                 cur_theta = thetas[rep] if rank_local_counters else int(batches[i_batch][0, 0])

@@ -137,6 +137,14 @@ W2_RUNS = {
 }
 
 
+# ---------------------------------------------------------------- F15: rotate_out_of_loop through the driver (E2E inputs)
+ROOL_RUNS = {
+    'immediate': dict(n_epochs=2, optimizer='adam', learning_rate=1e-6),
+    'immediate_reg': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5),
+    'perangle': dict(n_epochs=1, optimizer='adam', learning_rate=1e-6, update_scheme='per angle'),
+}
+
+
 # ---------------------------------------------------------------- F11: config-1-shaped 2-D ptychography (f2 row)
 C1MINI = dict(Y=40, X=44, P=16, M=2, energy_ev=8801.121930115722, psize_cm=1.32789376566526e-06, minibatch_size=5, n_dp_batch=2)
 

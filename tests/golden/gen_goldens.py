@@ -744,8 +744,61 @@ def gen_f13():
     save('F13_beamstop', **out)
 
 
+# ----------------------------------------------------------------------------- F16 (reweighted L1, unknown_type='real_imag')
+def gen_f16():
+    """ReweightedL1Regularizer with unknown_type='real_imag' (adorym/regularizers.py:73-82) and the weight update of the DP
+    branch (adorym/ptychography.py:995-1000)."""
+    out = {}
+    r = cases.rng(16)
+    shape = (6, 7, 5)
+    mag = 1 - 0.3 * r.uniform(size=shape)
+    ph = 0.6 * r.uniform(size=shape) - 0.25
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    out['obj'] = obj
+    for fp64 in (True, False):
+        gs.run_fp64 = fp64
+        dt = torch.float64 if fp64 else torch.float32
+        o = torch.tensor(obj, dtype=dt, requires_grad=True)
+        with torch.no_grad():
+            wgt = w.max(o) / (w.abs(o) + 1e-4 * w.mean(o))
+        reg = adorym.ReweightedL1Regularizer(alpha_d=0.8, alpha_b=0.3, unknown_type='real_imag')
+        reg.update_l1_weight(wgt)
+        val = reg.get_value(o)
+        tag = '64' if fp64 else '32'
+        out['weight_' + tag] = wgt.numpy()
+        out['val_' + tag] = np.array(val.item())
+        out['grad_' + tag] = torch.autograd.grad(val, [o])[0].numpy()
+    gs.run_fp64 = False
+    save('F16_rwl1_real_imag', **out)
+
+
+# ----------------------------------------------------------------------------- F15 (rotate_out_of_loop, DP mode)
+def gen_f15():
+    """rotate_out_of_loop=True through the reference driver (adorym/ptychography.py:917-947, 1011, 1063-1078): the object is
+    rotated outside the differentiated block once per angle, the gradient buffer is resampled back with the -theta table."""
+    g6 = np.load(os.path.join(HERE, 'F6_e2e.npz'))
+    prj = g6['prj'].astype(np.float64)
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    N = E['N']
+    common = dict(minibatch_size=E['minibatch_size'], initial_guess=[inp['guess'][0], inp['guess'][1]],
+                  probe_type='supplied', probe_initial=[inp['probe_mag'], inp['probe_phase']], rotate_out_of_loop=True)
+    out = {}
+    for rn, extra in cases.ROOL_RUNS.items():
+        for fp64 in (True, False):
+            rec = {}
+            ex = dict(common); ex.update(extra); ex['run_float64'] = fp64
+            run_driver(prj, [N, N, N], inp['probe_pos'], 2 * np.pi, E['n_theta'], ex, rec)
+            tag = rn + ('_64' if fp64 else '_32')
+            out['delta_' + tag] = rec['delta'].astype(np.float64 if fp64 else np.float32)
+            out['beta_' + tag] = rec['beta'].astype(np.float64 if fp64 else np.float32)
+            out['losses_' + tag] = rec['losses']
+    gs.run_fp64 = False
+    save('F15_rotate_out_of_loop', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
+    which = sys.argv[1:] or ['f15', 'f16', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -758,3 +811,5 @@ if __name__ == '__main__':
     if 'f11' in which: gen_f11()
     if 'f12' in which: gen_f12()
     if 'f13' in which: gen_f13()
+    if 'f15' in which: gen_f15()
+    if 'f16' in which: gen_f16()

@@ -79,3 +79,92 @@ def test_side_stream_gather_beside_next_reduce_scatter_1000_iterations(A, ctx, r
         ctx.sync()
         ctx.lib.adm_comm_destroy(ctx.handle)
         rc.ctx = None
+
+
+# ------------------------------------------------------------------------------------------------ f4 leftovers
+def _driver(tmp_path, **extra):
+    g6 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F6_e2e.npz'))
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    import adorym_amd as AA
+    params = dict(fname=g6['prj'].astype(np.float32), obj_size=[E['N']] * 3, probe_pos=inp['probe_pos'], theta_st=0,
+                  theta_end=2 * np.pi, n_theta=E['n_theta'], energy_ev=E['energy_ev'], psize_cm=E['psize_cm'], free_prop_cm='inf',
+                  minibatch_size=E['minibatch_size'], initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='supplied',
+                  probe_initial=[inp['probe_mag'], inp['probe_phase']], gamma=0, alpha_d=0, alpha_b=0,
+                  save_path=str(tmp_path), output_folder='out', store_checkpoint=False, use_checkpoint=False, return_state=True)
+    params.update(extra)
+    return inp, AA.reconstruct_ptychography(**params)
+
+
+@pytest.mark.parametrize('run', list(cases.ROOL_RUNS))
+def test_rotate_out_of_loop_driver_matches_reference(tmp_path, run):
+    """rotate_out_of_loop=True (adorym/ptychography.py:917-947, 1011, 1063-1078) against the reference driver's own runs
+    (golden F15): object RMSE vs its fp64 run < 1e-5 and the 3x rule against its fp32 run; per-minibatch losses."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F15_rotate_out_of_loop.npz'))
+    inp, st = _driver(tmp_path, rotate_out_of_loop=True, **cases.ROOL_RUNS[run])
+    x = np.stack([st['delta'], st['beta']], -1).astype(np.float64)
+    x64 = np.stack([g['delta_%s_64' % run], g['beta_%s_64' % run]], -1).astype(np.float64)
+    x32 = np.stack([g['delta_%s_32' % run], g['beta_%s_32' % run]], -1).astype(np.float64)
+    upd = np.linalg.norm(x64 - np.stack(inp['guess'], -1))
+    e_us, e_ref = np.linalg.norm(x - x64), np.linalg.norm(x32 - x64)
+    print('%s: |x-x64|/|update| = %.2e (reference fp32: %.2e)' % (run, e_us / upd, e_ref / upd))
+    assert np.sqrt(np.mean((x[..., 0] - x64[..., 0]) ** 2)) < 1e-5
+    if run == 'immediate_reg':          # sign() gradients: a handful of voxels flip in any fp32 implementation
+        d = np.abs(x - x64)
+        assert (d > 1e-6).mean() < 1e-3 and d.max() < 1e-4
+    else:
+        assert e_us <= 3 * e_ref + 1e-4 * upd, (e_us, e_ref, upd)
+    assert np.allclose(st['losses'], g['losses_%s_64' % run], rtol=2e-4)
+    # and it is NOT the in-loop result: the two modes differ by design (stale rotated object within an angle, resampled gradient)
+    g6 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F6_e2e.npz'))
+    if run == 'perangle':
+        assert np.linalg.norm(x[..., 0] - g6['delta_adam_e1_perangle_64']) > 10 * e_us
+
+
+def test_reweighted_l1_real_imag_kernel_matches_reference(A, ctx):
+    """adm_rwl1_update + adm_reg_grad_weighted on a real_imag plan against golden F16 (adorym/regularizers.py:73-82,
+    adorym/ptychography.py:995-1000): weights, value, gradient."""
+    from adorym_amd._lib import check
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F16_rwl1_real_imag.npz'))
+    obj = g['obj'].astype(np.float32)
+    Y, X, Z = obj.shape[:3]
+    eng = A.MultisliceEngine(ctx, (Y, X, Z), (8, 8), np.zeros((1, 2), int), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm=0, max_batch=1,
+                             unknown_type='real_imag')
+    d_obj, d_w, d_g, d_v = ctx.array(obj), ctx.empty(obj.shape), ctx.zeros(obj.shape), ctx.zeros((1,))
+    scratch = ctx.empty((2 * 1024 + 2,))
+    check(ctx.lib.adm_rwl1_update(eng.plan.handle, d_obj.ptr, d_w.ptr, scratch.ptr))
+    assert rel(d_w.get(), g['weight_64']) < 1e-6
+    check(ctx.lib.adm_reg_grad_weighted(eng.plan.handle, d_obj.ptr, d_w.ptr, 0.8, 0.3, d_g.ptr, d_v.ptr))
+    e_ref = rel(g['grad_32'], g['grad_64'])
+    e_us = rel(d_g.get(), g['grad_64'])
+    print('rwl1 real_imag: grad rel err %.2e (reference fp32 %.2e)' % (e_us, e_ref))
+    assert e_us <= max(3 * e_ref, 2e-6)
+    assert abs(float(d_v.get()[0]) - float(g['val_64'])) <= 2e-6 * abs(float(g['val_64']))
+    # accumulates: a second call doubles the gradient
+    check(ctx.lib.adm_reg_grad_weighted(eng.plan.handle, d_obj.ptr, d_w.ptr, 0.8, 0.3, d_g.ptr, None))
+    assert rel(d_g.get(), 2 * g['grad_64']) <= max(3 * e_ref, 2e-6)
+
+
+def test_reweighted_l1_real_imag_through_the_driver(tmp_path):
+    """The reference's real_imag run with reweighted_l1=True is accepted by the driver (it raised in round 2): 2-D object,
+    finite result, loss decreasing."""
+    import adorym_amd as AA
+    c = cases.C1MINI
+    inp = cases.c1mini_inputs()
+    from oracle import adorym_oracle as OO
+    phys = OO.Physics((c['P'], c['P']), c['energy_ev'], c['psize_cm'], free_prop_cm='inf', unknown_type='real_imag')
+    pm, pp = inp['probe_true']
+    probes = pm * np.exp(1j * pp)
+    truth = np.stack([inp['truth'][0] * np.cos(inp['truth'][1]), inp['truth'][0] * np.sin(inp['truth'][1])], -1)
+    pos = np.round(inp['pos_nominal']).astype(int)
+    tiles, _ = OO.extract_tiles(truth, pos, (c['P'], c['P']), 'real_imag')
+    prj = OO.predict(tiles, probes, phys, 'float64')[0][None].astype(np.float32)
+    st = AA.reconstruct_ptychography(
+        fname=prj, obj_size=[c['Y'], c['X'], 1], probe_pos=pos.astype(float), energy_ev=c['energy_ev'], psize_cm=c['psize_cm'],
+        free_prop_cm='inf', minibatch_size=c['minibatch_size'], n_epochs=3, unknown_type='real_imag', optimizer='adam', learning_rate=1e-2,
+        initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='supplied', probe_initial=[pm, pp], n_probe_modes=c['M'],
+        reweighted_l1=True, alpha_d=1e-4, alpha_b=1e-4, gamma=0, save_path=str(tmp_path), output_folder='out', store_checkpoint=False,
+        use_checkpoint=False, return_state=True)
+    l = np.array(st['losses'])
+    assert np.all(np.isfinite(st['delta'])) and np.all(np.isfinite(l))
+    assert l[len(l) // 2:].mean() < l[:len(l) // 2].mean()

@@ -290,6 +290,32 @@ def test_f14_world2_task_split_both_ranks():
             assert np.array_equal(np.stack(ind), g['r%d_ind_%s_64' % (rank, run)])
 
 
+# ------------------------------------------------------------------ F15: rotate_out_of_loop through the driver
+@pytest.mark.parametrize('run', list(cases.ROOL_RUNS))
+def test_f15_rotate_out_of_loop_driver_fp64(run):
+    """adorym/ptychography.py:917-947, 1011, 1063-1078: object rotated outside the differentiated block once per angle,
+    regularisers on the rotated array, accumulated gradient resampled with the -theta table after every minibatch
+    (literally, including the re-resampling of 'per angle' accumulation the reference's TODO mentions)."""
+    g = load('F15_rotate_out_of_loop')
+    kw = dict(cases.ROOL_RUNS[run])
+    kw.pop('optimizer')
+    _, (obj, losses, _) = _e2e(run, 'float64', rotate_out_of_loop=True, **kw)
+    x64 = np.stack([g['delta_%s_64' % run], g['beta_%s_64' % run]], -1)
+    upd = np.linalg.norm(x64 - np.stack(cases.e2e_inputs()['guess'], -1))
+    assert np.linalg.norm(obj - x64) < 1e-11 * upd
+    assert np.allclose(losses, g['losses_%s_64' % run], rtol=1e-11, atol=0)
+
+
+# ------------------------------------------------------------------ F16: reweighted L1, unknown_type='real_imag'
+def test_f16_reweighted_l1_real_imag():
+    g = load('F16_rwl1_real_imag')
+    wgt = O.reweighted_l1_weight(g['obj'])
+    assert np.allclose(wgt, g['weight_64'], rtol=1e-13)
+    val, grad = O.reweighted_l1_value_grad_ri(g['obj'], wgt, 0.8, 0.3)
+    assert abs(val - g['val_64']) < 1e-13 * abs(g['val_64'])
+    assert rel(grad, g['grad_64']) < 1e-13
+
+
 # ------------------------------------------------------------------ F9 (variants: Poisson, Momentum, reweighted L1)
 @pytest.mark.parametrize('rdt', ['magnitude', 'intensity'])
 @pytest.mark.parametrize('pm', [1.0, 50.0])
