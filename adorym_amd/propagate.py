@@ -297,9 +297,14 @@ class MultisliceEngine(object):
         so the asynchronous driver path is covered too, not only the blocking loss()."""
         if len(pos) <= self.MAX_COVER:
             return
+        import collections
         key = pos.tobytes()
-        cache = self.__dict__.setdefault('_cover_ok', {})
-        if key not in cache:
+        cache = self.__dict__.setdefault('_cover_ok', collections.OrderedDict())
+        if key in cache:
+            cache.move_to_end(key)
+        else:
+            while len(cache) >= 64:           # bounded: randomised scans meet a new position set every minibatch
+                cache.popitem(last=False)
             Py, Px = self.probe_size
             y0 = pos[:, 0] - pos[:, 0].min()
             x0 = pos[:, 1] - pos[:, 1].min()

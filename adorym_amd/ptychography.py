@@ -50,35 +50,60 @@ def print_flush(a, designate_rank=None, this_rank=None, save_stdout=False, outpu
     sys.stdout.flush()
 
 
+def _atomic_write(path, writer):
+    """Write through a temporary name and os.replace() it into place: a reader never sees a half-written file."""
+    tmp = path + '.tmp'
+    with open(tmp, 'wb') as f_tmp:
+        writer(f_tmp)
+    os.replace(tmp, path)
+
+
 def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_name='obj', rank=0, n_ranks=1, params=None):
     """Reference file formats (adorym/misc.py:179-194, adorym/optimizers.py:170-188, :779-790):
     checkpoint/checkpoint.txt (epoch, batch), obj_checkpoint.npy [Y,X,Z,2], opt_obj_params_checkpoint.npy
     (stacked moments [n,Y,X,Z,2]) and the pickled params_{rank}.  With more than one rank the moments are sharded,
-    so every rank writes its shard as opt_obj_params_checkpoint_rank_{r}.npy (the reference's per-rank naming)."""
+    so every rank writes its shard as opt_obj_params_checkpoint_rank_{r}.npy (the reference's per-rank naming).
+
+    Every rank writes its files from its own helper thread, so a crash can leave files of different minibatches side by
+    side.  To make that detectable (not part of the reference's format): every file goes through a temporary name +
+    os.replace, each rank writes stamp_rank_{r}.txt = (epoch, batch) AFTER its own files, and rank 0 writes checkpoint.txt
+    last; restore_checkpoint() only accepts a checkpoint whose stamps all equal checkpoint.txt."""
     import pickle
     path = os.path.join(output_folder, 'checkpoint')
     os.makedirs(path, exist_ok=True)
+    stamp = np.array([i_epoch, i_batch])
     if rank == 0:
-        np.savetxt(os.path.join(path, 'checkpoint.txt'), np.array([i_epoch, i_batch]), fmt='%d')
-        np.save(os.path.join(path, 'obj_checkpoint.npy'), obj_array)
+        _atomic_write(os.path.join(path, 'obj_checkpoint.npy'), lambda f_: np.save(f_, obj_array))
     if len(moments) > 0:
         arr = np.stack(moments)
         if n_ranks == 1:
-            np.save(os.path.join(path, 'opt_{}_params_checkpoint.npy'.format(opt_name)), arr.reshape((len(moments),) + obj_array.shape))
+            arr = arr.reshape((len(moments),) + obj_array.shape)
+            name = 'opt_{}_params_checkpoint.npy'.format(opt_name)
         else:
-            np.save(os.path.join(path, 'opt_{}_params_checkpoint_rank_{}.npy'.format(opt_name, rank)), arr)
+            name = 'opt_{}_params_checkpoint_rank_{}.npy'.format(opt_name, rank)
+        _atomic_write(os.path.join(path, name), lambda f_: np.save(f_, arr))
     if params is not None:
-        with open(os.path.join(path, 'params_{}'.format(rank)), 'wb') as f_pcp:
-            pickle.dump(params, f_pcp)
+        _atomic_write(os.path.join(path, 'params_{}'.format(rank)), lambda f_: pickle.dump(params, f_))
+    _atomic_write(os.path.join(path, 'stamp_rank_{}.txt'.format(rank)), lambda f_: np.savetxt(f_, stamp, fmt='%d'))
+    if rank == 0:
+        _atomic_write(os.path.join(path, 'checkpoint.txt'), lambda f_: np.savetxt(f_, stamp, fmt='%d'))
 
 
 def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks=1, obj_shape=None, shard_size=None):
     """adorym/misc.py:197-211 + load_params_checkpoint (adorym/ptychography.py:462).  Everything is read and shape-checked
-    BEFORE anything is returned, so a partial checkpoint cannot leave a run half restored.
+    BEFORE anything is returned, so a partial checkpoint cannot leave a run half restored; this rank's stamp must equal
+    checkpoint.txt (a checkpoint torn by a crash in the middle of a save is refused; checkpoints written by the reference
+    itself carry no stamps and are accepted as they are).
     Returns (i_epoch, i_batch, obj [Y,X,Z,2], moments or None, params dict or None)."""
     import pickle
     path = os.path.join(output_folder, 'checkpoint')
     i_epoch, i_batch = [int(i) for i in np.loadtxt(os.path.join(path, 'checkpoint.txt'))]
+    fs = os.path.join(path, 'stamp_rank_{}.txt'.format(rank))
+    if os.path.exists(fs):
+        st = [int(i) for i in np.loadtxt(fs)]
+        if st != [i_epoch, i_batch]:
+            raise ValueError('torn checkpoint: rank %d wrote its files for (epoch, batch) = %s, checkpoint.txt says %s'
+                             % (rank, tuple(st), (i_epoch, i_batch)))
     obj = np.load(os.path.join(path, 'obj_checkpoint.npy'))
     if obj_shape is not None and tuple(obj.shape) != tuple(obj_shape):
         raise ValueError('obj_checkpoint.npy has shape %s, expected %s' % (obj.shape, tuple(obj_shape)))

@@ -1,0 +1,43 @@
+"""Checkpoint files (adorym/misc.py:179-211, adorym/optimizers.py:170-188 formats) on the host side: round trip, atomic
+replacement, and refusal of a checkpoint whose per-rank stamp disagrees with checkpoint.txt (a save torn by a crash).  CPU."""
+import os
+import numpy as np
+import pytest
+
+from adorym_amd.ptychography import save_checkpoint, restore_checkpoint
+
+
+def test_round_trip_and_no_temporaries(tmp_path):
+    obj = np.random.default_rng(0).random((3, 4, 5, 2)).astype(np.float32)
+    mom = [np.random.default_rng(k).random(obj.size).astype(np.float32) for k in (1, 2)]
+    save_checkpoint(1, 20, str(tmp_path), obj, mom, params={'probe_real': np.ones((1, 2, 2))})
+    files = sorted(os.listdir(tmp_path / 'checkpoint'))
+    assert files == ['checkpoint.txt', 'obj_checkpoint.npy', 'opt_obj_params_checkpoint.npy', 'params_0', 'stamp_rank_0.txt']
+    e, b, o, m, p = restore_checkpoint(str(tmp_path), 2, obj_shape=obj.shape)
+    assert (e, b) == (1, 20) and np.array_equal(o, obj) and m.shape == (2,) + obj.shape
+    assert np.array_equal(m[1].reshape(-1), mom[1]) and np.array_equal(p['probe_real'], np.ones((1, 2, 2)))
+
+
+def test_torn_checkpoint_is_refused(tmp_path):
+    """Rank 1 wrote its shard for batch 20, rank 0 never got that far (checkpoint.txt still says 10): every rank's own stamp is
+    compared with checkpoint.txt, so rank 1 refuses and the driver's agreement step drops the checkpoint on all ranks."""
+    obj = np.zeros((2, 2, 2, 2), np.float32)
+    shard = [np.zeros(8, np.float32), np.zeros(8, np.float32)]
+    save_checkpoint(0, 10, str(tmp_path), obj, shard, rank=0, n_ranks=2)
+    save_checkpoint(0, 10, str(tmp_path), None, shard, rank=1, n_ranks=2)
+    restore_checkpoint(str(tmp_path), 2, rank=1, n_ranks=2, obj_shape=obj.shape, shard_size=8)       # consistent: accepted
+    save_checkpoint(0, 20, str(tmp_path), None, shard, rank=1, n_ranks=2)                              # rank 0 "crashed" before its save
+    restore_checkpoint(str(tmp_path), 2, rank=0, n_ranks=2, obj_shape=obj.shape, shard_size=8)       # rank 0 alone looks fine ...
+    with pytest.raises(ValueError, match='torn checkpoint'):
+        restore_checkpoint(str(tmp_path), 2, rank=1, n_ranks=2, obj_shape=obj.shape, shard_size=8)   # ... rank 1 does not
+
+
+def test_reference_written_checkpoint_without_stamps_is_accepted(tmp_path):
+    d = tmp_path / 'checkpoint'
+    os.makedirs(d)
+    obj = np.ones((2, 2, 2, 2), np.float32)
+    np.savetxt(d / 'checkpoint.txt', np.array([2, 5]), fmt='%d')
+    np.save(d / 'obj_checkpoint.npy', obj)
+    np.save(d / 'opt_obj_params_checkpoint.npy', np.zeros((2,) + obj.shape, np.float32))
+    e, b, o, m, p = restore_checkpoint(str(tmp_path), 2, obj_shape=obj.shape)
+    assert (e, b, p) == (2, 5, None) and np.array_equal(o, obj)
