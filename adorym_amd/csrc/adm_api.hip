@@ -252,6 +252,8 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->trans_src = nullptr;
     p->cover_ws = p->cover_pos = nullptr;
     p->cover_batch = p->cover_row0 = p->cover_nrows = 0;
+    p->chase_buf = nullptr;
+    p->chase_total = 0;
     p->generic = !tuned;
     {   // radix lists of the generic kernel's transforms: 8, 4, 2, 9, 3, 5, 7, then whatever primes remain
         auto factor = [](int n, int* r) {
@@ -324,6 +326,7 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
     if (plan->reg_partial) (void)hipFree(plan->reg_partial);
     if (plan->trans_dev) (void)hipFree(plan->trans_dev);
+    if (plan->chase_buf) (void)hipFree(plan->chase_buf);
     if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
     delete plan;
     return ADM_OK;
@@ -380,9 +383,11 @@ size_t ws_off_det(const adm_plan* plan, int batch) { return ws_off_cover(plan, b
 size_t ws_off_gprobe(const adm_plan* plan, int batch) { return ws_off_det(plan, batch) + ws_det_bytes(plan, batch); }
 }  // namespace adm
 
-static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                           const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
-                           float grad_scale, void* workspace, size_t workspace_bytes, bool per_position) {
+int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                         const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
+                         float grad_scale, void* workspace, size_t workspace_bytes, bool per_position, unsigned* progress,
+                         int progress_shift, bool* chase_armed) {
+    if (chase_armed) *chase_armed = false;
     if (!plan || !obj_rot || !probe || !pos || !target || !loss_sum)
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: batch must be positive");
@@ -458,6 +463,11 @@ static int multislice_impl(adm_plan* plan, const float* obj_rot, const float* pr
         ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
     } else {
         if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
+        if (progress && want_grad && ms_chase_supported(p)) {
+            p.progress = progress;
+            p.progress_shift = progress_shift;
+            if (chase_armed) *chase_armed = true;
+        }
         ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     }
     if (!per_position && grad_probe && want_grad)
@@ -483,14 +493,14 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
                                       const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                                       float grad_scale, void* workspace, size_t workspace_bytes) {
     return multislice_impl(plan, obj_rot, probe, pos, batch, target, want_grad, grad_probe, pred, loss_sum, grad_scale, workspace,
-                           workspace_bytes, false);
+                           workspace_bytes, false, nullptr, 0, nullptr);
 }
 
 extern "C" int adm_multislice_fwd_adj_pp(adm_plan* plan, const float* obj_rot, const float* probes, const int32_t* pos, int batch,
                                          const float* target, int want_grad, float* grad_probes, float* pred, float* loss_sum,
                                          float grad_scale, void* workspace, size_t workspace_bytes) {
     return multislice_impl(plan, obj_rot, probes, pos, batch, target, want_grad, grad_probes, pred, loss_sum, grad_scale, workspace,
-                           workspace_bytes, true);
+                           workspace_bytes, true, nullptr, 0, nullptr);
 }
 
 extern "C" int adm_probe_shift(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,

@@ -1,6 +1,7 @@
 // Whole-object passes: rotation gather / scatter (R2), regulariser gradient (R9),
 // fused Adam / GD + constraints (R13-R15), axpy.  All HBM-bound streaming kernels.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include "adm_common.h"
 #include "adm_ms_math.h"
@@ -354,17 +355,10 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
 #ifndef TA_CU
 #define TA_CU 1
 #endif
-__global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
-                                                              float2* __restrict__ grad_rot, TileGeom g) {
-    // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs, and the 72-144-byte runs a block reads from a
-    // tile row straddle 128-byte lines that its x / y neighbours read too.  XCD k takes the step chunks k, k + 8, ... and
-    // ALL pixel blocks of each, x fastest, so that neighbours share an L2 (with blockIdx = (x, y, z) every straddled
-    // line was fetched from HBM by two or three XCDs; FETCH_SIZE -12 %, time -10 % from the mapping alone).
-    const int nbx = (g.Xp + 31) / 32, nby = (g.nrows + 7) / 8;
-    const int idx = blockIdx.x >> 3;
-    const int zc = (blockIdx.x & 7) + 8 * (idx / (nbx * nby));
-    if (zc * TA_STEPS >= g.n_steps) return;
-    const int rem = idx % (nbx * nby);
+// the work of one block of tile_accumulate_kernel: step chunk zc, pixel block `rem` (x fastest)
+__device__ __forceinline__ void ta_block(const float2* __restrict__ gtile, const unsigned* __restrict__ cover, float2* __restrict__ grad_rot,
+                                         const TileGeom& g, int zc, int rem) {
+    const int nbx = (g.Xp + 31) / 32;
     const int x = (rem % nbx) * 32 + (threadIdx.x & 31);
     const int r = (rem / nbx) * 8 + (threadIdx.x >> 5);
     if (x >= g.Xp || r >= g.nrows) return;
@@ -422,6 +416,58 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
                 out[(size_t)sl * slice_stride] = v;
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
+                                                              float2* __restrict__ grad_rot, TileGeom g) {
+    // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs, and the 72-144-byte runs a block reads from a
+    // tile row straddle 128-byte lines that its x / y neighbours read too.  XCD k takes the step chunks k, k + 8, ... and
+    // ALL pixel blocks of each, x fastest, so that neighbours share an L2 (with blockIdx = (x, y, z) every straddled
+    // line was fetched from HBM by two or three XCDs; FETCH_SIZE -12 %, time -10 % from the mapping alone).
+    const int nbx = (g.Xp + 31) / 32, nby = (g.nrows + 7) / 8;
+    const int idx = blockIdx.x >> 3;
+    const int zc = (blockIdx.x & 7) + 8 * (idx / (nbx * nby));
+    if (zc * TA_STEPS >= g.n_steps) return;
+    ta_block(gtile, cover, grad_rot, g, zc, idx % (nbx * nby));
+}
+
+// The same overlap-add CHASING the multislice launch that produces the tile gradients (ms_fwd_adj_kernel<..., CHASE>): a small
+// persistent grid (one block per compute unit, so that it fits beside the multislice workgroups in whatever order the two
+// launches become resident) walks the step chunks from the highest down -- the order in which the reverse sweep finishes them
+// -- and waits at each progress chunk until every workgroup of the launch has reported it (progress[c] has reached `target`;
+// the counters only ever grow, so nothing is reset between launches).  XCD k again takes the step chunks k, k + 8, ...
+// A block that waits longer than ~0.2 s gives up, raises *err and poisons loss_sum[0] with NaN so that the failure cannot
+// go unnoticed; it never hangs.  Same sums in the same order as tile_accumulate_kernel: bit-identical results.
+__global__ __launch_bounds__(256) void tile_accumulate_chase_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
+                                                                    float2* __restrict__ grad_rot, TileGeom g,
+                                                                    const unsigned* __restrict__ progress, unsigned target, int progress_shift,
+                                                                    unsigned* err, float* poison) {
+    const int nbx = (g.Xp + 31) / 32, nby = (g.nrows + 7) / 8, npix = nbx * nby;
+    const int nz = (g.n_steps + TA_STEPS - 1) / TA_STEPS;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    int zc = xcd + 8 * ((nz - 1 - xcd) / 8);            // the highest chunk congruent to xcd (mod 8); negative if there is none
+    if (nz - 1 - xcd < 0) return;
+    int ready_chunk = 1 << 30;                           // progress chunks >= this one are known to be complete
+    for (; zc >= 0; zc -= 8) {
+        const int chunk = (zc * TA_STEPS) >> progress_shift;
+        if (chunk < ready_chunk) {
+            if (threadIdx.x == 0) {
+                unsigned spins = 0;
+                while ((int)(__hip_atomic_load(progress + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                    __builtin_amdgcn_s_sleep(64);
+                    if (++spins > 100000u) {             // ~0.2 s: the producer is not coming
+                        atomicExch(err, 1u);
+                        if (poison) *poison = __builtin_nanf("");
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            ready_chunk = chunk;
+        }
+        for (int rem = slot; rem < npix; rem += per_xcd) ta_block(gtile, cover, grad_rot, g, zc, rem);
     }
 }
 
@@ -982,6 +1028,59 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     hipLaunchKernelGGL(tile_accumulate_kernel, dim3(8u * nz8 * grid.x * grid.y), dim3(256), 0, st, gtile, (const unsigned*)cover,
                        (float2*)grad_rot, g);
     ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+// Multislice forward + adjoint with the overlap-add of the tile gradients chasing the reverse sweep (see
+// tile_accumulate_chase_kernel): the launch goes to the main stream, the chaser to the side stream, where it runs beside the
+// rest of the launch; adm_ctx_join() orders everything behind both.  Falls back to launch + plain overlap-add (same results,
+// main stream) for kernel variants without progress signals.
+extern "C" int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                                             const float* target, float* grad_probe, float* pred, float* loss_sum, float grad_scale,
+                                             void* workspace, size_t workspace_bytes, const int32_t* pos_host, float* grad_rot,
+                                             int win_y_lo, int win_y_hi, int add) {
+    if (!plan || !workspace || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: null argument");
+    adm_ctx* ctx = plan->ctx;
+    if (ctx->stream != ctx->main_stream) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: call it outside adm_ctx_fork / adm_ctx_end_fork");
+    if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: bad workspace");
+    TileGeom g;
+    int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
+    if (rc) return rc;
+    const int shift = 5;                                  // 32 steps per progress chunk
+    const int n_chunks = ((plan->n_steps - 1) >> shift) + 1;
+    if (!plan->chase_buf && n_chunks <= 240) {
+        ADM_HIP(hipMalloc((void**)&plan->chase_buf, 256 * sizeof(unsigned)));
+        ADM_HIP(hipMemsetAsync(plan->chase_buf, 0, 256 * sizeof(unsigned), ctx->main_stream));
+        plan->chase_total = 0;
+    }
+    unsigned* progress = (plan->chase_buf && n_chunks <= 240) ? plan->chase_buf + 16 : nullptr;
+    // everything the side stream still holds was queued before this point; the chaser goes behind it
+    ADM_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
+    bool armed = false;
+    rc = adm::multislice_impl(plan, obj_rot, probe, pos, batch, target, 1, grad_probe, pred, loss_sum, grad_scale, workspace, workspace_bytes,
+                              false, progress, shift, &armed);
+    if (rc) return rc;
+    if (!armed) return adm_tile_grad_accumulate_part(plan, workspace, workspace_bytes, pos, batch, pos_host, grad_rot, win_y_lo, win_y_hi, add);
+    plan->chase_total += (unsigned)batch;
+    ADM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+    const bool prebuilt = plan->cover_ws == workspace && plan->cover_pos == pos && plan->cover_batch == batch &&
+                          plan->cover_row0 == g.row0 && plan->cover_nrows == g.nrows;
+    plan->cover_ws = nullptr;
+    ctx->stream = ctx->aux_stream;                        // (cover_build queues on the context's current stream)
+    if (!prebuilt) rc = cover_build(plan, workspace, pos, batch, g);
+    ctx->stream = ctx->main_stream;
+    if (rc) return rc;
+    char* ws = (char*)workspace;
+    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
+    const unsigned* cover = (const unsigned*)(ws + ws_off_cover(plan, batch));
+    // blocks of the persistent chaser: 24 VGPRs each, so two per compute unit still fit beside a multislice workgroup (3 x 144
+    // of a SIMD's 512 registers) whichever of the two launches becomes resident first; ADM_CHASE_BLOCKS overrides (tuning)
+    static const int chase_blocks = [] { const char* e = getenv("ADM_CHASE_BLOCKS"); const int v = e ? atoi(e) : 512; return v >= 8 ? (v & ~7) : 512; }();
+    hipLaunchKernelGGL(tile_accumulate_chase_kernel, dim3(chase_blocks), dim3(256), 0, ctx->aux_stream, gtile, cover, (float2*)grad_rot, g,
+                       (const unsigned*)progress, plan->chase_total, shift, plan->chase_buf, loss_sum);
+    ADM_HIP(hipGetLastError());
+    ADM_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+    ctx->join_pending = true;
     return ADM_OK;
 }
 

@@ -8,6 +8,7 @@ a reference to its model (``calculate_loss.forward_model``) so that ``Differenti
 call the hand-derived adjoint (``loss_and_gradients``) instead of ``torch.autograd.grad``.
 """
 import inspect
+import os
 import numpy as np
 
 from ._lib import check
@@ -305,6 +306,10 @@ class PtychographyModel(ForwardModel):
             # no join here: the overlapped launch forks again, and the side stream is in order, so its overlap-adds queue
             # behind the regulariser kernel while the first round of workgroups already runs beside it
             eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)
+        elif want_grad and shifts is None and os.environ.get('ADM_CHASE', '1') == '1':
+            # the overlap-add of the tile gradients chases the reverse sweep on the side stream, chunk of slices by chunk
+            eng.multislice_chased(probe, grad_probe=gp, want_pred=want_pred, grad_scale=gs)
+            ctx.join()
         else:
             eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
                            shift_index=idx, grad_shifts=gsh, accumulate=False)

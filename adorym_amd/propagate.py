@@ -6,6 +6,7 @@ Reference: adorym/propagate.py (get_kernel :62-81, gen_freq_mesh :54-60,
 multislice_propagate_batch :131-288).
 """
 import ctypes as C
+import os
 import numpy as np
 
 from . import _lib
@@ -289,6 +290,22 @@ class MultisliceEngine(object):
         if want_grad and accumulate:
             self.accumulate_tiles()
 
+    def multislice_chased(self, probe, grad_probe=None, want_pred=False, grad_scale=None):
+        """multislice(want_grad=True) + accumulate_tiles() with the overlap-add CHASING the launch on the side stream
+        (adm_multislice_fwd_adj_chased): every chunk of 32 slices is overlap-added as soon as the reverse sweep of all positions
+        has passed it.  Same result bit for bit.  The caller joins (Context.join) before it reads grad_rot."""
+        B = self._B
+        if grad_scale is None:
+            grad_scale = 2.0 / (B * self.n_det)
+        self._check_cover(self._pos_host)
+        self._next_loss_buffer()
+        check(self.ctx.lib.adm_multislice_fwd_adj_chased(
+            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
+            grad_probe.ptr if grad_probe is not None else None, self._pred.ptr if want_pred else None, self._loss.ptr,
+            float(grad_scale), self._ws.ptr, self._ws.nbytes, self._pos_host.ctypes.data, self.grad_rot.ptr, 0, 0, 0))
+        self._accumulated = True
+        self._acc_parts = [(self._ws, B)]
+
     MAX_COVER = 64        # ADM_MAXCOVER of adm_object.hip: cover-list entries per rotated-frame pixel
 
     def _check_cover(self, pos):
@@ -368,15 +385,23 @@ class MultisliceEngine(object):
         self._acc_parts = []
         for o, n in parts:
             self._check_cover(self._pos_host[o:o + n])
+        chase = os.environ.get('ADM_CHASE', '1') == '1'
         for i, (o, n) in enumerate(parts):
             ws = self._ws_parts[i]
-            check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
-                                             self._cur_target.ptr + 4 * o * Py * Px, 1, gp, (pr + 4 * o * Py * Px) if pr else None,
-                                             self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes))
-            self.ctx.fork()                   # side stream: waits for this round, then runs beside the next one
-            check(lib.adm_tile_grad_accumulate_part(h, ws.ptr, ws.nbytes, self._cur_pos.ptr + 8 * o, n,
-                                                    self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
-            self.ctx.end_fork()
+            if chase:
+                # every round's overlap-add chases its own launch on the side stream (in order there: round i before i + 1)
+                check(lib.adm_multislice_fwd_adj_chased(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
+                                                        self._cur_target.ptr + 4 * o * Py * Px, gp, (pr + 4 * o * Py * Px) if pr else None,
+                                                        self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes,
+                                                        self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
+            else:
+                check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
+                                                 self._cur_target.ptr + 4 * o * Py * Px, 1, gp, (pr + 4 * o * Py * Px) if pr else None,
+                                                 self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes))
+                self.ctx.fork()                   # side stream: waits for this round, then runs beside the next one
+                check(lib.adm_tile_grad_accumulate_part(h, ws.ptr, ws.nbytes, self._cur_pos.ptr + 8 * o, n,
+                                                        self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
+                self.ctx.end_fork()
             self._acc_parts.append((ws, n))
         self.ctx.join()
         self._accumulated = True

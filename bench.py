@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CHASE = os.environ.get('ADM_CHASE', '1') == '1'      # A/B switch of the chased overlap-add (default on, like the driver)
 
 
 def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
@@ -485,11 +486,15 @@ def main():
         evs = ev_ms[k & 1] if timed else None
         if timed:
             evs[0].record()
-        eng.multislice(probe, accumulate=False)
+        if CHASE:
+            eng.multislice_chased(probe)      # the overlap-add chases the reverse sweep on the side stream
+        else:
+            eng.multislice(probe, accumulate=False)
         if timed:
             evs[1].record()
         ctx.join()
-        eng.accumulate_tiles()
+        if not CHASE:
+            eng.accumulate_tiles()
         eng.rotate_adjoint(state.grad, tables[it], yr)
         # update the y-planes the next minibatch reads first; the rest of the Adam pass overlaps the next kernel
         # (several ranks: the planes the next minibatches of ALL ranks read are gathered first, the rest of the all-gather

@@ -285,6 +285,17 @@ int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t worksp
  * two calls is the caller's (adm_ctx_join).  No reference counterpart: autograd's index bookkeeping (adorym/forward_model.py:313-331). */
 int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                          const int32_t* pos_host, int win_y_lo, int win_y_hi, int add);
+/* adm_multislice_fwd_adj(want_grad = 1) + adm_tile_grad_accumulate_part in one call, with the overlap-add CHASING the launch:
+ * the reverse sweep reports its progress per chunk of 32 slices, and a small persistent kernel on the context's side stream
+ * overlap-adds every chunk as soon as all positions have passed it -- beside the rest of the launch instead of behind it.  Same
+ * sums in the same order (bit-identical to the two separate calls).  Call on the main stream; adm_ctx_join() before the first
+ * consumer of grad_rot.  Kernel variants without progress signals (several probe modes, real_imag, binning, generic sizes, no
+ * transmission cache) run the two steps one after the other on the main stream.  Replaces the same reference code as the two
+ * calls it fuses (adorym/forward_model.py:313-375, adorym/wrappers.py:322). */
+int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
+                                  const float* target, float* grad_probe, float* pred, float* loss_sum, float grad_scale,
+                                  void* workspace, size_t workspace_bytes, const int32_t* pos_host, float* grad_rot,
+                                  int win_y_lo, int win_y_hi, int add);
 /* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
  * (the overlap-add then dropped contributions; use smaller batches). */
 int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);

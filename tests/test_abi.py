@@ -103,7 +103,7 @@ def test_sharded_checkpoint_files_round_trip(tmp_path):
                         params={'probe_real': np.full((1, 2, 2), rank, np.float32), 'probe_imag': np.zeros((1, 2, 2), np.float32)})
     names = sorted(os.listdir(os.path.join(str(tmp_path), 'checkpoint')))
     assert names == ['checkpoint.txt', 'obj_checkpoint.npy', 'opt_obj_params_checkpoint_rank_0.npy',
-                     'opt_obj_params_checkpoint_rank_1.npy', 'params_0', 'params_1']
+                     'opt_obj_params_checkpoint_rank_1.npy', 'params_0', 'params_1', 'stamp_rank_0.txt', 'stamp_rank_1.txt']
     for rank in range(2):
         e, b, o, mom, params = restore_checkpoint(str(tmp_path), 2, rank=rank, n_ranks=2, obj_shape=obj.shape, shard_size=120)
         assert (e, b) == (3, 8) and np.array_equal(o, obj)

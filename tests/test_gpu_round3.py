@@ -168,3 +168,45 @@ def test_reweighted_l1_real_imag_through_the_driver(tmp_path):
     l = np.array(st['losses'])
     assert np.all(np.isfinite(st['delta'])) and np.all(np.isfinite(l))
     assert l[len(l) // 2:].mean() < l[:len(l) // 2].mean()
+
+
+# ------------------------------------------------------------------------------------------------ chased overlap-add
+@pytest.mark.parametrize('P,S,B', [(72, 40, 40), (72, 6, 9), (16, 70, 300), (36, 33, 64)])
+def test_chased_overlap_add_is_bitwise_the_plain_one(A, ctx, P, S, B):
+    """adm_multislice_fwd_adj_chased: the overlap-add of the tile gradients runs on the side stream, chunk of 32 slices by
+    chunk, as soon as the reverse sweep of every position has passed the chunk (device-side progress counters).  Same sums in
+    the same order as launch + adm_tile_grad_accumulate: gradient, loss and probe gradient bit for bit; slice counts that are
+    not multiples of the chunk; more positions than compute units (several rounds, each chased)."""
+    r = cases.rng(77)
+    Y, X = 2 * P + 20, 3 * P
+    pos = np.stack([r.integers(-P // 4, Y - P + P // 4, B), r.integers(-P // 4, X - P + P // 4, B)], 1)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
+    obj = ctx.array(np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1).astype(np.float32))
+    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
+    meas = (np.abs(r.standard_normal((B, P, P))) * 20).astype(np.float32)
+    eng.rotate(obj, None)
+    out = []
+    for chased in (False, True, True):
+        eng.set_batch(pos, meas)
+        gp = ctx.zeros((1, P, P, 2))
+        eng.grad_rot.zero_()
+        os.environ['ADM_CHASE'] = '1' if chased else '0'
+        try:
+            if B > eng.N_CU:
+                eng.multislice_overlapped(probe, grad_probe=gp)
+            elif chased:
+                eng.multislice_chased(probe, grad_probe=gp)
+                ctx.join()
+            else:
+                eng.multislice(probe, grad_probe=gp)
+        finally:
+            os.environ.pop('ADM_CHASE', None)
+        g = ctx.zeros((Y, X, S, 2))
+        eng.rotate_adjoint(g, None)
+        out.append((eng.loss(), g.get(), gp.get()))
+    assert np.all(np.isfinite(out[1][1])) and np.isfinite(out[1][0])
+    for k in (1, 2):
+        assert out[k][0] == out[0][0]
+        assert np.array_equal(out[k][1], out[0][1])
+        assert np.array_equal(out[k][2], out[0][2])
+    assert np.abs(out[0][1]).max() > 0
