@@ -1053,7 +1053,12 @@ extern "C" int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_ro
         ADM_HIP(hipMemsetAsync(plan->chase_buf, 0, 256 * sizeof(unsigned), ctx->main_stream));
         plan->chase_total = 0;
     }
-    unsigned* progress = (plan->chase_buf && n_chunks <= 240) ? plan->chase_buf + 16 : nullptr;
+    // Measured (round 3, profiles/README.md): NOT a gain on MI355X.  At 32 positions the 8 progress signals (agent-scope release =
+    // L2 write-back) cost the sweep 0.12 ms and the chaser's traffic up to 0.11 ms more, against 0.1 ms of overlap-add hidden;
+    // with the chip full the chaser takes issue slots and power from the sweep it is chasing (7.5 -> 11.2 ms per 544 positions).
+    // The callers therefore use it only on request (ADM_CHASE=1), and large launches never do.  ADM_CHASE_MAX_BATCH overrides.
+    static const int chase_max_batch = [] { const char* e = getenv("ADM_CHASE_MAX_BATCH"); return e ? atoi(e) : 96; }();
+    unsigned* progress = (plan->chase_buf && n_chunks <= 240 && batch <= chase_max_batch) ? plan->chase_buf + 16 : nullptr;
     // everything the side stream still holds was queued before this point; the chaser goes behind it
     ADM_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
     bool armed = false;
@@ -1073,9 +1078,10 @@ extern "C" int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_ro
     char* ws = (char*)workspace;
     const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
     const unsigned* cover = (const unsigned*)(ws + ws_off_cover(plan, batch));
-    // blocks of the persistent chaser: 24 VGPRs each, so two per compute unit still fit beside a multislice workgroup (3 x 144
-    // of a SIMD's 512 registers) whichever of the two launches becomes resident first; ADM_CHASE_BLOCKS overrides (tuning)
-    static const int chase_blocks = [] { const char* e = getenv("ADM_CHASE_BLOCKS"); const int v = e ? atoi(e) : 512; return v >= 8 ? (v & ~7) : 512; }();
+    // blocks of the persistent chaser: 24 VGPRs each, so three per compute unit still fit beside a multislice workgroup (3 x 144
+    // of a SIMD's 512 registers, 3 + 3 of its 8 wave slots) whichever of the two launches becomes resident first;
+    // ADM_CHASE_BLOCKS overrides (tuning)
+    static const int chase_blocks = [] { const char* e = getenv("ADM_CHASE_BLOCKS"); const int v = e ? atoi(e) : 768; return v >= 8 ? (v & ~7) : 768; }();
     hipLaunchKernelGGL(tile_accumulate_chase_kernel, dim3(chase_blocks), dim3(256), 0, ctx->aux_stream, gtile, cover, (float2*)grad_rot, g,
                        (const unsigned*)progress, plan->chase_total, shift, plan->chase_buf, loss_sum);
     ADM_HIP(hipGetLastError());

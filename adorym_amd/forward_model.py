@@ -306,8 +306,10 @@ class PtychographyModel(ForwardModel):
             # no join here: the overlapped launch forks again, and the side stream is in order, so its overlap-adds queue
             # behind the regulariser kernel while the first round of workgroups already runs beside it
             eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)
-        elif want_grad and shifts is None and os.environ.get('ADM_CHASE', '1') == '1':
-            # the overlap-add of the tile gradients chases the reverse sweep on the side stream, chunk of slices by chunk
+        elif want_grad and shifts is None and os.environ.get('ADM_CHASE', '0') == '1':
+            # opt-in (ADM_CHASE=1): the overlap-add of the tile gradients chases the reverse sweep on the side stream, chunk of
+            # slices by chunk.  Bit-identical, but measured SLOWER (the progress signals cost the sweep 0.12 ms per launch, the
+            # chaser's traffic another 0.1 ms, against 0.1 ms of overlap-add hidden): profiles/README.md, round 3
             eng.multislice_chased(probe, grad_probe=gp, want_pred=want_pred, grad_scale=gs)
             ctx.join()
         else:

@@ -385,7 +385,7 @@ class MultisliceEngine(object):
         self._acc_parts = []
         for o, n in parts:
             self._check_cover(self._pos_host[o:o + n])
-        chase = os.environ.get('ADM_CHASE', '1') == '1'
+        chase = os.environ.get('ADM_CHASE', '0') == '1'
         for i, (o, n) in enumerate(parts):
             ws = self._ws_parts[i]
             if chase:

@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-CHASE = os.environ.get('ADM_CHASE', '1') == '1'      # A/B switch of the chased overlap-add (default on, like the driver)
+CHASE = os.environ.get('ADM_CHASE', '0') == '1'      # A/B switch of the chased overlap-add (opt-in, like the driver: measured slower, profiles/README.md)
 
 
 def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
