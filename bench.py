@@ -257,7 +257,7 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
     return out
 
 
-def kernel_sweep(ctx, eng, probe, cfg, targets, batches=(1, 8, 32, 64, 128, 256, 512, 544), reps=3):
+def kernel_sweep(ctx, eng, probe, cfg, targets, batches=(1, 8, 32, 64, 128, 256, 512, 544), reps=5):
     """Duration of the multislice forward+adjoint launch alone (HIP events on its stream) over the number of positions in
     flight: ms per launch, positions/s and fraction of the HBM roofline with SURVEY 8(d)'s algorithmic bytes."""
     mb = cfg['minibatch_size']
@@ -283,9 +283,10 @@ def kernel_sweep(ctx, eng, probe, cfg, targets, batches=(1, 8, 32, 64, 128, 256,
                 eng.multislice(probe, accumulate=False)
             e1.record()
             ts.append(e0.elapsed_ms(e1))
-        ms = float(np.min(ts[1:]))
+        ms = float(np.median(ts[1:]))          # the median of the repetitions (the best of three flattered 256 positions)
         alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
-        rows.append({'positions': B, 'ms': ms, 'positions_per_s': B / (ms * 1e-3), 'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        rows.append({'positions': B, 'ms': ms, 'ms_min': float(np.min(ts[1:])), 'ms_max': float(np.max(ts[1:])), 'repetitions': reps,
+                     'positions_per_s': B / (ms * 1e-3), 'frac_of_hbm_peak': alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      'includes_overlap_add_of_all_but_last_round': B > eng.N_CU})
     return rows
 

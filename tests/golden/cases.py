@@ -137,6 +137,17 @@ W2_RUNS = {
 }
 
 
+# ---------------------------------------------------------------- F17: config-3 depth (P = 72, 256 slices) on a small lateral object
+def depth256_inputs():
+    r = rng(41)
+    P, S, Y, X = 72, 256, 84, 84
+    obj = np.stack([3e-4 * smooth_field((Y, X, S), 7, cutoff=0.15), 1.5e-5 * smooth_field((Y, X, S), 8, cutoff=0.15)], -1)
+    pos = np.array([(0, 0), (12, 12), (-6, 5)])
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    truth = np.stack([3e-4 * smooth_field((Y, X, S), 17, cutoff=0.15), 1.5e-5 * smooth_field((Y, X, S), 18, cutoff=0.15)], -1)
+    return dict(P=P, S=S, obj=obj, pos=pos, probe=probe, truth=truth)
+
+
 # ---------------------------------------------------------------- F15: rotate_out_of_loop through the driver (E2E inputs)
 ROOL_RUNS = {
     'immediate': dict(n_epochs=2, optimizer='adam', learning_rate=1e-6),

@@ -744,6 +744,46 @@ def gen_f13():
     save('F13_beamstop', **out)
 
 
+# ----------------------------------------------------------------------------- F17 (config-3 depth: the reference's own fp32 error)
+def gen_f17():
+    """P = 72, 256 slices, far field (config 3's depth) on a small lateral object: the REFERENCE in fp64 and in fp32 on the same
+    inputs (cases.depth256_inputs).  Stored: the fp64 prediction and loss, a strided sample of the fp64 object gradient, and the
+    reference's own fp32-vs-fp64 errors (prediction, loss, gradient) -- the yardstick of the 3x rule at this depth."""
+    d = cases.depth256_inputs()
+    P, S = d['P'], d['S']
+    Y, X = d['obj'].shape[:2]
+    out = {}
+    res = {}
+    for fp64 in (True, False):
+        gs.run_fp64 = fp64
+        dt = torch.float64 if fp64 else torch.float32
+        o = torch.tensor(d['obj'], dtype=dt, requires_grad=True)
+        op, pad = U.pad_object(o, [Y, X, S], d['pos'], [P, P], unknown_type='delta_beta')
+        tiles = torch.stack([op[y + pad[0, 0]:y + pad[0, 0] + P, x + pad[1, 0]:x + pad[1, 0] + P] for y, x in d['pos']])
+        er, ei = multislice_propagate_batch(tiles, torch.tensor(d['probe'].real.copy(), dtype=dt), torch.tensor(d['probe'].imag.copy(), dtype=dt),
+                                            cases.ENERGY_EV, cases.PSIZE_CM, kernel=None, free_prop_cm='inf', obj_batch_shape=[len(d['pos']), P, P, S])
+        pred = w.norm(er, ei)
+        if fp64:
+            truth = torch.tensor(d['truth'], dtype=dt)
+            tp, tpad = U.pad_object(truth, [Y, X, S], d['pos'], [P, P], unknown_type='delta_beta')
+            tt = torch.stack([tp[y + tpad[0, 0]:y + tpad[0, 0] + P, x + tpad[1, 0]:x + tpad[1, 0] + P] for y, x in d['pos']])
+            tr, ti = multislice_propagate_batch(tt, torch.tensor(d['probe'].real.copy(), dtype=dt), torch.tensor(d['probe'].imag.copy(), dtype=dt),
+                                                cases.ENERGY_EV, cases.PSIZE_CM, kernel=None, free_prop_cm='inf', obj_batch_shape=[len(d['pos']), P, P, S])
+            out['target'] = w.norm(tr, ti).detach().numpy()
+        loss = w.mean((pred - torch.tensor(out['target'], dtype=dt)) ** 2)
+        g, = torch.autograd.grad(loss, [o])
+        res[fp64] = (pred.detach().numpy().astype(np.float64), float(loss.item()), g.numpy().astype(np.float64))
+    gs.run_fp64 = False
+    p64, l64, g64 = res[True]
+    p32, l32, g32 = res[False]
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    out.update(pred_64=p64, loss_64=np.array(l64), grad_64_sample=g64[::4, ::4, ::4].copy(), grad_64_norm=np.array(np.linalg.norm(g64)),
+               ref32_pred_err=np.array(rel(p32, p64)), ref32_loss_err=np.array(abs(l32 - l64) / abs(l64)), ref32_grad_err=np.array(rel(g32, g64)),
+               ref32_grad_sample_err=np.array(rel(g32[::4, ::4, ::4], g64[::4, ::4, ::4])))
+    print('reference fp32 vs fp64 at depth 256: pred %.2e, loss %.2e, grad %.2e' % (out['ref32_pred_err'], out['ref32_loss_err'], out['ref32_grad_err']))
+    save('F17_depth256', **out)
+
+
 # ----------------------------------------------------------------------------- F16 (reweighted L1, unknown_type='real_imag')
 def gen_f16():
     """ReweightedL1Regularizer with unknown_type='real_imag' (adorym/regularizers.py:73-82) and the weight update of the DP
@@ -798,7 +838,7 @@ def gen_f15():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f15', 'f16', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
+    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -813,3 +853,4 @@ if __name__ == '__main__':
     if 'f13' in which: gen_f13()
     if 'f15' in which: gen_f15()
     if 'f16' in which: gen_f16()
+    if 'f17' in which: gen_f17()

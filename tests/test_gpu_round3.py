@@ -210,3 +210,64 @@ def test_chased_overlap_add_is_bitwise_the_plain_one(A, ctx, P, S, B):
         assert np.array_equal(out[k][1], out[0][1])
         assert np.array_equal(out[k][2], out[0][2])
     assert np.abs(out[0][1]).max() > 0
+
+
+# ------------------------------------------------------------------------------------------------ depth 256 vs the reference's own fp32
+def test_depth_256_against_the_references_own_fp32_error(A, ctx):
+    """VERDICT r2 (weak, parity): the forward bar for S >= 32 was argued, not pinned.  Golden F17 holds the REFERENCE's fp64
+    results at config 3's depth (P = 72, 256 slices, far field) and the reference's OWN fp32-vs-fp64 errors on the same inputs
+    (prediction 1.3e-5, gradient 6.4e-4).  The kernel must be within 3x of those -- and it is inside the 5e-6 forward bar of
+    DESIGN.md section 2, i.e. closer to fp64 than the reference's fp32 path."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F17_depth256.npz'))
+    d = cases.depth256_inputs()
+    P = d['P']
+    Y, X, S = d['obj'].shape[:3]
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), d['pos'], cases.ENERGY_EV, cases.PSIZE_CM)
+    d_obj = ctx.array(d['obj'], np.float32)
+    d_grad = ctx.zeros(d['obj'].shape)
+    d_probe = ctx.array(np.stack([d['probe'].real, d['probe'].imag], -1)[None], np.float32)
+    eng.set_batch(d['pos'], g['target'].astype(np.float32))
+    eng.rotate(d_obj, None)
+    eng.multislice(d_probe, want_pred=True)
+    eng.rotate_adjoint(d_grad, None)
+    e_pred = rel(eng.pred(), g['pred_64'])
+    e_loss = abs(eng.loss() - float(g['loss_64'])) / float(g['loss_64'])
+    e_grad = rel(d_grad.get()[::4, ::4, ::4], g['grad_64_sample'])
+    print('depth 256 vs reference fp64: pred %.2e (reference fp32 %.2e), loss %.2e (%.2e), grad %.2e (%.2e)'
+          % (e_pred, float(g['ref32_pred_err']), e_loss, float(g['ref32_loss_err']), e_grad, float(g['ref32_grad_sample_err'])))
+    assert e_pred <= 3 * float(g['ref32_pred_err']) and e_pred <= 5e-6
+    assert e_loss <= 3 * float(g['ref32_loss_err'])
+    assert e_grad <= 3 * float(g['ref32_grad_sample_err'])
+
+
+@pytest.mark.parametrize('B', [300])
+def test_more_positions_than_compute_units_vs_oracle(A, ctx, B):
+    """VERDICT r2 (weak, parity): the > 256-position path (several rounds of workgroups, every round's overlap-add beside the
+    next round) had only a self-comparison.  Here: 300 positions with duplicates against the fp64 oracle -- loss, object gradient
+    and probe gradient under the 3x rule measured against the oracle's fp32 run."""
+    r = cases.rng(315)
+    Y, X, S, P = 60, 64, 4, 16
+    pos = np.stack([r.integers(-6, Y - 8, B), r.integers(-6, X - 8, B)], 1)
+    pos[B - 10:] = pos[:10]
+    obj = np.stack([r.uniform(0, 2e-3, (Y, X, S)), r.uniform(0, 2e-4, (Y, X, S))], -1)
+    probe = (0.5 + r.uniform(0, 1, (P, P))) * np.exp(1j * r.uniform(-np.pi, np.pi, (P, P)))
+    meas = np.abs(r.standard_normal((B, P, P))) * 10
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm='inf')
+    l64, _, g64, gp64 = O.forward_adjoint_object(obj, None, probe, pos, meas, phys, 'float64')
+    l32, _, g32, gp32 = O.forward_adjoint_object(obj.astype(np.float32), None, probe, pos, meas.astype(np.float32), phys, 'float32')
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
+    d_obj = ctx.array(obj, np.float32)
+    d_probe = ctx.array(np.stack([probe.real, probe.imag], -1)[None], np.float32)
+    eng.set_batch(pos, meas.astype(np.float32))
+    eng.rotate(d_obj, None, None)
+    gp = ctx.zeros(d_probe.shape)
+    eng.multislice_overlapped(d_probe, grad_probe=gp)
+    g = ctx.zeros(obj.shape)
+    eng.rotate_adjoint(g, None, None)
+    gpc = gp.get()[0, ..., 0] + 1j * gp.get()[0, ..., 1]
+    e_g, e_g32 = rel(g.get(), g64), rel(g32, g64)
+    e_p, e_p32 = np.linalg.norm(gpc - gp64) / np.linalg.norm(gp64), np.linalg.norm(np.squeeze(gp32) - np.squeeze(gp64)) / np.linalg.norm(gp64)
+    print('B=%d: grad %.2e (oracle fp32 %.2e), probe grad %.2e (%.2e)' % (B, e_g, e_g32, e_p, e_p32))
+    assert abs(eng.loss() - l64) <= 1e-5 * abs(l64)
+    assert e_g <= 3 * e_g32 + 1e-6 and e_g < 1e-4
+    assert e_p <= 3 * e_p32 + 1e-6 and e_p < 1e-4

@@ -290,6 +290,19 @@ def test_f14_world2_task_split_both_ranks():
             assert np.array_equal(np.stack(ind), g['r%d_ind_%s_64' % (rank, run)])
 
 
+# ------------------------------------------------------------------ F17: config-3 depth (P = 72, 256 slices)
+def test_f17_depth256_fp64():
+    g = load('F17_depth256')
+    d = cases.depth256_inputs()
+    phys = O.Physics((d['P'], d['P']), cases.ENERGY_EV, cases.PSIZE_CM, free_prop_cm='inf')
+    tt, _ = O.extract_tiles(d['truth'], d['pos'], (d['P'], d['P']))
+    assert rel(np.abs(O.multislice_forward(tt, d['probe'], phys, 'float64')), g['target']) < 1e-11
+    loss, pred, grad, _ = O.forward_adjoint_object(d['obj'], None, d['probe'], d['pos'], g['target'], phys, 'float64')
+    assert rel(pred, g['pred_64']) < 1e-11 and abs(loss - float(g['loss_64'])) < 1e-10 * float(g['loss_64'])
+    assert rel(grad[::4, ::4, ::4], g['grad_64_sample']) < 1e-9
+    assert abs(np.linalg.norm(grad) - float(g['grad_64_norm'])) < 1e-9 * float(g['grad_64_norm'])
+
+
 # ------------------------------------------------------------------ F15: rotate_out_of_loop through the driver
 @pytest.mark.parametrize('run', list(cases.ROOL_RUNS))
 def test_f15_rotate_out_of_loop_driver_fp64(run):
