@@ -1,0 +1,28 @@
+#!/bin/bash
+# The evidence set of a round, in one go (run on the GPU box from the repo root):  tools/profile_round.sh r03a
+#   gpurun_out/<tag>_bench.json            the default `python bench.py` line
+#   gpurun_out/<tag>_stats/                rocprofv3 --kernel-trace --stats of the headline loop (kernel averages)
+#   gpurun_out/<tag>_pmc_B32, _B256/       five --pmc passes each over tools/kbench.py (+ summary.json); traffic_latest.json refreshed
+#   gpurun_out/<tag>_timeline_*.txt        kernel timelines of the B=32 step, the per-angle step and the 16-virtual-rank step
+# Counters are collected in their own runs (no --pmc together with trace domains other than --kernel-trace).
+set -u
+TAG=${1:-r03}
+OUT=gpurun_out
+ROOT=$(pwd)
+export TMPDIR=/tmp
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-driver --no-per-angle > $ROOT/$OUT/${TAG}_stats.log 2>&1 )
+python tools/kstats.py $OUT/${TAG}_stats > $OUT/${TAG}_kernel_stats.txt 2>&1
+for B in 32 256; do
+  bash tools/pmc_sq.sh $OUT/${TAG}_pmc_B$B $B > $OUT/${TAG}_pmc_B$B.log 2>&1
+done
+python tools/traffic_update.py $OUT/${TAG}_pmc_B32 32 "profiles/${TAG}_pmc_B32.json" > $OUT/${TAG}_traffic.log 2>&1
+for LEG in none per_angle vr16; do
+  ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/${TAG}_tr_$LEG -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-driver --legs $LEG > /dev/null 2>&1 )
+  f=$(find $OUT/${TAG}_tr_$LEG -name "*kernel_trace.csv" | head -1)
+  python tools/trace_tail.py $f 40 > $OUT/${TAG}_timeline_$LEG.txt 2>&1
+done
+python tools/bench_rows.py > $OUT/${TAG}_rows.json 2>/dev/null
+python tools/bench_brief.py $OUT/${TAG}_bench.json
+cat $OUT/${TAG}_kernel_stats.txt | head -20
+cat $OUT/${TAG}_traffic.log | head -12
