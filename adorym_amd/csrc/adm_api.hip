@@ -250,8 +250,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->hs_dev = p->hfree_s_dev = p->twid_y_dev = nullptr;
     p->trans_dev = nullptr;
     p->trans_src = nullptr;
-    p->cover_ws = p->cover_pos = nullptr;
-    p->cover_batch = p->cover_row0 = p->cover_nrows = 0;
+    std::memset(p->cover_keys, 0, sizeof(p->cover_keys));
     p->chase_buf = nullptr;
     p->chase_total = 0;
     p->generic = !tuned;

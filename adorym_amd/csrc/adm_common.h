@@ -42,9 +42,9 @@ struct adm_plan {
     int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
     float2* trans_dev;     // [Z][Yp][Xp] slice transmissions of the voxels of trans_src, or nullptr (adm_plan_set_transmission_cache)
     const void* trans_src; // the obj_rot buffer trans_dev was last filled from (adm_rotate_fwd / adm_transmission_refresh)
-    const void* cover_ws;  // adm_tile_cover_build: the cover lists in this workspace are current for (cover_pos, cover_batch, window)
-    const void* cover_pos;
-    int cover_batch, cover_row0, cover_nrows;
+    // adm_tile_cover_build: the cover lists in workspace `ws` are current for (pos, batch, window); a few entries, so that every
+    // round of a batch launched in parts can have its lists built ahead
+    struct CoverKey { const void* ws; const void* pos; int batch, row0, nrows; } cover_keys[4];
     unsigned* chase_buf;   // [0] error flag (a chaser gave up waiting), [16 ...] progress counters of the chunks (lazily allocated)
     unsigned chase_total;  // workgroups that have reported to every counter so far (the counters only ever grow)
 };

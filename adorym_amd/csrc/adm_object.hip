@@ -973,6 +973,28 @@ static int tile_geom(adm_plan* plan, int batch, const int32_t* pos_host, int win
     return ADM_OK;
 }
 
+// what adm_tile_cover_build has built and nobody has used yet (a workspace holds one set of lists: a new build for the same
+// workspace replaces its entry)
+static void cover_key_put(adm_plan* plan, const void* ws, const void* pos, int batch, const TileGeom& g) {
+    int slot = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (plan->cover_keys[i].ws == ws) { slot = i; break; }
+        if (!plan->cover_keys[i].ws) slot = i;
+    }
+    plan->cover_keys[slot] = {ws, pos, batch, g.row0, g.nrows};
+}
+static bool cover_key_take(adm_plan* plan, const void* ws, const void* pos, int batch, const TileGeom& g) {
+    for (int i = 0; i < 4; ++i) {
+        adm_plan::CoverKey& k = plan->cover_keys[i];
+        if (k.ws == ws) {
+            const bool ok = k.pos == pos && k.batch == batch && k.row0 == g.row0 && k.nrows == g.nrows;
+            k.ws = nullptr;
+            return ok;
+        }
+    }
+    return false;
+}
+
 static int cover_build(adm_plan* plan, void* workspace, const int32_t* pos, int batch, const TileGeom& g) {
     char* ws = (char*)workspace;
     unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
@@ -1000,7 +1022,7 @@ extern "C" int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t work
     if (rc) return rc;
     rc = cover_build(plan, workspace, pos, batch, g);
     if (rc) return rc;
-    plan->cover_ws = workspace; plan->cover_pos = pos; plan->cover_batch = batch; plan->cover_row0 = g.row0; plan->cover_nrows = g.nrows;
+    cover_key_put(plan, workspace, pos, batch, g);
     return ADM_OK;
 }
 
@@ -1012,9 +1034,7 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     TileGeom g;
     int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
     if (rc) return rc;
-    const bool prebuilt = plan->cover_ws == workspace && plan->cover_pos == pos && plan->cover_batch == batch &&
-                          plan->cover_row0 == g.row0 && plan->cover_nrows == g.nrows;
-    plan->cover_ws = nullptr;            // one use: the position buffer may be rewritten before the next launch
+    const bool prebuilt = cover_key_take(plan, workspace, pos, batch, g);     // one use: the position buffer may be rewritten later
     if (!prebuilt) {
         rc = cover_build(plan, workspace, pos, batch, g);
         if (rc) return rc;
@@ -1068,9 +1088,7 @@ extern "C" int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_ro
     if (!armed) return adm_tile_grad_accumulate_part(plan, workspace, workspace_bytes, pos, batch, pos_host, grad_rot, win_y_lo, win_y_hi, add);
     plan->chase_total += (unsigned)batch;
     ADM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    const bool prebuilt = plan->cover_ws == workspace && plan->cover_pos == pos && plan->cover_batch == batch &&
-                          plan->cover_row0 == g.row0 && plan->cover_nrows == g.nrows;
-    plan->cover_ws = nullptr;
+    const bool prebuilt = cover_key_take(plan, workspace, pos, batch, g);
     ctx->stream = ctx->aux_stream;                        // (cover_build queues on the context's current stream)
     if (!prebuilt) rc = cover_build(plan, workspace, pos, batch, g);
     ctx->stream = ctx->main_stream;

@@ -386,6 +386,14 @@ class MultisliceEngine(object):
         for o, n in parts:
             self._check_cover(self._pos_host[o:o + n])
         chase = os.environ.get('ADM_CHASE', '0') == '1'
+        if len(parts) <= 4:
+            # the cover lists of every round only need the positions: all built now, on the side stream beside the first
+            # round, so that no round's overlap-add waits for its own list (the LAST one's build sat behind the last launch)
+            self.ctx.fork()
+            for i, (o, n) in enumerate(parts):
+                check(lib.adm_tile_cover_build(h, self._ws_parts[i].ptr, self._ws_parts[i].nbytes, self._cur_pos.ptr + 8 * o, n,
+                                               self._pos_host[o:o + n].ctypes.data, y_lo, y_hi, 1 if i else 0))
+            self.ctx.end_fork()
         for i, (o, n) in enumerate(parts):
             ws = self._ws_parts[i]
             if chase:
