@@ -250,6 +250,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->hs_dev = p->hfree_s_dev = p->twid_y_dev = nullptr;
     p->trans_dev = nullptr;
     p->trans_src = nullptr;
+    p->trans_only = false;
     std::memset(p->cover_keys, 0, sizeof(p->cover_keys));
     p->chase_buf = nullptr;
     p->chase_total = 0;
@@ -444,6 +445,9 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
     }
     // cached slice transmissions: only for the buffer they were computed from (the two-per-CU kernel evaluates in the loop)
     const bool use_t = plan->trans_dev && plan->trans_src == (const void*)obj_rot && d.unknown_type == 0 && d.binning == 1;
+    if (plan->trans_only && !use_t)
+        return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: the plan keeps slice transmissions only (cache mode 2) and this obj_rot was not "
+                                     "produced by adm_rotate_fwd on it");
     if (plan->generic) {
         if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
         if (per_position) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: per-position probes need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
@@ -456,7 +460,7 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
             ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
         return ADM_OK;
     }
-    const bool lean = plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
+    const bool lean = !plan->trans_only && plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
                       d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
     if (lean) {
         ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));

@@ -42,6 +42,7 @@ struct adm_plan {
     int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
     float2* trans_dev;     // [Z][Yp][Xp] slice transmissions of the voxels of trans_src, or nullptr (adm_plan_set_transmission_cache)
     const void* trans_src; // the obj_rot buffer trans_dev was last filled from (adm_rotate_fwd / adm_transmission_refresh)
+    bool trans_only;       // adm_plan_set_transmission_cache(plan, 2): adm_rotate_fwd writes ONLY the transmissions (obj_rot is an identity, not data)
     // adm_tile_cover_build: the cover lists in workspace `ws` are current for (pos, batch, window); a few entries, so that every
     // round of a batch launched in parts can have its lists built ahead
     struct CoverKey { const void* ws; const void* pos; int batch, row0, nrows; } cover_keys[4];

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restric
         r.x = v00.x * b.w00 + v01.x * b.w01 + v10.x * b.w10 + v11.x * b.w11;
         r.y = v00.y * b.w00 + v01.y * b.w01 + v10.y * b.w10 + v11.y * b.w11;
         const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
-        rot[o_rot] = r;
+        if (rot) rot[o_rot] = r;
         if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
     }
 }
@@ -842,8 +842,10 @@ extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* 
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
     const int y_chunk = 32;
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
-    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, (float2*)obj_rot,
-                       plan->trans_dev, d.k1, (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
+    // cache mode 2: only the transmissions are written (half the stores); obj_rot then merely names the image the cache holds
+    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords,
+                       (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot, plan->trans_dev, d.k1,
+                       (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
     ADM_HIP(hipGetLastError());
     if (plan->trans_dev) plan->trans_src = obj_rot;
     return ADM_OK;
@@ -869,8 +871,10 @@ extern "C" int adm_plan_set_transmission_cache(adm_plan* plan, int on) {
         }
         plan->trans_dev = nullptr;
         plan->trans_src = nullptr;
+        plan->trans_only = false;
         return ADM_OK;
     }
+    plan->trans_only = (on == 2);
     if (d.unknown_type != 0 || d.binning != 1)
         return fail(ADM_ERR_UNSUPPORTED, "adm_plan_set_transmission_cache: needs unknown_type delta_beta and binning 1");
     if (plan->trans_dev) return ADM_OK;

@@ -296,7 +296,7 @@ class Plan(object):
     def set_transmission_cache(self, on=True):
         """adm_rotate_fwd also stores the slice transmission of every voxel it writes and the multislice kernel multiplies
         with it instead of evaluating exp / sincos per covering position (delta_beta unknowns, binning 1; bit-identical)."""
-        check(self.ctx.lib.adm_plan_set_transmission_cache(self.handle, 1 if on else 0))
+        check(self.ctx.lib.adm_plan_set_transmission_cache(self.handle, int(on)))
 
     def workspace_bytes(self, batch):
         return int(self.ctx.lib.adm_plan_workspace_bytes(self.handle, int(batch)))

@@ -105,7 +105,7 @@ class MultisliceEngine(object):
     def __init__(self, ctx, obj_size, probe_size, probe_pos, energy_ev, psize_cm, free_prop_cm='inf', binning=1,
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
                  n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta',
-                 beamstop=None, generic=False, transmission_cache=True):
+                 beamstop=None, generic=False, transmission_cache=True, transmissions_only=False):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -138,8 +138,12 @@ class MultisliceEngine(object):
             self.plan.set_generic(True)       # the any-size kernel even where a tuned one exists (tests, A/B timing)
         # slice transmissions cached per rotated-frame voxel by rotate() (include/adm.h: adm_plan_set_transmission_cache)
         self.transmission_cache = bool(transmission_cache) and unknown_type == 'delta_beta' and binning == 1
+        # transmissions_only: rotate() stores the slice transmissions and nothing else (nobody reads the rotated (delta, beta)
+        # once the slice loop multiplies with cached numbers): half the stores of the rotation.  For callers that never look at
+        # obj_rot themselves -- the driver and bench.py; tests and tools that read it keep the default.
+        self.transmissions_only = bool(transmissions_only) and self.transmission_cache
         if self.transmission_cache:
-            self.plan.set_transmission_cache(True)
+            self.plan.set_transmission_cache(2 if self.transmissions_only else 1)
         self.unknown_type = unknown_type
         self.loss_function_type = loss_function_type
         self.pads = pads

@@ -415,7 +415,9 @@ def reconstruct_ptychography(
                                   binning=binning, fresnel_approx=fresnel_approx, sign_convention=sign_convention,
                                   normalize_fft=normalize_fft, kernel=h, scale_ri_by_k=scale_ri_by_k, n_probe_modes=n_probe_modes,
                                   max_batch=minibatch_size, loss_function_type=loss_function_type,
-                                  poisson_multiplier=poisson_multiplier, unknown_type=unknown_type, beamstop=beamstop)
+                                  poisson_multiplier=poisson_multiplier, unknown_type=unknown_type, beamstop=beamstop,
+                                  # the rotation stores slice transmissions only; rotate_out_of_loop and plugin models read obj_rot
+                                  transmissions_only=(forward_model == 'auto' and not rotate_out_of_loop))
 
     # rotation lookup tables: computed like save_rotation_lookup (util.py:492-516), cached on the device per angle
     # (the reference caches them as .npy files in ./arrsize_*; no files are written here)

@@ -402,7 +402,7 @@ def main():
     Y, X, Z = cfg['obj_size']
     Py, Px = cfg['probe_size']
     eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'],
-                             free_prop_cm=cfg['free_prop_cm'], binning=cfg['binning'], max_batch=B)
+                             free_prop_cm=cfg['free_prop_cm'], binning=cfg['binning'], max_batch=B, transmissions_only=True)
     ops = HipOps(ctx)
     state = DataParallelObject(ops, comm, (Y, X, Z, 2))
     # reference-default Gaussian random initial guess (throughput is data independent)
@@ -451,7 +451,7 @@ def main():
         targets[key] = t
     truth.free()
     ctx.sync()
-    eng.plan.set_transmission_cache(eng.transmission_cache)
+    eng.plan.set_transmission_cache(2 if eng.transmissions_only else eng.transmission_cache)
 
     opt_options = {'step_size': cfg['learning_rate']}
     # two sets of timing events / loss read-backs: step k's results are looked at after step k+1 has been queued, so the

@@ -232,7 +232,10 @@ int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch);
  * last filled from; a caller that writes obj_rot by any other route than adm_rotate_fwd must call adm_transmission_refresh
  * for the rows [y_lo, y_hi) (object coordinates) it changed.  One rotated-object buffer per plan while the cache is on: the
  * cache has a single image, so alternating PARTIAL-row rotations between two obj_rot buffers would leave rows of one beside
- * rows of the other.  Off by default at this level; adorym_amd's engine (one obj_rot per plan) turns it on. */
+ * rows of the other.  Off by default at this level; adorym_amd's engine (one obj_rot per plan) turns it on.
+ * on = 2: the cache REPLACES the rotated object -- adm_rotate_fwd writes the transmissions only (half the stores of the rotation:
+ * nobody reads the rotated (delta, beta) once the slice loop multiplies with cached numbers) and obj_rot is just the name of the
+ * image the cache holds; adm_multislice_fwd_adj then refuses an obj_rot the cache was not filled from. */
 int adm_plan_set_transmission_cache(adm_plan* plan, int on);
 int adm_transmission_refresh(adm_plan* plan, const float* obj_rot, int y_lo, int y_hi);
 /* Probe sizes.  Any Py x Px with Py*Px <= 16384 whose field fits the LDS is accepted (the reference takes whatever

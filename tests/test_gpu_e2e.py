@@ -77,7 +77,7 @@ def test_probe_optimisation_runs_and_reduces_loss(tmp_path):
 
 
 def test_unsupported_options_raise(tmp_path):
-    for bad in (dict(distribution_mode='shared_file'), dict(unknown_type='real_imag', reweighted_l1=True, alpha_d=1e-3), dict(optimizer='cg'),
+    for bad in (dict(distribution_mode='shared_file'), dict(optimizer='cg'), dict(multiscale_level=2),
                 dict(optimize_probe_pos_offset=True), dict(optimize_probe_defocusing=True), dict(cpu_only=True)):
         with pytest.raises(NotImplementedError):
             run(tmp_path, n_epochs=1, **bad)

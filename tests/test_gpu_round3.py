@@ -272,3 +272,28 @@ def test_more_positions_than_compute_units_vs_oracle(A, ctx, B):
     assert abs(eng.loss() - l64) <= 1e-5 * abs(l64)
     assert e_g <= 3 * e_g32 + 1e-6 and e_g < 1e-4
     assert e_p <= 3 * e_p32 + 1e-6 and e_p < 1e-4
+
+
+def test_transmissions_only_rotation_is_bitwise_the_default(A, ctx):
+    """adm_plan_set_transmission_cache(plan, 2): the rotation stores the slice transmissions only (the driver's and bench.py's
+    mode: nobody reads the rotated (delta, beta) once the slice loop multiplies with cached numbers).  Loss, prediction and
+    gradient are bit for bit the default mode's; an obj_rot the cache was not filled from is refused instead of read."""
+    r = cases.rng(88)
+    N, P, S, theta = 40, 16, 12, 0.6
+    obj = np.stack([r.uniform(0, 2e-3, (N, N, S)), r.uniform(0, 2e-4, (N, N, S))], -1).astype(np.float32)
+    pos = np.array([(-3, -2), (4, 6), (10, 12), (13, 5), (20, 22)])
+    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
+    meas = (np.abs(r.standard_normal((len(pos), P, P))) * 5).astype(np.float32)
+    out = []
+    for only in (False, True):
+        eng = A.MultisliceEngine(ctx, (N, N, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, transmissions_only=only)
+        tab = A.RotationTable(ctx, (N, N, S), np.float32(theta))
+        g = ctx.zeros(obj.shape)
+        loss = eng.loss_and_grad(ctx.array(obj), g, tab, probe, pos, meas)
+        out.append((loss, g.get()))
+        if only:
+            other = ctx.zeros(eng.plan.rot_shape)
+            with pytest.raises(ValueError):
+                A._lib.check(ctx.lib.adm_multislice_fwd_adj(eng.plan.handle, other.ptr, probe.ptr, eng._cur_pos.ptr, len(pos), eng._cur_target.ptr,
+                                                            0, None, None, eng._loss.ptr, 1.0, eng._ws.ptr, eng._ws.nbytes))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
