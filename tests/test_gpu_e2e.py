@@ -102,7 +102,8 @@ def test_checkpoint_files_and_resume(tmp_path):
     kw = dict(optimizer='adam', learning_rate=1e-6, store_checkpoint=True, n_batch_per_checkpoint=4)
     g, inp, full = run(tmp_path / 'a', n_epochs=2, **kw)
     ck = os.path.join(full['output_folder'], 'checkpoint')
-    assert sorted(os.listdir(ck)) == ['checkpoint.txt', 'obj_checkpoint.npy', 'opt_obj_params_checkpoint.npy', 'params_0']
+    # (stamp_rank_0.txt: this build's torn-save detector, beside the reference's files)
+    assert sorted(os.listdir(ck)) == ['checkpoint.txt', 'obj_checkpoint.npy', 'opt_obj_params_checkpoint.npy', 'params_0', 'stamp_rank_0.txt']
     assert np.load(os.path.join(ck, 'obj_checkpoint.npy')).shape == (32, 32, 32, 2)
     assert np.load(os.path.join(ck, 'opt_obj_params_checkpoint.npy')).shape == (2, 32, 32, 32, 2)
     assert [int(v) for v in np.loadtxt(os.path.join(ck, 'checkpoint.txt'))] == [1, 8]
