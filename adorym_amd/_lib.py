@@ -99,6 +99,7 @@ SIGNATURES = {
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_reg_grad_set': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
+    'adm_rotate_fwd_pending_adam': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _I, _VP, _VP, _VP, _I, _I]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
     'adm_momentum_step': (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _D, _D, _I, _VP]),
     'adm_rwl1_update': (_I, [_VP, _VP, _VP, _VP]),

@@ -730,23 +730,73 @@ __device__ __forceinline__ float constrain(float xv, size_t i, int flags, const 
     return xv;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, size_t lo, size_t hi, float step, float b1, float b2,
-                                                   float omb1, float omb2, float q1, float q2, float eps, int flags,
-                                                   const float* __restrict__ mask) {
+struct AdamScalars {
+    float step, b1, b2, omb1, omb2, q1, q2, eps;
+    int flags;
+    const float* mask;
+};
+
+// one element of AdamOptimizer.apply_gradient + constraints; shared by adam_kernel and the rotation that applies a PENDING
+// update on the fly (rotate_fwd_pending_kernel), with contraction off so that both produce the same bits
+__device__ __forceinline__ float adam_value(float xv, float gv, float m_in, float v_in, const AdamScalars& a, size_t i, float& m_out,
+                                            float& v_out) {
 #pragma clang fp contract(off)
+    float mv = a.b1 * m_in;
+    mv = mv + a.omb1 * gv;
+    float vv = a.b2 * v_in;
+    vv = vv + a.omb2 * (gv * gv);
+    const float mhat = mv / a.q1;
+    const float vhat = vv / a.q2;
+    const float d = a.step * mhat / (sqrtf(vhat) + a.eps);
+    m_out = mv;
+    v_out = vv;
+    return constrain(xv - d, i, a.flags, a.mask);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t lo, size_t hi, AdamScalars a) {
     for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
-        const float gv = g[i];
-        float mv = b1 * m[i];
-        mv = mv + omb1 * gv;
-        float vv = b2 * v[i];
-        vv = vv + omb2 * (gv * gv);
-        const float mhat = mv / q1;
-        const float vhat = vv / q2;
-        const float d = step * mhat / (sqrtf(vhat) + eps);
+        float mv, vv;
+        const float xn = adam_value(x[i], g[i], m[i], v[i], a, i, mv, vv);
         m[i] = mv;
         v[i] = vv;
-        x[i] = constrain(x[i] - d, i, flags, mask);
+        x[i] = xn;
+    }
+}
+
+// adm_rotate_fwd for an object whose Adam update is still PENDING: every gathered voxel is first updated on the fly from
+// (x, g, m, v) -- the value adam_kernel will store later -- and nothing is written back.  Takes the optimiser launch (and the gap
+// around it) off the chain between the back-rotation and the next multislice launch: the update proper then runs on the side
+// stream, beside that launch.
+__global__ __launch_bounds__(256) void rotate_fwd_pending_kernel(const float2* __restrict__ obj, const float2* __restrict__ grad,
+                                                                 const float2* __restrict__ mom, const float2* __restrict__ vel,
+                                                                 AdamScalars a, const uint16_t* __restrict__ coords,
+                                                                 float2* __restrict__ rot, float2* __restrict__ trans, float k1, float sigma,
+                                                                 RotGeom g, int y_lo, int y_hi, int y_chunk) {
+    const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (xr >= g.X || zr >= g.Z) return;
+    const Bilin b = make_bilin(coords, xr, zr, g.X, g.Z);
+    const int ya = y_lo + blockIdx.z * y_chunk;
+    const int yb = min(ya + y_chunk, y_hi);
+    const size_t plane = (size_t)g.X * g.Z;
+    const int idx[4] = {b.i00, b.i01, b.i10, b.i11};
+    for (int y = ya; y < yb; ++y) {
+        float2 val[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t e = (size_t)y * plane + idx[q];
+            const float2 xv = obj[e], gv = grad[e], mv = mom[e], vv = vel[e];
+            float mo, vo;
+            val[q].x = adam_value(xv.x, gv.x, mv.x, vv.x, a, 2 * e, mo, vo);
+            val[q].y = adam_value(xv.y, gv.y, mv.y, vv.y, a, 2 * e + 1, mo, vo);
+        }
+        float2 r;
+        r.x = val[0].x * b.w00 + val[1].x * b.w01 + val[2].x * b.w10 + val[3].x * b.w11;
+        r.y = val[0].y * b.w00 + val[1].y * b.w01 + val[2].y * b.w10 + val[3].y * b.w11;
+        const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
+        if (rot) rot[o_rot] = r;
+        if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
     }
 }
 
@@ -1183,19 +1233,44 @@ extern "C" int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols
     return ADM_OK;
 }
 
+static AdamScalars adam_scalars(int i_batch, double step_size, double b1, double b2, double eps, int flags, const float* mask) {
+    // the reference evaluates the scalars in Python doubles and torch casts them to fp32 at the op
+    AdamScalars a;
+    double p1 = 1.0, p2 = 1.0;
+    for (int k = 0; k < i_batch + 1; ++k) { p1 *= b1; p2 *= b2; }
+    a.step = (float)step_size; a.b1 = (float)b1; a.b2 = (float)b2;
+    a.omb1 = (float)(1.0 - b1); a.omb2 = (float)(1.0 - b2);
+    a.q1 = (float)(1.0 - p1); a.q2 = (float)(1.0 - p2);
+    a.eps = (float)eps; a.flags = flags; a.mask = mask;
+    return a;
+}
+
 extern "C" int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
                              double step_size, double b1, double b2, double eps, int flags, const float* mask) {
     if (!ctx || !x || !g || !m || !v) return fail(ADM_ERR_INVALID, "adm_adam_step: null argument");
     if (hi <= lo) return ADM_OK;
-    // the reference evaluates the scalars in Python doubles and torch casts them to fp32 at the op
-    const double b1d = b1, b2d = b2;
-    const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
-    double p1 = 1.0, p2 = 1.0;
-    for (int k = 0; k < i_batch + 1; ++k) { p1 *= b1d; p2 *= b2d; }
-    const float q1 = (float)(1.0 - p1), q2 = (float)(1.0 - p2);
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi, (float)step_size,
-                       (float)b1, (float)b2, omb1, omb2, q1, q2, (float)eps, flags, mask);
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi,
+                       adam_scalars(i_batch, step_size, b1, b2, eps, flags, mask));
     ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_fwd_pending_adam(adm_plan* plan, const float* obj, const float* grad, const float* m, const float* v, int i_batch,
+                                           double step_size, double b1, double b2, double eps, int flags, const float* mask,
+                                           const uint16_t* coords, float* obj_rot, int y_lo, int y_hi) {
+    if (!plan || !obj || !grad || !m || !v || !obj_rot) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_pending_adam: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_pending_adam: bad y range");
+    if (y_lo == y_hi) return ADM_OK;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    const int y_chunk = 32;
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
+    hipLaunchKernelGGL(rotate_fwd_pending_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, (const float2*)grad,
+                       (const float2*)m, (const float2*)v, adam_scalars(i_batch, step_size, b1, b2, eps, flags, mask), coords,
+                       (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot, plan->trans_dev, d.k1,
+                       (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    if (plan->trans_dev) plan->trans_src = obj_rot;
     return ADM_OK;
 }
 

@@ -269,7 +269,8 @@ class PtychographyModel(ForwardModel):
         if not (rool and obj is getattr(self, 'arr_rot', None)):
             # (rotate_out_of_loop: ``obj`` IS the rotated object; the driver hands over arr_rot, whose slice-major twin the
             # engine already holds from rotate_outside(); any other array is loaded as it is, coords = None)
-            eng.rotate(obj, coords, yr)
+            pend = self.pending_update() if getattr(self, 'pending_update', None) is not None else None
+            eng.rotate(obj, coords, yr, pending=pend)
         ctx.fork()
         eng.flush_loss_copy()       # the previous minibatch's loss read-back: on the side stream, beside this kernel
         if side_hook is not None:

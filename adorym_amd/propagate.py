@@ -205,11 +205,19 @@ class MultisliceEngine(object):
         return lo, max(lo, hi)
 
     # -------------------------------------------------------------------------------- stages
-    def rotate(self, obj, coords, y_range=None):
-        """obj: DeviceArray [Y,X,Z,2]; coords: DeviceArray uint16 [X*Z,2] or None (no rotation)."""
+    def rotate(self, obj, coords, y_range=None, pending=None):
+        """obj: DeviceArray [Y,X,Z,2]; coords: DeviceArray uint16 [X*Z,2] or None (no rotation).
+        ``pending`` = DataParallelObject.pending_update(): an Adam update of ``obj`` that has not been applied yet is applied on
+        the fly to every gathered voxel (adm_rotate_fwd_pending_adam; obj itself is left as it is)."""
         lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
-        check(self.ctx.lib.adm_rotate_fwd(self.plan.handle, obj.ptr, coords.ptr if coords is not None else None,
-                                          self.obj_rot.ptr, lo, hi))
+        cp = coords.ptr if coords is not None else None
+        if pending is not None:
+            g, m, v, i_batch, step, b1, b2, eps, flags, mask = pending
+            check(self.ctx.lib.adm_rotate_fwd_pending_adam(self.plan.handle, obj.ptr, g.ptr, m.ptr, v.ptr, i_batch, float(step), float(b1),
+                                                           float(b2), float(eps), flags, mask.ptr if mask is not None else None, cp,
+                                                           self.obj_rot.ptr, lo, hi))
+            return
+        check(self.ctx.lib.adm_rotate_fwd(self.plan.handle, obj.ptr, cp, self.obj_rot.ptr, lo, hi))
 
     def rotate_adjoint(self, grad_obj, coords, y_range=None):
         """grad_obj += R^T grad_rot.  With a RotationTable the deterministic CSR gather is used; with a bare

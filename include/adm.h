@@ -328,6 +328,14 @@ int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b,
 #define ADM_FLAG_ZERO_CH1 4
 int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
                   double step_size, double b1, double b2, double eps, int flags, const float* mask);
+/* adm_rotate_fwd of an object whose Adam update is still PENDING: every gathered voxel is updated on the fly from (obj, grad, m, v)
+ * with adm_adam_step's arithmetic (same bits: one shared device function, contraction off) and nothing is written back; m, v and
+ * mask are indexed like obj (whole arrays).  The optimiser launch proper can then run later -- on the side stream, beside the
+ * multislice launch -- instead of between the back-rotation and the rotation of the next minibatch: adm_adam_step +
+ * adm_rotate_fwd (adorym/optimizers.py:309-318 + adorym/util.py:536-552) with one launch and one dependency gap less on the chain. */
+int adm_rotate_fwd_pending_adam(adm_plan* plan, const float* obj, const float* grad, const float* m, const float* v, int i_batch,
+                                double step_size, double b1, double b2, double eps, int flags, const float* mask,
+                                const uint16_t* coords, float* obj_rot, int y_lo, int y_hi);
 /* GDOptimizer.apply_gradient (adorym/optimizers.py:440-464); step_size already scheduled by the host */
 int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, double step_size, int flags,
                 const float* mask);

@@ -297,3 +297,24 @@ def test_transmissions_only_rotation_is_bitwise_the_default(A, ctx):
                 A._lib.check(ctx.lib.adm_multislice_fwd_adj(eng.plan.handle, other.ptr, probe.ptr, eng._cur_pos.ptr, len(pos), eng._cur_target.ptr,
                                                             0, None, None, eng._loss.ptr, 1.0, eng._ws.ptr, eng._ws.nbytes))
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize('extra', [dict(), dict(update_scheme='per angle'), dict(non_negativity=True, learning_rate=1e-5),
+                                   dict(gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)])
+def test_pending_update_rotation_is_bitwise_the_separate_optimiser_launch(tmp_path, extra):
+    """One rank, Adam: at the end of a minibatch the update stays PENDING; the next rotation applies it on the fly to the voxels
+    it gathers (adm_rotate_fwd_pending_adam) and the optimiser launch proper runs on the side stream beside the next multislice
+    launch.  One shared device function with contraction off: the driver's result equals the ADM_PENDING_ROTATION=0 run (optimiser
+    launch between back-rotation and rotation) bit for bit -- object, losses."""
+    out = []
+    for mode in ('0', '1'):
+        os.environ['ADM_PENDING_ROTATION'] = mode
+        try:
+            kw = dict(n_epochs=2, optimizer='adam', learning_rate=1e-6)
+            kw.update(extra)
+            _, st = _driver(tmp_path / mode, **kw)
+        finally:
+            os.environ.pop('ADM_PENDING_ROTATION', None)
+        out.append(st)
+    assert np.array_equal(out[0]['delta'], out[1]['delta']) and np.array_equal(out[0]['beta'], out[1]['beta'])
+    assert out[0]['losses'] == out[1]['losses']
