@@ -29,6 +29,12 @@ class HoloDesc(C.Structure):
                 ('unknown_type', C.c_int32), ('raw_intensity', C.c_int32), ('k1', C.c_float)]
 
 
+class SmallParam(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_uint64), ('step_size', C.c_double),
+                ('center_cols', C.c_int32), ('zero_grad', C.c_int32), ('pin', C.c_void_p), ('pin_n', C.c_uint64)]
+
+
+SMALL_PARAMS_MAX = 6
 _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol include/adm.h declares
@@ -100,6 +106,7 @@ SIGNATURES = {
     'adm_reg_grad_set': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
     'adm_rotate_fwd_pending_adam': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _I, _VP, _VP, _VP, _I, _I]),
+    'adm_adam_step_small': (_I, [_VP, C.POINTER(SmallParam), _I, _I, _D, _D, _D]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
     'adm_momentum_step': (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _D, _D, _I, _VP]),
     'adm_rwl1_update': (_I, [_VP, _VP, _VP, _VP]),

@@ -2,6 +2,7 @@
 // fused Adam / GD + constraints (R13-R15), axpy.  All HBM-bound streaming kernels.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_fp16.h>
 #include "adm_common.h"
 #include "adm_ms_math.h"
@@ -697,9 +698,8 @@ __global__ __launch_bounds__(256) void reg_grad_ri_weighted_kernel(const float2*
 }
 
 // x[r][c] -= mean_r x[r][c]   (adorym/optimizers.py:1046-1048), one workgroup
-__global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x, size_t n_rows, int n_cols) {
-    __shared__ float red[4];
-    __shared__ float mean;
+// body of center_rows_kernel for one workgroup of 256 threads (also the tail of small_adam_kernel: same sums, same bits)
+__device__ __forceinline__ void center_rows_block(float* __restrict__ x, size_t n_rows, int n_cols, float* red, float* mean) {
     for (int c = 0; c < n_cols; ++c) {
         float acc = 0.f;
         for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) acc += x[r * n_cols + c];
@@ -707,12 +707,18 @@ __global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x,
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) mean = (red[0] + red[1] + red[2] + red[3]) / (float)n_rows;
+        if (threadIdx.x == 0) *mean = (red[0] + red[1] + red[2] + red[3]) / (float)n_rows;
         __syncthreads();
-        const float mu = mean;
+        const float mu = *mean;
         for (size_t r = threadIdx.x; r < n_rows; r += blockDim.x) x[r * n_cols + c] -= mu;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x, size_t n_rows, int n_cols) {
+    __shared__ float red[4];
+    __shared__ float mean;
+    center_rows_block(x, n_rows, n_cols, red, &mean);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -797,6 +803,33 @@ __global__ __launch_bounds__(256) void rotate_fwd_pending_kernel(const float2* _
         const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
         if (rot) rot[o_rot] = r;
         if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
+    }
+}
+
+// The small optimisable parameters of a minibatch (probe modes, sub-pixel position corrections, propagation distances, affine
+// matrices: KBs each) updated in ONE launch, one workgroup per array: Adam with adam_kernel's arithmetic, then -- per array, as
+// asked -- the drift guard of the position corrections (center_rows_kernel's sums), the pin of the first entries to fixed values,
+// and the zero fill of the gradient accumulator for the next minibatch.  These paths are launch-bound (4-5 us per launch whatever
+// its size): config-5 shape 24 -> 17 launches per minibatch, config-1 shape 17 -> 10.
+struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; };
+
+__global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamScalars a) {
+    __shared__ float red[4];
+    __shared__ float mean;
+    const adm_small_param q = sp.p[blockIdx.x];
+    a.step = (float)q.step_size;
+    for (size_t i = threadIdx.x; i < q.n; i += blockDim.x) {
+        float mv, vv;
+        const float xn = adam_value(q.x[i], q.g[i], q.m[i], q.v[i], a, i, mv, vv);
+        q.m[i] = mv;
+        q.v[i] = vv;
+        q.x[i] = xn;
+        if (q.zero_grad) q.g[i] = 0.f;
+    }
+    __syncthreads();
+    if (q.center_cols > 0) center_rows_block(q.x, q.n / (size_t)q.center_cols, q.center_cols, red, &mean);
+    if (q.pin) {
+        for (size_t i = threadIdx.x; i < q.pin_n; i += blockDim.x) q.x[i] = q.pin[i];
     }
 }
 
@@ -1251,6 +1284,24 @@ extern "C" int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, f
     if (hi <= lo) return ADM_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(hi - lo)), dim3(256), 0, ctx->stream, x, g, m, v, lo, hi,
                        adam_scalars(i_batch, step_size, b1, b2, eps, flags, mask));
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, int count, int i_batch, double b1, double b2, double eps) {
+    if (!ctx || !params) return fail(ADM_ERR_INVALID, "adm_adam_step_small: null argument");
+    if (count <= 0) return ADM_OK;
+    if (count > ADM_SMALL_PARAMS_MAX) return fail(ADM_ERR_INVALID, "adm_adam_step_small: too many arrays in one call");
+    SmallParams sp;
+    std::memset(&sp, 0, sizeof(sp));
+    for (int k = 0; k < count; ++k) {
+        const adm_small_param& q = params[k];
+        if (!q.x || !q.g || !q.m || !q.v) return fail(ADM_ERR_INVALID, "adm_adam_step_small: null array");
+        if (q.center_cols > 0 && q.n % (uint64_t)q.center_cols) return fail(ADM_ERR_INVALID, "adm_adam_step_small: n is not a multiple of center_cols");
+        if (q.pin && q.pin_n > q.n) return fail(ADM_ERR_INVALID, "adm_adam_step_small: pin_n exceeds n");
+        sp.p[k] = q;
+    }
+    hipLaunchKernelGGL(small_adam_kernel, dim3(count), dim3(256), 0, ctx->stream, sp, adam_scalars(i_batch, 0.0, b1, b2, eps, 0, nullptr));
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

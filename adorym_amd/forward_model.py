@@ -562,8 +562,10 @@ class MultiDistModel(PtychographyModel):
                 self._ga = self.device.empty((nd, 2, 3))
             grads['affine'] = self._ga.zero_()
         self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=True, grad_obj=grad_obj, grads=grads)
-        reg = self._regularize(obj, grad_obj)
-        self.current_loss = float(self.holo.loss() + reg)
+        # loss and regulariser value are read back lazily (the driver looks at them after the next minibatch has been queued)
+        regv = self._reg_value_async(self._regularize_launch(obj, grad_obj))
+        datav = self.holo.loss_async()
+        self._loss_thunk = lambda: datav() + regv()
         out = []
         for i in opt_args_ls:
             if i == 0:

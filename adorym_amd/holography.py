@@ -52,5 +52,24 @@ class HolographyEngine(object):
         """mean over (distance, pixel) of the squared residual -- blocks."""
         return float(self._loss.get().astype(np.float64).sum() / (self.n_dists * self.ny * self.nx))
 
+    def loss_async(self):
+        """Queue the read-back of the per-distance sums (pinned memory + event) and return a callable that gives the loss: the
+        host does not wait, the driver resolves it after the next minibatch has been queued."""
+        from .device import PinnedArray, Event
+        if getattr(self, '_pinned', None) is None:
+            self._pinned = [PinnedArray(self.ctx, (self.n_dists,)) for _ in range(2)]
+            self._events = [Event(self.ctx) for _ in range(2)]
+            self._slot = 0
+        self._slot ^= 1
+        k = self._slot
+        self._pinned[k].copy_from_async(self._loss, 4 * self.n_dists)
+        self._events[k].record()
+        norm = float(self.n_dists * self.ny * self.nx)
+
+        def value():
+            self._events[k].synchronize()
+            return float(self._pinned[k].array[:self.n_dists].astype(np.float64).sum() / norm)
+        return value
+
     def pred(self):
         return self._pred.get()

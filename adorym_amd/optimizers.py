@@ -124,6 +124,42 @@ class MomentumOptimizer(Optimizer):
         return x
 
 
+def apply_small_params(ctx, items, i_batch):
+    """The small optimisable parameters of one minibatch (adorym/optimizers.py:1022-1083: probe, probe_pos_correction,
+    free_prop_cm, prj_affine_ls) in ONE launch (adm_adam_step_small) when every one of them is driven by a plain AdamOptimizer with
+    the same (b1, b2, eps); otherwise one by one through the optimisers' own apply_gradient.  ``items``: dicts with
+    opt, x, g (DeviceArrays), and optionally center_cols (drift guard, :1046-1048), pin (DeviceArray copied over the first
+    entries of x, :1067-1073), zero_grad (the gradient accumulator is zero-filled once used).  Same arithmetic either way."""
+    import ctypes as C
+    from ._lib import SmallParam, SMALL_PARAMS_MAX
+    if not items:
+        return
+    keys = {(float(it['opt'].options_dict.get('b1', 0.9)), float(it['opt'].options_dict.get('b2', 0.999)),
+             float(it['opt'].options_dict.get('eps', 1e-7))) for it in items}
+    plain = all(type(it['opt']) is AdamOptimizer and set(it['opt'].options_dict) <= {'step_size', 'b1', 'b2', 'eps'} for it in items)
+    if plain and len(keys) == 1 and len(items) <= SMALL_PARAMS_MAX:
+        arr = (SmallParam * len(items))()
+        for k, it in enumerate(items):
+            o = it['opt']
+            pin = it.get('pin')
+            arr[k] = SmallParam(x=it['x'].ptr, g=it['g'].ptr, m=o.params_whole_array_dict['m'].ptr, v=o.params_whole_array_dict['v'].ptr,
+                                n=it['x'].size, step_size=float(o.options_dict.get('step_size', 0.001)),
+                                center_cols=int(it.get('center_cols', 0)), zero_grad=1 if it.get('zero_grad') else 0,
+                                pin=pin.ptr if pin is not None else None, pin_n=pin.size if pin is not None else 0)
+            o.i_batch += 1
+        b1, b2, eps = next(iter(keys))
+        check(ctx.lib.adm_adam_step_small(ctx.handle, arr, len(items), int(i_batch), b1, b2, eps))
+        return
+    for it in items:
+        it['opt'].apply_gradient(it['x'], it['g'], i_batch, **it['opt'].options_dict)
+        if it.get('center_cols'):
+            check(ctx.lib.adm_center_rows(ctx.handle, it['x'].ptr, it['x'].size // it['center_cols'], it['center_cols']))
+        if it.get('pin') is not None:
+            check(ctx.lib.adm_d2d(ctx.handle, it['x'].ptr, it['pin'].ptr, it['pin'].nbytes))
+        if it.get('zero_grad'):
+            it['g'].zero_()
+
+
 def _unsupported(name):
     class _U(Optimizer):
         def __init__(self, *a, **k):

@@ -32,7 +32,7 @@ from .device import Context
 from .differentiator import Differentiator
 from .dp import DataParallelObject, HipOps, constraint_flags
 from .forward_model import ForwardModel, PtychographyModel, MultiDistModel
-from .optimizers import Optimizer, AdamOptimizer, GDOptimizer, MomentumOptimizer
+from .optimizers import Optimizer, AdamOptimizer, GDOptimizer, MomentumOptimizer, apply_small_params
 from .propagate import MultisliceEngine, RotationTable, get_kernel
 from .regularizers import L1Regularizer, TVRegularizer, ReweightedL1Regularizer
 from .util import rotation_lookup, split_tasks, initialize_probe
@@ -736,6 +736,7 @@ def reconstruct_ptychography(
         initialize_gradients = True
         pending_ind = []
         current_i_theta = -1                                         # (:855)
+        zeroed_by_update = set()
 
         for i_batch in range(starting_batch, n_batch):
             starting_batch = 0
@@ -807,14 +808,16 @@ def reconstruct_ptychography(
                     side_hook, init_grad = state.finish_update, True
                 else:
                     state.zero_grad()
-                if optimize_probe:
+                # (an accumulator that the last small-parameter update consumed was zero-filled by that launch)
+                if optimize_probe and id(probe_grad_dev) not in zeroed_by_update:
                     probe_grad_dev.zero_()
-                if optimize_all_probe_pos:
+                if optimize_all_probe_pos and id(pos_grad_dev) not in zeroed_by_update:
                     pos_grad_dev.zero_()
-                if opt_free_prop is not None:
+                if opt_free_prop is not None and id(free_prop_grad_dev) not in zeroed_by_update:
                     free_prop_grad_dev.zero_()
-                if opt_prj_affine is not None:
+                if opt_prj_affine is not None and id(affine_grad_dev) not in zeroed_by_update:
                     affine_grad_dev.zero_()
+                zeroed_by_update = set()
             grad_func_args = {}
             for arg in forward_model.argument_ls:
                 if arg == 'obj':
@@ -884,37 +887,33 @@ def reconstruct_ptychography(
                     opt.apply_gradient(obj.arr, gradient, i_opt_batch, flags=flags, mask=mask.mask if mask is not None else None,
                                        **opt.options_dict)
 
-            # ---- probe (optimizers.py:1022-1032) ----
+            # ---- the small parameters (optimizers.py:1022-1083): probe, sub-pixel positions, propagation distances, affine
+            # registration.  Gradients are summed over the ranks on the device, then ONE launch updates them all (per-array
+            # Adam, the drift guard of the positions, the identity pin of affine matrix 0, and the zero fill of the accumulators
+            # for the next minibatch); custom optimiser objects fall back to their own apply_gradient ----
+            small = []
+            i_global = i_batch + i_epoch * n_batch
             if optimize_probe:
-                if probe_update_delay <= i_batch + i_epoch * n_batch < probe_update_limit:
-                    if n_ranks > 1:
-                        comm.all_reduce_device(probe_grad_dev)
-                    opt_probe.apply_gradient(probe_dev, probe_grad_dev, i_opt_batch, **opt_probe.options_dict)
+                if probe_update_delay <= i_global < probe_update_limit:
+                    small.append(dict(opt=opt_probe, x=probe_dev, g=probe_grad_dev, zero_grad=True))
                 else:
                     print_flush('  Probe is not updated because current batch is out of the specified range ({}, {}).'.format(
                         probe_update_delay, probe_update_limit), 0, rank, **stdout_options)
-
-            # ---- sub-pixel probe positions (optimizers.py:1037-1049) ----
-            if optimize_all_probe_pos and i_batch + i_epoch * n_batch >= other_params_update_delay:
-                corr_dev = optimizable_params['probe_pos_correction']
-                if n_ranks > 1:
-                    comm.all_reduce_device(pos_grad_dev)
-                opt_probe_pos.apply_gradient(corr_dev, pos_grad_dev, i_opt_batch, **opt_probe_pos.options_dict)
-                # prevent position drifting: subtract the mean over (theta, position)
-                _lib.check(ctx.lib.adm_center_rows(ctx.handle, corr_dev.ptr, corr_dev.size // 2, 2))
-
-            # ---- propagation distances and affine registration (optimizers.py:1062-1083) ----
-            if (opt_free_prop is not None or opt_prj_affine is not None) and i_batch + i_epoch * n_batch >= other_params_update_delay:
-                for o_, g_, name_ in ((opt_free_prop, 'free_prop_grad_dev', 'free_prop_cm'), (opt_prj_affine, 'affine_grad_dev', 'prj_affine_ls')):
-                    if o_ is None:
-                        continue
-                    gdev = free_prop_grad_dev if name_ == 'free_prop_cm' else affine_grad_dev
-                    if n_ranks > 1:
-                        comm.all_reduce_device(gdev)
-                    o_.apply_gradient(optimizable_params[name_], gdev, i_opt_batch, **o_.options_dict)
+            if i_global >= other_params_update_delay:
+                if optimize_all_probe_pos:
+                    # (+ "prevent position drifting": subtract the mean over (theta, position))
+                    small.append(dict(opt=opt_probe_pos, x=optimizable_params['probe_pos_correction'], g=pos_grad_dev, center_cols=2, zero_grad=True))
+                if opt_free_prop is not None:
+                    small.append(dict(opt=opt_free_prop, x=optimizable_params['free_prop_cm'], g=free_prop_grad_dev, zero_grad=True))
                 if opt_prj_affine is not None:
-                    # "regularize transformation of image 0": matrix 0 is pinned to the identity
-                    _lib.check(ctx.lib.adm_d2d(ctx.handle, optimizable_params['prj_affine_ls'].ptr, affine_identity_dev.ptr, 6 * 4))
+                    # (+ "regularize transformation of image 0": matrix 0 is pinned to the identity)
+                    small.append(dict(opt=opt_prj_affine, x=optimizable_params['prj_affine_ls'], g=affine_grad_dev, pin=affine_identity_dev,
+                                      zero_grad=True))
+            if n_ranks > 1:
+                for it_ in small:
+                    comm.all_reduce_device(it_['g'])
+            apply_small_params(ctx, small, i_opt_batch)
+            zeroed_by_update = {id(it_['g']) for it_ in small}
 
             # ---- intermediate output (ptychography.py:1231-1246; util.py:1958-2028, optimizers.py:1111-1160) ----
             if save_intermediate and ((save_intermediate_level == 'epoch' and i_batch == n_batch - 1) or save_intermediate_level == 'batch'):

@@ -328,6 +328,26 @@ int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b,
 #define ADM_FLAG_ZERO_CH1 4
 int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,
                   double step_size, double b1, double b2, double eps, int flags, const float* mask);
+/* The SMALL optimisable parameters of a minibatch -- probe modes, sub-pixel position corrections, propagation distances, affine
+ * matrices (adorym/optimizers.py:1022-1083) -- updated in one launch, one workgroup per array, with adm_adam_step's arithmetic:
+ *   x, g, m, v   device arrays of n floats (g is the accumulated gradient; flags = 0, no mask)
+ *   step_size    per array (the reference gives every parameter its own optimiser and learning rate)
+ *   center_cols  > 0: afterwards subtract from every column of x viewed as [n / center_cols][center_cols] its mean over the rows
+ *                (the drift guard of probe_pos_correction, optimizers.py:1046-1048; same sums as adm_center_rows)
+ *   pin, pin_n   != NULL: afterwards x[0 .. pin_n) = pin[0 .. pin_n) ("regularize transformation of image 0", optimizers.py:1067-1073)
+ *   zero_grad    != 0: g is zero-filled once used (the accumulator of the next minibatch, ptychography.py:1017-1031)
+ * i_batch, b1, b2, eps are common to the arrays of one call (at most ADM_SMALL_PARAMS_MAX).  These updates are launch-bound. */
+#define ADM_SMALL_PARAMS_MAX 6
+typedef struct adm_small_param {
+    float* x; float* g; float* m; float* v;
+    uint64_t n;
+    double step_size;
+    int32_t center_cols;
+    int32_t zero_grad;
+    const float* pin;
+    uint64_t pin_n;
+} adm_small_param;
+int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, int count, int i_batch, double b1, double b2, double eps);
 /* adm_rotate_fwd of an object whose Adam update is still PENDING: every gathered voxel is updated on the fly from (obj, grad, m, v)
  * with adm_adam_step's arithmetic (same bits: one shared device function, contraction off) and nothing is written back; m, v and
  * mask are indexed like obj (whole arrays).  The optimiser launch proper can then run later -- on the side stream, beside the

@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import adorym_amd as A                      # noqa: E402
 from adorym_amd._lib import check           # noqa: E402
+from adorym_amd.optimizers import AdamOptimizer, apply_small_params      # noqa: E402
 import bench                                # noqa: E402  (its cpu_baseline legs own the oracle timing)
 
 
@@ -37,27 +38,35 @@ def bench_c1(ctx, steps=50):
     m, v, g = ctx.zeros(obj.shape), ctx.zeros(obj.shape), ctx.zeros(obj.shape)
     probe_h = (r.standard_normal((M, P, P)) + 1j * r.standard_normal((M, P, P)))
     probe = ctx.array(np.stack([probe_h.real, probe_h.imag], -1).astype(np.float32))
-    pm, pv, gp = ctx.zeros(probe.shape), ctx.zeros(probe.shape), ctx.zeros(probe.shape)
+    gp = ctx.zeros(probe.shape)
     corr = ctx.array((pos - pos_int)[None].astype(np.float32))
-    cm, cv, gc = ctx.zeros(corr.shape), ctx.zeros(corr.shape), ctx.zeros(corr.shape)
+    gc = ctx.zeros(corr.shape)
     meas = ctx.array((np.abs(r.standard_normal((B, P, P))) * 50).astype(np.float32))
     idx = ctx.array(np.arange(B, dtype=np.int32))
     lib = ctx.lib
+    # the driver's optimiser objects and its ONE launch for the small parameters (adorym_amd/ptychography.py)
+    o_probe = AdamOptimizer('probe', options_dict={'step_size': 1e-3}); o_probe.create_param_arrays(list(probe.shape), device=ctx)
+    o_pos = AdamOptimizer('probe_pos_correction', options_dict={'step_size': 1e-2}); o_pos.create_param_arrays(list(corr.shape), device=ctx)
+    ring = ctx.uploader()
+    pending = [None]
 
     def step(k):
         s = (k * B) % (len(pos_int) - B)
+        eng.flush_loss_copy()               # the previous minibatch's loss read-back goes first: its event precedes this minibatch's work
         eng.set_batch(pos_int[s:s + B], meas)
-        idx.set(np.arange(s, s + B, dtype=np.int32))
+        ring.upload(idx, np.arange(s, s + B, dtype=np.int32))          # asynchronous, like the driver's per-minibatch uploads
         eng.rotate(obj, None, None)
-        g.zero_(); gp.zero_(); gc.zero_()
+        g.zero_()
         eng.multislice(probe, grad_probe=gp, shifts=corr, shift_index=idx, grad_shifts=gc)
         eng.rotate_adjoint(g, None, None)
         check(lib.adm_reg_grad(eng.plan.handle, obj.ptr, 0., 0., 1e-6, g.ptr, None))
         check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_adam_step(ctx.handle, probe.ptr, gp.ptr, pm.ptr, pv.ptr, 0, probe.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_adam_step(ctx.handle, corr.ptr, gc.ptr, cm.ptr, cv.ptr, 0, corr.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_center_rows(ctx.handle, corr.ptr, corr.size // 2, 2))
-        return eng.loss()
+        apply_small_params(ctx, [dict(opt=o_probe, x=probe, g=gp, zero_grad=True),
+                                 dict(opt=o_pos, x=corr, g=gc, center_cols=2, zero_grad=True)], 0)
+        tok = eng.loss_async()
+        out = eng.loss_result(pending[0]) if pending[0] is not None else None     # the PREVIOUS minibatch's loss: no pipeline drain
+        pending[0] = tok
+        return out
 
     for k in range(3):
         step(k)
@@ -85,23 +94,27 @@ def bench_c5(ctx, steps=50):
     probe = ctx.array(np.stack([np.ones((1, N, N)), np.zeros((1, N, N))], -1).astype(np.float32))
     d_h = np.array([40., 60., 90., 140.])
     dists = ctx.array(d_h.astype(np.float32))
-    dm, dv, gd = ctx.zeros((nd,)), ctx.zeros((nd,)), ctx.zeros((nd,))
+    gd = ctx.zeros((nd,))
     a_h = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1])
     aff = ctx.array(a_h.astype(np.float32))
-    am, av, ga = ctx.zeros(aff.shape), ctx.zeros(aff.shape), ctx.zeros(aff.shape)
+    ga = ctx.zeros(aff.shape)
     data_h = (1 + 0.1 * r.standard_normal((nd, N, N))) ** 2
     data = ctx.array(data_h.astype(np.float32))
     ident = ctx.array(np.array([[1., 0, 0], [0, 1., 0]], np.float32))
     lib = ctx.lib
+    o_d = AdamOptimizer('free_prop_cm', options_dict={'step_size': 1e-1}); o_d.create_param_arrays([nd], device=ctx)
+    o_a = AdamOptimizer('prj_affine_ls', options_dict={'step_size': 1e-3}); o_a.create_param_arrays(list(aff.shape), device=ctx)
+    pending = [None]
 
     def step():
-        g.zero_(); gd.zero_(); ga.zero_()
+        g.zero_()
         eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd, grad_affine=ga)
         check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_adam_step(ctx.handle, dists.ptr, gd.ptr, dm.ptr, dv.ptr, 0, nd, 0, 1e-1, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_adam_step(ctx.handle, aff.ptr, ga.ptr, am.ptr, av.ptr, 0, aff.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
-        check(lib.adm_d2d(ctx.handle, aff.ptr, ident.ptr, 24))
-        return eng.loss()
+        apply_small_params(ctx, [dict(opt=o_d, x=dists, g=gd, zero_grad=True), dict(opt=o_a, x=aff, g=ga, pin=ident, zero_grad=True)], 0)
+        tok = eng.loss_async()
+        out = pending[0]() if pending[0] is not None else None           # the PREVIOUS minibatch's loss
+        pending[0] = tok
+        return out
 
     for _ in range(3):
         step()
