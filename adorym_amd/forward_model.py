@@ -201,7 +201,7 @@ class PtychographyModel(ForwardModel):
         if getattr(self, '_idx_dev', None) is None or self._idx_dev.size < len(idx):
             self._idx_dev = DeviceArray(self.device, (max(len(idx), 64),), np.int32)
         view = self._idx_dev.view(0, (len(idx),))
-        view.set(idx)
+        self.device.uploader().upload(view, idx)     # asynchronous (pinned ring): a blocking copy here drained the stream every minibatch
         return dev, view
 
     def _coords(self, this_i_theta):
