@@ -318,3 +318,49 @@ def test_pending_update_rotation_is_bitwise_the_separate_optimiser_launch(tmp_pa
         out.append(st)
     assert np.array_equal(out[0]['delta'], out[1]['delta']) and np.array_equal(out[0]['beta'], out[1]['beta'])
     assert out[0]['losses'] == out[1]['losses']
+
+
+def test_small_parameter_update_in_one_launch_is_bitwise_the_separate_launches(A, ctx):
+    """adm_adam_step_small (probe modes, position corrections + drift guard, distances, affine matrices + identity pin, zero fill of
+    the gradient accumulators: adorym/optimizers.py:1022-1083) against adm_adam_step / adm_center_rows / adm_d2d / zero fill one
+    by one -- same device functions, same bits -- over three updates; and apply_small_params' fallback for a customised optimiser."""
+    from adorym_amd.optimizers import AdamOptimizer, apply_small_params
+    r = cases.rng(123)
+    shapes = {'probe': (5, 16, 16, 2), 'pos': (1, 77, 2), 'dist': (4,), 'aff': (4, 2, 3)}
+    steps = {'probe': 1e-3, 'pos': 1e-2, 'dist': 1e-1, 'aff': 1e-3}
+    x0 = {k: r.standard_normal(v).astype(np.float32) for k, v in shapes.items()}
+    grads = [{k: r.standard_normal(v).astype(np.float32) for k, v in shapes.items()} for _ in range(3)]
+    ident = ctx.array(np.array([[1., 0, 0], [0, 1., 0]], np.float32))
+    out = []
+    for mode in ('fused', 'separate', 'fallback'):
+        x = {k: ctx.array(v) for k, v in x0.items()}
+        g = {k: ctx.zeros(v) for k, v in shapes.items()}
+        opts = {}
+        for k in shapes:
+            o = AdamOptimizer(k, options_dict={'step_size': steps[k]})
+            o.create_param_arrays(list(shapes[k]), device=ctx)
+            opts[k] = o
+        if mode == 'fallback':
+            opts['dist'].options_dict['custom'] = 1          # not a plain option set any more: one-by-one path
+        for it in range(3):
+            for k in shapes:
+                A._lib.check(ctx.lib.adm_axpy(ctx.handle, g[k].ptr, ctx.array(grads[it][k]).ptr, 1.0, g[k].size))
+            if mode == 'separate':
+                for k in shapes:
+                    opts[k].apply_gradient(x[k], g[k], it, step_size=steps[k])
+                A._lib.check(ctx.lib.adm_center_rows(ctx.handle, x['pos'].ptr, x['pos'].size // 2, 2))
+                A._lib.check(ctx.lib.adm_d2d(ctx.handle, x['aff'].ptr, ident.ptr, 24))
+                for k in shapes:
+                    g[k].zero_()
+            else:
+                apply_small_params(ctx, [dict(opt=opts['probe'], x=x['probe'], g=g['probe'], zero_grad=True),
+                                         dict(opt=opts['pos'], x=x['pos'], g=g['pos'], center_cols=2, zero_grad=True),
+                                         dict(opt=opts['dist'], x=x['dist'], g=g['dist'], zero_grad=True),
+                                         dict(opt=opts['aff'], x=x['aff'], g=g['aff'], pin=ident, zero_grad=True)], it)
+        out.append({k: x[k].get() for k in shapes} | {'g_' + k: g[k].get() for k in shapes} |
+                   {'m_' + k: opts[k].params_whole_array_dict['m'].get() for k in shapes})
+    for other in out[1:]:
+        for k in out[0]:
+            assert np.array_equal(out[0][k], other[k]), k
+    assert np.array_equal(out[0]['aff'][0], np.array([[1., 0, 0], [0, 1., 0]], np.float32))
+    assert np.abs(out[0]['pos'].reshape(-1, 2).mean(0)).max() < 1e-6 and not np.any(out[0]['g_probe'])
