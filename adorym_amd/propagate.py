@@ -383,6 +383,13 @@ class MultisliceEngine(object):
         # nothing before the kernel's load schedule; one round more: 9.37)
         n_rounds = -(-B // self.N_CU)
         sizes = [B // n_rounds + (1 if i < B % n_rounds else 0) for i in range(n_rounds)]
+        policy = os.environ.get('ADM_ROUNDS', 'equal')          # experiment switch (profiles/README.md, round 3)
+        if policy == 'full':                                      # full rounds, short last one
+            sizes = [self.N_CU] * (B // self.N_CU) + ([B % self.N_CU] if B % self.N_CU else [])
+        elif policy.startswith('last'):                           # 'last96': a last round of that size, the rest split equally
+            last = min(int(policy[4:]), B - 1)
+            k = -(-(B - last) // self.N_CU)
+            sizes = [(B - last) // k + (1 if i < (B - last) % k else 0) for i in range(k)] + [last]
         bounds = [0] + [int(v) for v in np.cumsum(sizes)]
         parts = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1)]
         if getattr(self, '_ws_parts', None) is None or len(self._ws_parts) < len(parts):
