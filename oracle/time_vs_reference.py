@@ -55,13 +55,15 @@ def run_structured():
 
 
 run_reference(); run_structured()            # warm-up (allocator, FFT plans)
+REPS = int(os.environ.get('REPS', '5'))
 tr_, ts_ = [], []
-for _ in range(3):
+for _ in range(REPS):                        # interleaved, so that drifts of the shared 8-core container hit both alike
     lr, gr, tf, tb = run_reference(); tr_.append((tf + tb, tf, tb))
     ls, gs_, ts = run_structured(); ts_.append(ts)
+med_r, med_s = float(np.median([a[0] for a in tr_])), float(np.median(ts_))
 print('all runs: reference', ['%.2f' % a[0] for a in tr_], 'structured', ['%.2f' % a for a in ts_])
-print('mean: reference %.2f s, structured %.2f s, ratio %.3f' % (np.mean([a[0] for a in tr_]), np.mean(ts_), np.mean(ts_) / np.mean([a[0] for a in tr_])))
+print('median: reference %.2f s, structured %.2f s, ratio %.3f   (SURVEY 8d asks for 1 +- 0.15)' % (med_r, med_s, med_s / med_r))
 (_, tf, tb), ts = min(tr_), min(ts_)
-print('reference : fwd %.2f s + bwd %.2f s = %.2f s  (%d threads)' % (tf, tb, tf + tb, torch.get_num_threads()))
-print('structured: %.2f s   ratio %.3f' % (ts, ts / (tf + tb)))
+print('best:   reference fwd %.2f s + bwd %.2f s = %.2f s, structured %.2f s, ratio %.3f  (%d threads, B = %d, S = %d)'
+      % (tf, tb, tf + tb, ts, ts / (tf + tb), torch.get_num_threads(), B, S))
 print('loss rel diff %.2e, grad rel-L2 %.2e' % (abs(lr - ls) / abs(lr), np.linalg.norm(gr - gs_) / np.linalg.norm(gr)))
