@@ -87,7 +87,10 @@ def _serial_two_rank_update(A, params, seen, world):
     size = params['obj_size']
     pos = np.round(params['probe_pos']).astype(int)
     eng = A.MultisliceEngine(ctx, size, (E['P'], E['P']), pos, E['energy_ev'], E['psize_cm'], free_prop_cm='inf', max_batch=E['minibatch_size'])
-    init = np.stack(params['initial_guess'], -1).astype(np.float32)
+    init = np.stack(params['initial_guess'], -1).astype(np.float64)
+    if params.get('non_negativity'):
+        init[init < 0] = 0                  # initialize_object_for_dp clips the guess (adorym/util.py:71-125)
+    init = init.astype(np.float32)
     obj = ctx.array(init)
     probe = ctx.array(np.stack([params['probe_initial'][0] * np.cos(params['probe_initial'][1]),
                                 params['probe_initial'][0] * np.sin(params['probe_initial'][1])], -1)[None], np.float32)
@@ -107,7 +110,10 @@ def _serial_two_rank_update(A, params, seen, world):
     gsum = ctx.array(total)
     n = init.size
     m, v = ctx.zeros((n,)), ctx.zeros((n,))
-    HipOps(ctx).adam(obj, gsum, 0, m, v, 0, 0, n, 0, params['learning_rate'], 0.9, 0.999, 1e-7, 0, None)
+    from adorym_amd.dp import constraint_flags
+    flags = constraint_flags(bool(params.get('non_negativity')), params.get('object_type', 'normal'))
+    mask = ctx.array(params['finite_support_mask_path'], np.float32) if params.get('finite_support_mask_path') is not None else None
+    HipOps(ctx).adam(obj, gsum, 0, m, v, 0, 0, n, 0, params['learning_rate'], 0.9, 0.999, 1e-7, flags, mask)
     return obj.get()
 
 
@@ -221,6 +227,21 @@ def test_world2_two_part_gather_is_bitwise_the_plain_gather(tmp_path, run):
         assert np.array_equal(a['delta'], b['delta']) and np.array_equal(a['beta'], b['beta'])
         assert np.array_equal(a['losses'], b['losses'])
         assert np.array_equal(a['probe'], b['probe'])
+
+
+def test_world2_constraints_and_mask_on_shards(tmp_path):
+    """Non-negativity clip and finite-support mask are applied by the optimiser kernel on each rank's SHARD (absolute voxel
+    indices, adorym/ptychography.py:1135-1158, adorym/array_ops.py:239-251): the 2-rank result equals the one-context
+    restatement bit for bit, the clip and the mask are visible in it."""
+    r = np.random.default_rng(5)
+    N = cases.E2E['N']
+    support = (r.uniform(size=(N, N, N)) > 0.3).astype(np.float32)
+    extra = dict(n_epochs=1, optimizer='adam', learning_rate=1e-4, non_negativity=True, finite_support_mask_path=support)
+    res = run_world2(tmp_path, 6, extra, emulate=True)
+    emu = res[0]['emulated']
+    for r_ in res:
+        assert np.array_equal(r_['delta'], emu[..., 0]) and np.array_equal(r_['beta'], emu[..., 1])
+    assert np.all(res[0]['delta'] >= 0) and np.all(res[0]['delta'][support == 0] == 0) and np.any(res[0]['delta'][support == 1] > 0)
 
 
 @pytest.mark.parametrize('reg', [False, True])
