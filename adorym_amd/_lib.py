@@ -100,12 +100,10 @@ SIGNATURES = {
     'adm_tile_grad_accumulate': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP]),
     'adm_tile_grad_accumulate_part': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP, _I, _I, _I]),
     'adm_tile_cover_build': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _I, _I, _I]),
-    'adm_multislice_fwd_adj_chased': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _SZ, _VP, _VP, _I, _I, _I]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_reg_grad_set': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
-    'adm_rotate_fwd_pending_adam': (_I, [_VP, _VP, _VP, _VP, _VP, _I, _D, _D, _D, _D, _I, _VP, _VP, _VP, _I, _I]),
     'adm_adam_step_small': (_I, [_VP, C.POINTER(SmallParam), _I, _I, _D, _D, _D]),
     'adm_gd_step': (_I, [_VP, _VP, _VP, _SZ, _SZ, _D, _I, _VP]),
     'adm_momentum_step': (_I, [_VP, _VP, _VP, _VP, _SZ, _SZ, _D, _D, _I, _VP]),

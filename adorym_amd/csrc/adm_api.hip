@@ -252,8 +252,6 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->trans_src = nullptr;
     p->trans_only = false;
     std::memset(p->cover_keys, 0, sizeof(p->cover_keys));
-    p->chase_buf = nullptr;
-    p->chase_total = 0;
     p->generic = !tuned;
     {   // radix lists of the generic kernel's transforms: 8, 4, 2, 9, 3, 5, 7, then whatever primes remain
         auto factor = [](int n, int* r) {
@@ -326,7 +324,6 @@ extern "C" int adm_plan_destroy(adm_plan* plan) {
     if (plan->reg_stats) (void)hipFree(plan->reg_stats);
     if (plan->reg_partial) (void)hipFree(plan->reg_partial);
     if (plan->trans_dev) (void)hipFree(plan->trans_dev);
-    if (plan->chase_buf) (void)hipFree(plan->chase_buf);
     if (plan->det_weight_dev) adm_free(plan->ctx, plan->det_weight_dev);
     delete plan;
     return ADM_OK;
@@ -385,9 +382,7 @@ size_t ws_off_gprobe(const adm_plan* plan, int batch) { return ws_off_det(plan, 
 
 int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
                          const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
-                         float grad_scale, void* workspace, size_t workspace_bytes, bool per_position, unsigned* progress,
-                         int progress_shift, bool* chase_armed) {
-    if (chase_armed) *chase_armed = false;
+                         float grad_scale, void* workspace, size_t workspace_bytes, bool per_position) {
     if (!plan || !obj_rot || !probe || !pos || !target || !loss_sum)
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: batch must be positive");
@@ -466,11 +461,6 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
         ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
     } else {
         if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
-        if (progress && want_grad && ms_chase_supported(p)) {
-            p.progress = progress;
-            p.progress_shift = progress_shift;
-            if (chase_armed) *chase_armed = true;
-        }
         ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     }
     if (!per_position && grad_probe && want_grad)
@@ -496,14 +486,14 @@ extern "C" int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, cons
                                       const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                                       float grad_scale, void* workspace, size_t workspace_bytes) {
     return multislice_impl(plan, obj_rot, probe, pos, batch, target, want_grad, grad_probe, pred, loss_sum, grad_scale, workspace,
-                           workspace_bytes, false, nullptr, 0, nullptr);
+                           workspace_bytes, false);
 }
 
 extern "C" int adm_multislice_fwd_adj_pp(adm_plan* plan, const float* obj_rot, const float* probes, const int32_t* pos, int batch,
                                          const float* target, int want_grad, float* grad_probes, float* pred, float* loss_sum,
                                          float grad_scale, void* workspace, size_t workspace_bytes) {
     return multislice_impl(plan, obj_rot, probes, pos, batch, target, want_grad, grad_probes, pred, loss_sum, grad_scale, workspace,
-                           workspace_bytes, true, nullptr, 0, nullptr);
+                           workspace_bytes, true);
 }
 
 extern "C" int adm_probe_shift(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,

@@ -46,8 +46,6 @@ struct adm_plan {
     // adm_tile_cover_build: the cover lists in workspace `ws` are current for (pos, batch, window); a few entries, so that every
     // round of a batch launched in parts can have its lists built ahead
     struct CoverKey { const void* ws; const void* pos; int batch, row0, nrows; } cover_keys[4];
-    unsigned* chase_buf;   // [0] error flag (a chaser gave up waiting), [16 ...] progress counters of the chunks (lazily allocated)
-    unsigned chase_total;  // workgroups that have reported to every counter so far (the counters only ever grow)
 };
 
 namespace adm {
@@ -66,8 +64,6 @@ struct MsParams {
     float* loss_sum;           // [B]
     float2* stash;             // [B][n_steps][R1][NT] post-modulation wavefields
     float2* gtile;             // [B][n_steps][R1][NT] per-position tile gradients (d/ddelta, d/dbeta)
-    unsigned* progress;        // chase: progress[c] += 1 when a workgroup's reverse sweep has stored step c << progress_shift, or nullptr
-    int progress_shift;        // log2 of the steps per progress chunk
     const float2* h;           // [P][P] natural order, unscaled
     const float2* hfree;       // [P][P] or nullptr
     const float2* twid;        // [N] exp(-2 pi i j / N)
@@ -116,11 +112,10 @@ size_t ws_off_gprobe(const adm_plan* plan, int batch);
 hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* out, hipStream_t st);
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
-bool ms_chase_supported(const MsParams& p);     // the kernel instance ms_launch would pick signals its reverse-sweep progress
-// adm_multislice_fwd_adj's body; progress / progress_shift arm the reverse sweep's progress signals when *chase_armed comes back true
+// adm_multislice_fwd_adj's body (per_position: one probe set per position)
 int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch, const float* target,
                     int want_grad, float* grad_probe, float* pred, float* loss_sum, float grad_scale, void* workspace,
-                    size_t workspace_bytes, bool per_position, unsigned* progress, int progress_shift, bool* chase_armed);
+                    size_t workspace_bytes, bool per_position);
 bool ms_lean_supported(int n);
 bool ms_generic_supported(int py, int px);
 int ms_generic_threads(int py, int px);

@@ -298,11 +298,7 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
 }
 
 // ACC: add to the tile gradient already stored by a previous probe mode instead of overwriting it
-// CHASE: after the tile gradient of step c << progress_shift has been stored (the LOWEST step of progress chunk c: the sweep
-// runs downwards), every wave makes its stores visible to the whole device and the workgroup adds one to progress[c].  The
-// overlap-add of that chunk of steps (tile_accumulate_chase_kernel, queued on the side stream) starts as soon as all
-// workgroups of the launch have reported, i.e. while the sweep goes on, instead of after the whole launch.
-template <int N, int R1, int R2, bool BIN1, bool ACC, int MODE, bool CHASE = false>
+template <int N, int R1, int R2, bool BIN1, bool ACC, int MODE>
 __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const cf (&hs)[R2], const MsParams& p, const float2* stash,
                                           float2* gtile, const float2* tile_base, size_t slice_stride) {
     using GE = Geo<N, R1, R2>;
@@ -346,13 +342,6 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
             ADM_STAMP(10);
         }
         ADM_STAMP(11);
-        if (CHASE) {
-            if ((step & ((1 << p.progress_shift) - 1)) == 0) {          // uniform over the workgroup
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // this wave's tile-gradient stores, device-wide
-                __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(p.progress + (step >> p.progress_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         auto hook = [&](auto pt) {
             constexpr int HP = decltype(pt)::value, H = BIN1 ? R1 / 2 : R1;
             if (c.act1 && step > 0) {
@@ -419,7 +408,7 @@ __device__ __forceinline__ int xcd_position(int wg, int B) {
 
 // PP: one probe set per position (sub-pixel probe positions); a template parameter because even the two extra address
 // computations measurably perturb the schedule of the tuned default kernel (+3 %).
-template <int N, int R1, int R2, bool BIN1, bool MULTI, int MODE, bool PP, bool CHASE = false>
+template <int N, int R1, int R2, bool BIN1, bool MULTI, int MODE, bool PP>
 __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsParams p) {
     using GE = Geo<N, R1, R2>;
     __shared__ cf fld[GE::FLD];
@@ -513,7 +502,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
         if (!do_grad) return;
         detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
-        rev_sweep<N, R1, R2, BIN1, false, MODE, CHASE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
+        rev_sweep<N, R1, R2, BIN1, false, MODE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
         add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr, p.gprobe_bstride != 0);
     } else {
         // ================= several incoherent probe modes (adorym/forward_model.py:354-375) =================
@@ -610,9 +599,7 @@ template <int N, int R1, int R2> static hipError_t launch(const MsParams& p, int
     const bool multi = p.n_modes > 1;
     // binning == 1 is enforced for real_imag at plan creation, for per-position probes and the cached transmissions
     // by the caller
-    if (p.progress && ms_chase_supported(p)) {       // the default instance (cached transmissions, one mode) with progress signals
-        hipLaunchKernelGGL((ms_fwd_adj_kernel<N, R1, R2, true, false, 2, false, true>), g, t, 0, st, p);
-    } else if (p.probe_bstride) {
+    if (p.probe_bstride) {
         if (p.real_imag) { if (multi) ADM_LAUNCH(true, true, 1, true); else ADM_LAUNCH(true, false, 1, true); }
         else if (p.pre_t) { if (multi) ADM_LAUNCH(true, true, 2, true); else ADM_LAUNCH(true, false, 2, true); }
         else { if (multi) ADM_LAUNCH(true, true, 0, true); else ADM_LAUNCH(true, false, 0, true); }
@@ -793,10 +780,6 @@ int ms_r1_for(int n) {
 #undef X
         default: return 0;
     }
-}
-
-bool ms_chase_supported(const MsParams& p) {
-    return p.pre_t && p.n_modes == 1 && !p.probe_bstride && !p.real_imag && p.binning == 1 && p.want_grad;
 }
 
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st) {

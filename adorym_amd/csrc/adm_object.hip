@@ -433,45 +433,6 @@ __global__ __launch_bounds__(256) void tile_accumulate_kernel(const float2* __re
     ta_block(gtile, cover, grad_rot, g, zc, idx % (nbx * nby));
 }
 
-// The same overlap-add CHASING the multislice launch that produces the tile gradients (ms_fwd_adj_kernel<..., CHASE>): a small
-// persistent grid (one block per compute unit, so that it fits beside the multislice workgroups in whatever order the two
-// launches become resident) walks the step chunks from the highest down -- the order in which the reverse sweep finishes them
-// -- and waits at each progress chunk until every workgroup of the launch has reported it (progress[c] has reached `target`;
-// the counters only ever grow, so nothing is reset between launches).  XCD k again takes the step chunks k, k + 8, ...
-// A block that waits longer than ~0.2 s gives up, raises *err and poisons loss_sum[0] with NaN so that the failure cannot
-// go unnoticed; it never hangs.  Same sums in the same order as tile_accumulate_kernel: bit-identical results.
-__global__ __launch_bounds__(256) void tile_accumulate_chase_kernel(const float2* __restrict__ gtile, const unsigned* __restrict__ cover,
-                                                                    float2* __restrict__ grad_rot, TileGeom g,
-                                                                    const unsigned* __restrict__ progress, unsigned target, int progress_shift,
-                                                                    unsigned* err, float* poison) {
-    const int nbx = (g.Xp + 31) / 32, nby = (g.nrows + 7) / 8, npix = nbx * nby;
-    const int nz = (g.n_steps + TA_STEPS - 1) / TA_STEPS;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    int zc = xcd + 8 * ((nz - 1 - xcd) / 8);            // the highest chunk congruent to xcd (mod 8); negative if there is none
-    if (nz - 1 - xcd < 0) return;
-    int ready_chunk = 1 << 30;                           // progress chunks >= this one are known to be complete
-    for (; zc >= 0; zc -= 8) {
-        const int chunk = (zc * TA_STEPS) >> progress_shift;
-        if (chunk < ready_chunk) {
-            if (threadIdx.x == 0) {
-                unsigned spins = 0;
-                while ((int)(__hip_atomic_load(progress + chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                    __builtin_amdgcn_s_sleep(64);
-                    if (++spins > 100000u) {             // ~0.2 s: the producer is not coming
-                        atomicExch(err, 1u);
-                        if (poison) *poison = __builtin_nanf("");
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            ready_chunk = chunk;
-        }
-        for (int rem = slot; rem < npix; rem += per_xcd) ta_block(gtile, cover, grad_rot, g, zc, rem);
-    }
-}
-
 // --------------------------------------------------------------------------------------------
 // Regulariser gradient.  L1Regularizer (adorym/regularizers.py:30-46): alpha_c * mean|x_c|;
 // TVRegularizer (regularizers.py:95-110 -> util.py:1427-1440): gamma * sum_axes sum|roll(a,1)-a| / V.
@@ -742,8 +703,8 @@ struct AdamScalars {
     const float* mask;
 };
 
-// one element of AdamOptimizer.apply_gradient + constraints; shared by adam_kernel and the rotation that applies a PENDING
-// update on the fly (rotate_fwd_pending_kernel), with contraction off so that both produce the same bits
+// one element of AdamOptimizer.apply_gradient + constraints; shared by adam_kernel and small_adam_kernel, with contraction off
+// so that both produce the same bits
 __device__ __forceinline__ float adam_value(float xv, float gv, float m_in, float v_in, const AdamScalars& a, size_t i, float& m_out,
                                             float& v_out) {
 #pragma clang fp contract(off)
@@ -767,42 +728,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const 
         m[i] = mv;
         v[i] = vv;
         x[i] = xn;
-    }
-}
-
-// adm_rotate_fwd for an object whose Adam update is still PENDING: every gathered voxel is first updated on the fly from
-// (x, g, m, v) -- the value adam_kernel will store later -- and nothing is written back.  Takes the optimiser launch (and the gap
-// around it) off the chain between the back-rotation and the next multislice launch: the update proper then runs on the side
-// stream, beside that launch.
-__global__ __launch_bounds__(256) void rotate_fwd_pending_kernel(const float2* __restrict__ obj, const float2* __restrict__ grad,
-                                                                 const float2* __restrict__ mom, const float2* __restrict__ vel,
-                                                                 AdamScalars a, const uint16_t* __restrict__ coords,
-                                                                 float2* __restrict__ rot, float2* __restrict__ trans, float k1, float sigma,
-                                                                 RotGeom g, int y_lo, int y_hi, int y_chunk) {
-    const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (xr >= g.X || zr >= g.Z) return;
-    const Bilin b = make_bilin(coords, xr, zr, g.X, g.Z);
-    const int ya = y_lo + blockIdx.z * y_chunk;
-    const int yb = min(ya + y_chunk, y_hi);
-    const size_t plane = (size_t)g.X * g.Z;
-    const int idx[4] = {b.i00, b.i01, b.i10, b.i11};
-    for (int y = ya; y < yb; ++y) {
-        float2 val[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const size_t e = (size_t)y * plane + idx[q];
-            const float2 xv = obj[e], gv = grad[e], mv = mom[e], vv = vel[e];
-            float mo, vo;
-            val[q].x = adam_value(xv.x, gv.x, mv.x, vv.x, a, 2 * e, mo, vo);
-            val[q].y = adam_value(xv.y, gv.y, mv.y, vv.y, a, 2 * e + 1, mo, vo);
-        }
-        float2 r;
-        r.x = val[0].x * b.w00 + val[1].x * b.w01 + val[2].x * b.w10 + val[3].x * b.w11;
-        r.y = val[0].y * b.w00 + val[1].y * b.w01 + val[2].y * b.w10 + val[3].y * b.w11;
-        const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
-        if (rot) rot[o_rot] = r;
-        if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
     }
 }
 
@@ -1138,63 +1063,6 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     return ADM_OK;
 }
 
-// Multislice forward + adjoint with the overlap-add of the tile gradients chasing the reverse sweep (see
-// tile_accumulate_chase_kernel): the launch goes to the main stream, the chaser to the side stream, where it runs beside the
-// rest of the launch; adm_ctx_join() orders everything behind both.  Falls back to launch + plain overlap-add (same results,
-// main stream) for kernel variants without progress signals.
-extern "C" int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                                             const float* target, float* grad_probe, float* pred, float* loss_sum, float grad_scale,
-                                             void* workspace, size_t workspace_bytes, const int32_t* pos_host, float* grad_rot,
-                                             int win_y_lo, int win_y_hi, int add) {
-    if (!plan || !workspace || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: null argument");
-    adm_ctx* ctx = plan->ctx;
-    if (ctx->stream != ctx->main_stream) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: call it outside adm_ctx_fork / adm_ctx_end_fork");
-    if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj_chased: bad workspace");
-    TileGeom g;
-    int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
-    if (rc) return rc;
-    const int shift = 5;                                  // 32 steps per progress chunk
-    const int n_chunks = ((plan->n_steps - 1) >> shift) + 1;
-    if (!plan->chase_buf && n_chunks <= 240) {
-        ADM_HIP(hipMalloc((void**)&plan->chase_buf, 256 * sizeof(unsigned)));
-        ADM_HIP(hipMemsetAsync(plan->chase_buf, 0, 256 * sizeof(unsigned), ctx->main_stream));
-        plan->chase_total = 0;
-    }
-    // Measured (round 3, profiles/README.md): NOT a gain on MI355X.  At 32 positions the 8 progress signals (agent-scope release =
-    // L2 write-back) cost the sweep 0.12 ms and the chaser's traffic up to 0.11 ms more, against 0.1 ms of overlap-add hidden;
-    // with the chip full the chaser takes issue slots and power from the sweep it is chasing (7.5 -> 11.2 ms per 544 positions).
-    // The callers therefore use it only on request (ADM_CHASE=1), and large launches never do.  ADM_CHASE_MAX_BATCH overrides.
-    static const int chase_max_batch = [] { const char* e = getenv("ADM_CHASE_MAX_BATCH"); return e ? atoi(e) : 96; }();
-    unsigned* progress = (plan->chase_buf && n_chunks <= 240 && batch <= chase_max_batch) ? plan->chase_buf + 16 : nullptr;
-    // everything the side stream still holds was queued before this point; the chaser goes behind it
-    ADM_HIP(hipEventRecord(ctx->ev_fork, ctx->main_stream));
-    bool armed = false;
-    rc = adm::multislice_impl(plan, obj_rot, probe, pos, batch, target, 1, grad_probe, pred, loss_sum, grad_scale, workspace, workspace_bytes,
-                              false, progress, shift, &armed);
-    if (rc) return rc;
-    if (!armed) return adm_tile_grad_accumulate_part(plan, workspace, workspace_bytes, pos, batch, pos_host, grad_rot, win_y_lo, win_y_hi, add);
-    plan->chase_total += (unsigned)batch;
-    ADM_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-    const bool prebuilt = cover_key_take(plan, workspace, pos, batch, g);
-    ctx->stream = ctx->aux_stream;                        // (cover_build queues on the context's current stream)
-    if (!prebuilt) rc = cover_build(plan, workspace, pos, batch, g);
-    ctx->stream = ctx->main_stream;
-    if (rc) return rc;
-    char* ws = (char*)workspace;
-    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
-    const unsigned* cover = (const unsigned*)(ws + ws_off_cover(plan, batch));
-    // blocks of the persistent chaser: 24 VGPRs each, so three per compute unit still fit beside a multislice workgroup (3 x 144
-    // of a SIMD's 512 registers, 3 + 3 of its 8 wave slots) whichever of the two launches becomes resident first;
-    // ADM_CHASE_BLOCKS overrides (tuning)
-    static const int chase_blocks = [] { const char* e = getenv("ADM_CHASE_BLOCKS"); const int v = e ? atoi(e) : 768; return v >= 8 ? (v & ~7) : 768; }();
-    hipLaunchKernelGGL(tile_accumulate_chase_kernel, dim3(chase_blocks), dim3(256), 0, ctx->aux_stream, gtile, cover, (float2*)grad_rot, g,
-                       (const unsigned*)progress, plan->chase_total, shift, plan->chase_buf, loss_sum);
-    ADM_HIP(hipGetLastError());
-    ADM_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-    ctx->join_pending = true;
-    return ADM_OK;
-}
-
 extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host) {
     if (!plan || !workspace || !overflow_host) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: null argument");
     if (batch <= 0 || workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_status: bad workspace");
@@ -1303,25 +1171,6 @@ extern "C" int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, 
     }
     hipLaunchKernelGGL(small_adam_kernel, dim3(count), dim3(256), 0, ctx->stream, sp, adam_scalars(i_batch, 0.0, b1, b2, eps, 0, nullptr));
     ADM_HIP(hipGetLastError());
-    return ADM_OK;
-}
-
-extern "C" int adm_rotate_fwd_pending_adam(adm_plan* plan, const float* obj, const float* grad, const float* m, const float* v, int i_batch,
-                                           double step_size, double b1, double b2, double eps, int flags, const float* mask,
-                                           const uint16_t* coords, float* obj_rot, int y_lo, int y_hi) {
-    if (!plan || !obj || !grad || !m || !v || !obj_rot) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_pending_adam: null argument");
-    const adm_plan_desc& d = plan->d;
-    if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_pending_adam: bad y range");
-    if (y_lo == y_hi) return ADM_OK;
-    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
-    const int y_chunk = 32;
-    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
-    hipLaunchKernelGGL(rotate_fwd_pending_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, (const float2*)grad,
-                       (const float2*)m, (const float2*)v, adam_scalars(i_batch, step_size, b1, b2, eps, flags, mask), coords,
-                       (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot, plan->trans_dev, d.k1,
-                       (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
-    ADM_HIP(hipGetLastError());
-    if (plan->trans_dev) plan->trans_src = obj_rot;
     return ADM_OK;
 }
 

@@ -110,10 +110,6 @@ class DataParallelObject(object):
         # outside `first` are stale by contract; fill them with NaN so that a reader that skipped finish_update() shows up
         self.poison = os.environ.get('ADM_DEBUG_POISON', '0') == '1'
         self._gather_pending = False
-        self._pending = None
-        # one rank: exchange_and_update(first=...) with Adam may leave the WHOLE update pending for the next rotation to apply on the
-        # fly (see there); callers that rotate through MultisliceEngine.rotate(pending=state.pending_update()) switch it on
-        self.pending_rotation = False
         self.clock = None           # a device.PhaseClock while a caller (bench.py) wants per-phase device times
 
     def _tic(self, name):
@@ -164,13 +160,7 @@ class DataParallelObject(object):
             g, g_base = self.grad, 0
         self._toc('reduce_scatter')
         self._tic('update')
-        if first is not None and not self.dist and self.hi > self.lo and optimizer == 'adam' and self.pending_rotation:
-            # one rank, Adam: NOTHING is applied now.  The next rotation applies the pending update on the fly to the voxels it
-            # gathers (pending_update() -> adm_rotate_fwd_pending_adam, same bits as the optimiser kernel), and the update
-            # proper is queued with the rest of the side-stream work (finish_update), beside the next multislice launch
-            self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, self.lo, self.lo)
-            self._pending = (i_batch, dict(options), flags, mask, g)
-        elif first is not None and not self.dist and self.hi > self.lo:
+        if first is not None and not self.dist and self.hi > self.lo:
             f_lo, f_hi = max(self.lo, int(first[0])), min(self.hi, int(first[1]))
             self._apply(optimizer, i_batch, options, flags, mask, g, g_base, f_lo, f_hi)
             self._deferred = (optimizer, i_batch, dict(options), flags, mask, g, g_base, f_lo, f_hi)
@@ -206,16 +196,6 @@ class DataParallelObject(object):
                 if b > a:
                     check(self.ops.ctx.lib.adm_memset(self.ops.ctx.handle, self.obj.ptr + 4 * a, 0xFF, 4 * (b - a)))
 
-    def pending_update(self):
-        """The Adam update that exchange_and_update() left pending, as the argument tuple of MultisliceEngine.rotate(pending=...):
-        (grad, m, v, i_batch, step_size, b1, b2, eps, flags, mask), or None if the object is up to date."""
-        p_ = self._pending
-        if p_ is None:
-            return None
-        i_batch, o, flags, mask, g = p_
-        return (g, self.moments[0], self.moments[1], int(i_batch), o.get('step_size', 0.001), o.get('b1', 0.9), o.get('b2', 0.999),
-                o.get('eps', 1e-7), int(flags), mask)
-
     def finish_update(self):
         """Apply the part of the last update that exchange_and_update(first=...) deferred (on the current stream)."""
         if self._gather_pending:            # a collective: every rank reaches this at the same point of its stream of calls
@@ -224,7 +204,6 @@ class DataParallelObject(object):
             self.comm.all_gather(self.obj, self.obj.view(self.lo, (self.per,)))
             self._toc('deferred_gather')
         d = getattr(self, '_deferred', None)
-        self._pending = None
         if d is not None:
             self._deferred = None
             optimizer, i_batch, options, flags, mask, g, g_base, f_lo, f_hi = d

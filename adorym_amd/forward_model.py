@@ -269,8 +269,7 @@ class PtychographyModel(ForwardModel):
         if not (rool and obj is getattr(self, 'arr_rot', None)):
             # (rotate_out_of_loop: ``obj`` IS the rotated object; the driver hands over arr_rot, whose slice-major twin the
             # engine already holds from rotate_outside(); any other array is loaded as it is, coords = None)
-            pend = self.pending_update() if getattr(self, 'pending_update', None) is not None else None
-            eng.rotate(obj, coords, yr, pending=pend)
+            eng.rotate(obj, coords, yr)
         ctx.fork()
         eng.flush_loss_copy()       # the previous minibatch's loss read-back: on the side stream, beside this kernel
         if side_hook is not None:
@@ -307,12 +306,6 @@ class PtychographyModel(ForwardModel):
             # no join here: the overlapped launch forks again, and the side stream is in order, so its overlap-adds queue
             # behind the regulariser kernel while the first round of workgroups already runs beside it
             eng.multislice_overlapped(probe, grad_probe=gp, grad_scale=gs, want_pred=want_pred)
-        elif want_grad and shifts is None and os.environ.get('ADM_CHASE', '0') == '1':
-            # opt-in (ADM_CHASE=1): the overlap-add of the tile gradients chases the reverse sweep on the side stream, chunk of
-            # slices by chunk.  Bit-identical, but measured SLOWER (the progress signals cost the sweep 0.12 ms per launch, the
-            # chaser's traffic another 0.1 ms, against 0.1 ms of overlap-add hidden): profiles/README.md, round 3
-            eng.multislice_chased(probe, grad_probe=gp, want_pred=want_pred, grad_scale=gs)
-            ctx.join()
         else:
             eng.multislice(probe, grad_probe=gp, want_grad=want_grad, want_pred=want_pred, grad_scale=gs, shifts=shifts,
                            shift_index=idx, grad_shifts=gsh, accumulate=False)

@@ -205,18 +205,10 @@ class MultisliceEngine(object):
         return lo, max(lo, hi)
 
     # -------------------------------------------------------------------------------- stages
-    def rotate(self, obj, coords, y_range=None, pending=None):
-        """obj: DeviceArray [Y,X,Z,2]; coords: DeviceArray uint16 [X*Z,2] or None (no rotation).
-        ``pending`` = DataParallelObject.pending_update(): an Adam update of ``obj`` that has not been applied yet is applied on
-        the fly to every gathered voxel (adm_rotate_fwd_pending_adam; obj itself is left as it is)."""
+    def rotate(self, obj, coords, y_range=None):
+        """obj: DeviceArray [Y,X,Z,2]; coords: DeviceArray uint16 [X*Z,2] or None (no rotation)."""
         lo, hi = y_range if y_range is not None else (0, self.obj_size[0])
         cp = coords.ptr if coords is not None else None
-        if pending is not None:
-            g, m, v, i_batch, step, b1, b2, eps, flags, mask = pending
-            check(self.ctx.lib.adm_rotate_fwd_pending_adam(self.plan.handle, obj.ptr, g.ptr, m.ptr, v.ptr, i_batch, float(step), float(b1),
-                                                           float(b2), float(eps), flags, mask.ptr if mask is not None else None, cp,
-                                                           self.obj_rot.ptr, lo, hi))
-            return
         check(self.ctx.lib.adm_rotate_fwd(self.plan.handle, obj.ptr, cp, self.obj_rot.ptr, lo, hi))
 
     def rotate_adjoint(self, grad_obj, coords, y_range=None):
@@ -302,22 +294,6 @@ class MultisliceEngine(object):
         if want_grad and accumulate:
             self.accumulate_tiles()
 
-    def multislice_chased(self, probe, grad_probe=None, want_pred=False, grad_scale=None):
-        """multislice(want_grad=True) + accumulate_tiles() with the overlap-add CHASING the launch on the side stream
-        (adm_multislice_fwd_adj_chased): every chunk of 32 slices is overlap-added as soon as the reverse sweep of all positions
-        has passed it.  Same result bit for bit.  The caller joins (Context.join) before it reads grad_rot."""
-        B = self._B
-        if grad_scale is None:
-            grad_scale = 2.0 / (B * self.n_det)
-        self._check_cover(self._pos_host)
-        self._next_loss_buffer()
-        check(self.ctx.lib.adm_multislice_fwd_adj_chased(
-            self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
-            grad_probe.ptr if grad_probe is not None else None, self._pred.ptr if want_pred else None, self._loss.ptr,
-            float(grad_scale), self._ws.ptr, self._ws.nbytes, self._pos_host.ctypes.data, self.grad_rot.ptr, 0, 0, 0))
-        self._accumulated = True
-        self._acc_parts = [(self._ws, B)]
-
     MAX_COVER = 64        # ADM_MAXCOVER of adm_object.hip: cover-list entries per rotated-frame pixel
 
     def _check_cover(self, pos):
@@ -383,13 +359,6 @@ class MultisliceEngine(object):
         # nothing before the kernel's load schedule; one round more: 9.37)
         n_rounds = -(-B // self.N_CU)
         sizes = [B // n_rounds + (1 if i < B % n_rounds else 0) for i in range(n_rounds)]
-        policy = os.environ.get('ADM_ROUNDS', 'equal')          # experiment switch (profiles/README.md, round 3)
-        if policy == 'full':                                      # full rounds, short last one
-            sizes = [self.N_CU] * (B // self.N_CU) + ([B % self.N_CU] if B % self.N_CU else [])
-        elif policy.startswith('last'):                           # 'last96': a last round of that size, the rest split equally
-            last = min(int(policy[4:]), B - 1)
-            k = -(-(B - last) // self.N_CU)
-            sizes = [(B - last) // k + (1 if i < (B - last) % k else 0) for i in range(k)] + [last]
         bounds = [0] + [int(v) for v in np.cumsum(sizes)]
         parts = [(bounds[i], bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1)]
         if getattr(self, '_ws_parts', None) is None or len(self._ws_parts) < len(parts):
@@ -404,7 +373,6 @@ class MultisliceEngine(object):
         self._acc_parts = []
         for o, n in parts:
             self._check_cover(self._pos_host[o:o + n])
-        chase = os.environ.get('ADM_CHASE', '0') == '1'
         if len(parts) <= 4:
             # the cover lists of every round only need the positions: all built now, on the side stream beside the first
             # round, so that no round's overlap-add waits for its own list (the LAST one's build sat behind the last launch)
@@ -415,20 +383,13 @@ class MultisliceEngine(object):
             self.ctx.end_fork()
         for i, (o, n) in enumerate(parts):
             ws = self._ws_parts[i]
-            if chase:
-                # every round's overlap-add chases its own launch on the side stream (in order there: round i before i + 1)
-                check(lib.adm_multislice_fwd_adj_chased(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
-                                                        self._cur_target.ptr + 4 * o * Py * Px, gp, (pr + 4 * o * Py * Px) if pr else None,
-                                                        self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes,
-                                                        self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
-            else:
-                check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
-                                                 self._cur_target.ptr + 4 * o * Py * Px, 1, gp, (pr + 4 * o * Py * Px) if pr else None,
-                                                 self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes))
-                self.ctx.fork()                   # side stream: waits for this round, then runs beside the next one
-                check(lib.adm_tile_grad_accumulate_part(h, ws.ptr, ws.nbytes, self._cur_pos.ptr + 8 * o, n,
-                                                        self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
-                self.ctx.end_fork()
+            check(lib.adm_multislice_fwd_adj(h, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr + 8 * o, n,
+                                             self._cur_target.ptr + 4 * o * Py * Px, 1, gp, (pr + 4 * o * Py * Px) if pr else None,
+                                             self._loss.ptr + 4 * o, float(grad_scale), ws.ptr, ws.nbytes))
+            self.ctx.fork()                   # side stream: waits for this round, then runs beside the next one
+            check(lib.adm_tile_grad_accumulate_part(h, ws.ptr, ws.nbytes, self._cur_pos.ptr + 8 * o, n,
+                                                    self._pos_host[o:o + n].ctypes.data, self.grad_rot.ptr, y_lo, y_hi, 1 if i else 0))
+            self.ctx.end_fork()
             self._acc_parts.append((ws, n))
         self.ctx.join()
         self._accumulated = True

@@ -679,14 +679,6 @@ def reconstruct_ptychography(
                 else:
                     optimizable_params[k_] = restored_params[k_]
 
-    if n_ranks == 1 and builtin_model and not is_multi_dist and not rool and fused and opt_kind == 'adam' and \
-            os.environ.get('ADM_PENDING_ROTATION', '0') == '1':
-        # opt-in (ADM_PENDING_ROTATION=1), one rank: the Adam update is left pending at the end of a minibatch; the next rotation
-        # applies it on the fly to the voxels it gathers and the update proper runs on the side stream beside the next multislice
-        # launch (same bits).  Measured SLOWER: every object voxel is gathered ~4 times, so the rotation evaluates Adam 4 times
-        # per voxel and reads four arrays instead of one (step 2.14 -> 2.21 ms; profiles/README.md round 3)
-        state.pending_rotation = True
-        forward_model.pending_update = state.pending_update
     diff = Differentiator()
     calculate_loss = forward_model.get_loss_function()
     diff.create_loss_node(calculate_loss, opt_args_ls)

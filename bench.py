@@ -30,7 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-CHASE = os.environ.get('ADM_CHASE', '0') == '1'      # A/B switch of the chased overlap-add (opt-in, like the driver: measured slower, profiles/README.md)
 
 
 def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
@@ -224,7 +223,7 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
             t0 = _t.perf_counter()
         it = r % len(tables)
         eng.set_batch(pos, tgt)
-        eng.rotate(state.obj, tables[it], None, pending=state.pending_update())
+        eng.rotate(state.obj, tables[it], None)
         ctx.fork()
         eng.flush_loss_copy()
         state.finish_update()
@@ -235,7 +234,6 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         eng.multislice_overlapped(probe, grad_scale=2.0 / (mb * Py * Px))     # full rounds | overlap-add beside the last round
         e1.record()
         eng.rotate_adjoint(state.grad, tables[it], None)
-        # (first = everything: with one rank the whole update stays pending for the next rotation, see the main loop)
         state.exchange_and_update('adam', r, {'step_size': cfg['learning_rate']}, first=(0, state.n))
         # as in the main loop and the driver: the loss of step r is read back after step r+1 has been queued
         token = eng.loss_async(last=mb)
@@ -416,7 +414,6 @@ def main():
             m_.zero_()
 
     reset_state()
-    state.pending_rotation = (not use_dist) and os.environ.get('ADM_PENDING_ROTATION', '0') == '1'      # like the driver: opt-in, measured slower
     probe = ctx.array(W.probe_array(cfg))
     n_theta_used = max(2, min(8, args.steps + args.warmup))
     thetas = np.linspace(cfg['theta_st'], cfg['theta_end'], cfg['n_theta'], dtype='float32')[:: cfg['n_theta'] // n_theta_used][:n_theta_used]
@@ -478,7 +475,7 @@ def main():
         # the multislice chain, which occupies `minibatch` of the 256 CUs, runs on the main stream
         eng.set_batch(pos, targets[(it, int(ind[0]))])
         yr = eng.y_footprint(pos)
-        eng.rotate(state.obj, tables[it], yr, pending=state.pending_update())     # (one rank: applies the pending Adam update on the fly)
+        eng.rotate(state.obj, tables[it], yr)
         ctx.fork()
         eng.flush_loss_copy()       # the previous step's loss read-back, off the main stream
         state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
@@ -489,15 +486,11 @@ def main():
         evs = ev_ms[k & 1] if timed else None
         if timed:
             evs[0].record()
-        if CHASE:
-            eng.multislice_chased(probe)      # the overlap-add chases the reverse sweep on the side stream
-        else:
-            eng.multislice(probe, accumulate=False)
+        eng.multislice(probe, accumulate=False)
         if timed:
             evs[1].record()
         ctx.join()
-        if not CHASE:
-            eng.accumulate_tiles()
+        eng.accumulate_tiles()
         eng.rotate_adjoint(state.grad, tables[it], yr)
         # update the y-planes the next minibatch reads first; the rest of the Adam pass overlaps the next kernel
         # (several ranks: the planes the next minibatches of ALL ranks read are gathered first, the rest of the all-gather

@@ -288,17 +288,6 @@ int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, size_t worksp
  * two calls is the caller's (adm_ctx_join).  No reference counterpart: autograd's index bookkeeping (adorym/forward_model.py:313-331). */
 int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
                          const int32_t* pos_host, int win_y_lo, int win_y_hi, int add);
-/* adm_multislice_fwd_adj(want_grad = 1) + adm_tile_grad_accumulate_part in one call, with the overlap-add CHASING the launch:
- * the reverse sweep reports its progress per chunk of 32 slices, and a small persistent kernel on the context's side stream
- * overlap-adds every chunk as soon as all positions have passed it -- beside the rest of the launch instead of behind it.  Same
- * sums in the same order (bit-identical to the two separate calls).  Call on the main stream; adm_ctx_join() before the first
- * consumer of grad_rot.  Kernel variants without progress signals (several probe modes, real_imag, binning, generic sizes, no
- * transmission cache) run the two steps one after the other on the main stream.  Replaces the same reference code as the two
- * calls it fuses (adorym/forward_model.py:313-375, adorym/wrappers.py:322). */
-int adm_multislice_fwd_adj_chased(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch,
-                                  const float* target, float* grad_probe, float* pred, float* loss_sum, float grad_scale,
-                                  void* workspace, size_t workspace_bytes, const int32_t* pos_host, float* grad_rot,
-                                  int win_y_lo, int win_y_hi, int add);
 /* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
  * (the overlap-add then dropped contributions; use smaller batches). */
 int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);
@@ -348,14 +337,6 @@ typedef struct adm_small_param {
     uint64_t pin_n;
 } adm_small_param;
 int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, int count, int i_batch, double b1, double b2, double eps);
-/* adm_rotate_fwd of an object whose Adam update is still PENDING: every gathered voxel is updated on the fly from (obj, grad, m, v)
- * with adm_adam_step's arithmetic (same bits: one shared device function, contraction off) and nothing is written back; m, v and
- * mask are indexed like obj (whole arrays).  The optimiser launch proper can then run later -- on the side stream, beside the
- * multislice launch -- instead of between the back-rotation and the rotation of the next minibatch: adm_adam_step +
- * adm_rotate_fwd (adorym/optimizers.py:309-318 + adorym/util.py:536-552) with one launch and one dependency gap less on the chain. */
-int adm_rotate_fwd_pending_adam(adm_plan* plan, const float* obj, const float* grad, const float* m, const float* v, int i_batch,
-                                double step_size, double b1, double b2, double eps, int flags, const float* mask,
-                                const uint16_t* coords, float* obj_rot, int y_lo, int y_hi);
 /* GDOptimizer.apply_gradient (adorym/optimizers.py:440-464); step_size already scheduled by the host */
 int adm_gd_step(adm_ctx* ctx, float* x, const float* g, size_t lo, size_t hi, double step_size, int flags,
                 const float* mask);
