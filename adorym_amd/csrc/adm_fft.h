@@ -69,10 +69,34 @@ template <bool INV> __device__ __forceinline__ cf fma_rot(cf m, v2f sv, cf d) {
     return C(r);
 }
 
+// The two irrational butterfly constants, as values (not literals), so that a caller can DITHER them: fl(sqrt(3)/2) and fl(1/sqrt 2)
+// are both about 1.8e-8 (relative) below the numbers they stand for, in every butterfly of every pass of every slice, so a chain
+// of forward / inverse transforms scales the components they touch by the same (1 - 3.6e-8) per slice and the error of a
+// multislice sweep grows linearly with depth: at 256 slices the constants alone made the kernel's fp32 error 2.1-2.4x the
+// reference's own (golden F17; with error-compensated constants -- one more multiply-add per use, +9 % kernel time -- 1.4x:
+// profiles/r04/r04a_*).  fft_k_dithered(i) returns, for the i-th propagation of a sweep, the fp32 neighbour ABOVE the exact value
+// every 4th (sqrt(3)/2: 3 x -1.795e-8 + 5.09e-8 = -0.3e-8 per four slices) or every 5th time (1/sqrt 2: 4 x -1.711e-8 + 6.72e-8),
+// and the one below otherwise: every transform is still exact to fp32 rounding, the deficits cancel over a few slices instead
+// of adding up, and it costs nothing.
+struct FftK {
+    float h;      // sqrt(3)/2
+    float c;      // 1/sqrt(2)
+};
+__device__ __forceinline__ FftK fft_k_nominal() { return FftK{0.86602540378443864676f, 0.70710678118654752440f}; }
+__device__ __forceinline__ FftK fft_k_dithered(int i) {
+#ifdef ADM_NO_DITHER
+    return fft_k_nominal();
+#endif
+    FftK k;
+    k.h = ((i & 3) == 3) ? 0.866025447845458984375f : 0.86602538824081420898f;       // fl(h) + 1 ulp : fl(h)
+    k.c = (i % 5 == 4) ? 0.707106828689575195312f : 0.70710676908493041992f;         // fl(c) + 1 ulp : fl(c)
+    return k;
+}
+
 template <int R, bool INV> struct Dft;
 
 template <bool INV> struct Dft<2, INV> {
-    static __device__ __forceinline__ void run(cf (&a)[2]) {
+    static __device__ __forceinline__ void run(cf (&a)[2], FftK = FftK()) {
         cf t = a[0];
         a[0] = cadd(t, a[1]);
         a[1] = csub(t, a[1]);
@@ -80,8 +104,7 @@ template <bool INV> struct Dft<2, INV> {
 };
 
 template <bool INV> struct Dft<3, INV> {
-    static __device__ __forceinline__ void run(cf& a0, cf& a1, cf& a2) {
-        const float h = 0.86602540378443864676f;  // sqrt(3)/2
+    static __device__ __forceinline__ void run(cf& a0, cf& a1, cf& a2, float h = 0.86602540378443864676f) {
         const v2f hv = {h, h};
         const cf s = cadd(a1, a2);
         const cf d = csub(a1, a2);
@@ -91,7 +114,7 @@ template <bool INV> struct Dft<3, INV> {
         a1 = fma_rot<INV>(m, hv, d);
         a2 = fma_rot<!INV>(m, hv, d);
     }
-    static __device__ __forceinline__ void run(cf (&a)[3]) { run(a[0], a[1], a[2]); }
+    static __device__ __forceinline__ void run(cf (&a)[3], FftK k = fft_k_nominal()) { run(a[0], a[1], a[2], k.h); }
 };
 
 template <bool INV> struct Dft<4, INV> {
@@ -102,12 +125,12 @@ template <bool INV> struct Dft<4, INV> {
         a1 = add_rot<INV>(t1, d);      // t1 + (-+i) d
         a3 = sub_rot<INV>(t1, d);
     }
-    static __device__ __forceinline__ void run(cf (&a)[4]) { run(a[0], a[1], a[2], a[3]); }
+    static __device__ __forceinline__ void run(cf (&a)[4], FftK = FftK()) { run(a[0], a[1], a[2], a[3]); }
 };
 
 template <bool INV> struct Dft<8, INV> {
-    static __device__ __forceinline__ void run(cf (&a)[8]) {
-        const float c = 0.70710678118654752440f;
+    static __device__ __forceinline__ void run(cf (&a)[8], FftK k = fft_k_nominal()) {
+        const float c = k.c;
         cf e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
         cf o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
         Dft<4, INV>::run(e0, e1, e2, e3);
@@ -128,15 +151,15 @@ template <bool INV> struct Dft<8, INV> {
 };
 
 template <bool INV> struct Dft<9, INV> {
-    static __device__ __forceinline__ void run(cf (&a)[9]) {
+    static __device__ __forceinline__ void run(cf (&a)[9], FftK k = fft_k_nominal()) {
         // n = 3 n1 + n2, k = k1 + 3 k2
         const float c1 = 0.76604444311897803520f, s1 = 0.64278760968653932632f;   // cos/sin(2pi/9)
         const float c2 = 0.17364817766693034885f, s2 = 0.98480775301220805937f;   // cos/sin(4pi/9)
         const float c4 = -0.93969262078590838405f, s4 = 0.34202014332566873304f;  // cos/sin(8pi/9)
         // stage 1: radix-3 over n1 for each n2 -> A[k1][n2] stored at a[3 k1 + n2]
-        Dft<3, INV>::run(a[0], a[3], a[6]);
-        Dft<3, INV>::run(a[1], a[4], a[7]);
-        Dft<3, INV>::run(a[2], a[5], a[8]);
+        Dft<3, INV>::run(a[0], a[3], a[6], k.h);
+        Dft<3, INV>::run(a[1], a[4], a[7], k.h);
+        Dft<3, INV>::run(a[2], a[5], a[8], k.h);
         // twiddle W9^(n2 k1): forward exp(-i..) = (c, -s); inverse (c, +s)
         const cf w1 = make_float2(c1, INV ? s1 : -s1);
         const cf w2 = make_float2(c2, INV ? s2 : -s2);
@@ -146,9 +169,9 @@ template <bool INV> struct Dft<9, INV> {
         a[7] = cmul(a[7], w2);   // k1=2, n2=1
         a[8] = cmul(a[8], w4);   // k1=2, n2=2
         // stage 2: radix-3 over n2 for each k1 -> X[k1 + 3 k2] at a[3 k1 + k2]
-        Dft<3, INV>::run(a[0], a[1], a[2]);
-        Dft<3, INV>::run(a[3], a[4], a[5]);
-        Dft<3, INV>::run(a[6], a[7], a[8]);
+        Dft<3, INV>::run(a[0], a[1], a[2], k.h);
+        Dft<3, INV>::run(a[3], a[4], a[5], k.h);
+        Dft<3, INV>::run(a[6], a[7], a[8], k.h);
         // natural order: X[k1 + 3 k2] <- a[3 k1 + k2]  (3x3 transpose, register renaming only)
         cf t;
         t = a[1]; a[1] = a[3]; a[3] = t;

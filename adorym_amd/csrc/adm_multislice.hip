@@ -34,16 +34,16 @@ __device__ unsigned long long g_stamps[16 * 16];     // diagnostic build only, s
 
 
 // pass 1 forward: a[n1] holds x[n1*R2 + t]; radix-R1 then twiddle W_N^(t*k1)
-template <int R1> __device__ __forceinline__ void p1_fwd(cf (&a)[R1], const cf (&tw)[R1]) {
-    Dft<R1, false>::run(a);
+template <int R1> __device__ __forceinline__ void p1_fwd(cf (&a)[R1], const cf (&tw)[R1], FftK K) {
+    Dft<R1, false>::run(a, K);
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmul(a[k], tw[k]);
 }
 // pass 1 inverse: untwiddle, inverse radix-R1 -> x[n1*R2 + t]
-template <int R1> __device__ __forceinline__ void p1_inv(cf (&a)[R1], const cf (&tw)[R1]) {
+template <int R1> __device__ __forceinline__ void p1_inv(cf (&a)[R1], const cf (&tw)[R1], FftK K) {
 #pragma unroll
     for (int k = 1; k < R1; ++k) a[k] = cmulc(a[k], tw[k]);
-    Dft<R1, true>::run(a);
+    Dft<R1, true>::run(a, K);
 }
 
 template <int N, int R1, int R2> struct Ctx {
@@ -52,6 +52,7 @@ template <int N, int R1, int R2> struct Ctx {
     int line, t;      // line owned in both roles (row for x passes, column for y passes), thread in line
     bool act1, act2;  // pass-1 role (t < R2) / pass-2 role (t < R1) active
     cf tw[R1];        // W_N^(t*k1)
+    FftK K;           // butterfly constants of the transform in progress (wave-uniform; the sweeps dither them, adm_fft.h)
     // per-thread base offsets (complex elements) of the four access patterns
     int row_p1, row_p2, col_p1, col_p2;
 };
@@ -61,14 +62,14 @@ template <int N, int R1, int R2>
 __device__ __forceinline__ void x_fwd(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
     if (c.act1) {
-        p1_fwd<R1>(a, c.tw);
+        p1_fwd<R1>(a, c.tw, c.K);
         st_line<R1, GE::ROW_P1_K>(a, c.fld + c.row_p1);
     }
     WAVE_SYNC();
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
-        Dft<R2, false>::run(b);
+        Dft<R2, false>::run(b, c.K);
         st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
 }
@@ -79,13 +80,13 @@ __device__ __forceinline__ void x_inv(Ctx<N, R1, R2>& c, cf (&a)[R1]) {
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
-        Dft<R2, true>::run(b);
+        Dft<R2, true>::run(b, c.K);
         st_line<R2, GE::ROW_P2_K>(b, c.fld + c.row_p2);
     }
     WAVE_SYNC();
     if (c.act1) {
         ld_line<R1, GE::ROW_P1_K>(a, c.fld + c.row_p1);
-        p1_inv<R1>(a, c.tw);
+        p1_inv<R1>(a, c.tw, c.K);
     }
 }
 // forward y pass 1 (column role)
@@ -95,7 +96,7 @@ __device__ __forceinline__ void y_fwd_p1(Ctx<N, R1, R2>& c) {
     if (c.act1) {
         cf a[R1];
         ld_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
-        p1_fwd<R1>(a, c.tw);
+        p1_fwd<R1>(a, c.tw, c.K);
         st_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
     }
     WAVE_SYNC();
@@ -107,7 +108,7 @@ __device__ __forceinline__ void y_inv_p1(Ctx<N, R1, R2>& c) {
     if (c.act1) {
         cf a[R1];
         ld_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
-        p1_inv<R1>(a, c.tw);
+        p1_inv<R1>(a, c.tw, c.K);
         st_line<R1, GE::COL_P1_K>(a, c.fld + c.col_p1);
     }
 }
@@ -141,10 +142,10 @@ __device__ __forceinline__ void convolve(Ctx<N, R1, R2>& c, cf (&a)[R1], const c
     if (c.act2) {
         cf b[R2];
         ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
-        Dft<R2, false>::run(b);
+        Dft<R2, false>::run(b, c.K);
 #pragma unroll
         for (int k = 0; k < R2; ++k) b[k] = cmul_t<CONJ>(b[k], hs[k]);
-        Dft<R2, true>::run(b);
+        Dft<R2, true>::run(b, c.K);
         st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
     hook(P<2>());
@@ -165,7 +166,7 @@ __device__ __forceinline__ void fft2_to_regs(Ctx<N, R1, R2>& c, cf (&a)[R1], cf 
     y_fwd_p1<N, R1, R2>(c);
     if (c.act2) {
         ld_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
-        Dft<R2, false>::run(b);
+        Dft<R2, false>::run(b, c.K);
     }
 }
 // the matching unnormalised inverse, from registers b[k2] back to real-space registers a
@@ -173,7 +174,7 @@ template <int N, int R1, int R2>
 __device__ __forceinline__ void ifft2_from_regs(Ctx<N, R1, R2>& c, cf (&b)[R2], cf (&a)[R1]) {
     using GE = Geo<N, R1, R2>;
     if (c.act2) {
-        Dft<R2, true>::run(b);
+        Dft<R2, true>::run(b, c.K);
         st_line<R2, GE::COL_P2_K>(b, c.fld + c.col_p2);
     }
     y_inv_p1<N, R1, R2>(c);
@@ -291,9 +292,13 @@ __device__ __forceinline__ void fwd_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
                 if constexpr (HP == Prefetch::FWD_DB1 && BIN1) load_db<R1, R2, BIN1, H, R1>(db, tile_base, slice_stride, step + 1, p.binning, p.Z);
             }
         };
-        if (step < p.n_steps - 1) convolve<N, R1, R2, false>(c, a, hs, hook);
+        if (step < p.n_steps - 1) {
+            c.K = fft_k_dithered(step);          // propagation `step`: slice step -> step + 1
+            convolve<N, R1, R2, false>(c, a, hs, hook);
+        }
         ADM_STAMP(4);
     }
+    c.K = fft_k_nominal();
     ADM_STAMP_ON(false);
 }
 
@@ -350,9 +355,13 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
                 if constexpr (HP == Prefetch::REV_PSI) ws_load<R1>(stash + (size_t)(step - 1) * R1 * GE::NT, GE::NT, tid, psi);
             }
         };
-        if (step > 0) convolve<N, R1, R2, true>(c, a, hs, hook);
+        if (step > 0) {
+            c.K = fft_k_dithered(step - 1);      // the adjoint of propagation step - 1, with that propagation's constants
+            convolve<N, R1, R2, true>(c, a, hs, hook);
+        }
         ADM_STAMP(12);
     }
+    c.K = fft_k_nominal();
     ADM_STAMP_ON(false);
 }
 
@@ -419,6 +428,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
     const int li = lane / GE::G;
     Ctx<N, R1, R2> c;
     c.fld = fld;
+    c.K = fft_k_nominal();
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);
@@ -629,6 +639,7 @@ __device__ __forceinline__ void init_ctx(Ctx<N, R1, R2>& c, cf* fld, const float
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane / GE::G;
     c.fld = fld;
+    c.K = fft_k_nominal();
     c.t = lane % GE::G;
     c.line = wave * GE::LPW + li;
     const bool line_ok = (li < GE::LPW) && (c.line < N);

@@ -109,11 +109,20 @@ def test_rotate_out_of_loop_driver_matches_reference(tmp_path, run):
     e_us, e_ref = np.linalg.norm(x - x64), np.linalg.norm(x32 - x64)
     print('%s: |x-x64|/|update| = %.2e (reference fp32: %.2e)' % (run, e_us / upd, e_ref / upd))
     assert np.sqrt(np.mean((x[..., 0] - x64[..., 0]) ** 2)) < 1e-5
+    d = np.abs(x - x64)
     if run == 'immediate_reg':          # sign() gradients: a handful of voxels flip in any fp32 implementation
-        d = np.abs(x - x64)
         assert (d > 1e-6).mean() < 1e-3 and d.max() < 1e-4
     else:
-        assert e_us <= 3 * e_ref + 1e-4 * upd, (e_us, e_ref, upd)
+        # Adam's first steps move a voxel by ~ learning_rate * sign(g): a voxel whose gradient is at the rounding level of the
+        # arithmetic type is pushed either way (two fp32 implementations of the SAME algorithm -- this kernel's 2-D sweep and the
+        # alternating sweep of profiles/r04_alternating_sweep_experiment.patch -- differed in 23 of 65536 voxels here, one of them
+        # by 3.9e-6).  Such voxels are counted (a handful, each off by a few learning rates at most); everything else is held to
+        # the 3x rule.
+        lr = cases.ROOL_RUNS[run]['learning_rate']
+        flipped = d > 0.5 * lr
+        assert flipped.mean() < 1e-3 and d.max() < 1e-4, (flipped.sum(), d.max())
+        e_rest = np.linalg.norm((x - x64)[~flipped])
+        assert e_rest <= 3 * e_ref + 1e-4 * upd, (e_rest, e_ref, upd)
     assert np.allclose(st['losses'], g['losses_%s_64' % run], rtol=2e-4)
     # and it is NOT the in-loop result: the two modes differ by design (stale rotated object within an angle, resampled gradient)
     g6 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F6_e2e.npz'))
@@ -172,11 +181,11 @@ def test_reweighted_l1_real_imag_through_the_driver(tmp_path):
 
 # ------------------------------------------------------------------------------------------------ depth 256 vs the reference's own fp32
 def test_depth_256_against_the_references_own_fp32_error(A, ctx):
-    """VERDICT r2 (weak, parity): the forward bar for S >= 32 was argued, not pinned.  Golden F17 holds the REFERENCE's fp64
-    results at config 3's depth (P = 72, 256 slices, far field) and the reference's OWN fp32-vs-fp64 errors on the same inputs
-    (prediction 1.3e-5, loss 9.8e-5, gradient 6.4e-4): fp32 rounding of twiddles and transfer function is coherent from slice
-    to slice, so ANY fp32 chain drifts linearly with depth.  The kernel must be within 3x of the reference's own errors
-    (measured: prediction 2.7e-5)."""
+    """Golden F17 holds the REFERENCE's fp64 results at config 3's depth (P = 72, 256 slices, far field) and the reference's OWN
+    fp32-vs-fp64 errors on the same inputs (prediction 1.3e-5, loss 9.8e-5, gradient 6.4e-4): fp32 rounding of twiddles and transfer
+    function is coherent from slice to slice, so ANY fp32 chain drifts linearly with depth.  The kernel must be within 2x of the
+    reference's own errors.  Measured (round 4, dithered butterfly constants, adm_fft.h: fft_k_dithered): 1.00x / 0.82x / 0.93x;
+    with the nominal constants in every slice it was 2.11x / 2.40x / 2.31x (profiles/r04/r04d_*)."""
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F17_depth256.npz'))
     d = cases.depth256_inputs()
     P = d['P']
@@ -194,9 +203,9 @@ def test_depth_256_against_the_references_own_fp32_error(A, ctx):
     e_grad = rel(d_grad.get()[::4, ::4, ::4], g['grad_64_sample'])
     print('depth 256 vs reference fp64: pred %.2e (reference fp32 %.2e), loss %.2e (%.2e), grad %.2e (%.2e)'
           % (e_pred, float(g['ref32_pred_err']), e_loss, float(g['ref32_loss_err']), e_grad, float(g['ref32_grad_sample_err'])))
-    assert e_pred <= 3 * float(g['ref32_pred_err'])
-    assert e_loss <= 3 * float(g['ref32_loss_err'])
-    assert e_grad <= 3 * float(g['ref32_grad_sample_err'])
+    assert e_pred <= 2 * float(g['ref32_pred_err'])
+    assert e_loss <= 2 * float(g['ref32_loss_err'])
+    assert e_grad <= 2 * float(g['ref32_grad_sample_err'])
 
 
 @pytest.mark.parametrize('B', [300])
