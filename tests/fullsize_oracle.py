@@ -1,0 +1,62 @@
+"""CPU side of tests/test_gpu_fullsize.py: the fp64 / fp32 oracle runs of the full-size config-3 case, each in its own process so
+that they run side by side with each other and with the GPU (`python tests/fullsize_oracle.py OUT.npz immediate float64`).
+Test infrastructure only: the oracle is the checker, never the product.
+
+The oracle works on the slab [s0, s1) of y planes (cases.fullsize_inputs): planes are independent under the rotation, the data
+term is zero outside the footprint, and the regularisers' 1/V normalisation (V = the FULL object's voxel count,
+adorym/regularizers.py:30-46, util.py:1427-1440) is restored by scaling their weights with V_slab / V."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import numpy as np
+import cases
+from oracle import adorym_oracle as O
+
+
+def setup():
+    from adorym_amd.workloads import c3_config
+    from adorym_amd.util import initialize_probe
+    cfg = c3_config()
+    inp = cases.fullsize_inputs()
+    P = cases.FULLSIZE['P']
+    pr, pi = initialize_probe((P, P), **cfg['probe'])
+    probe = np.squeeze(pr) + 1j * np.squeeze(pi)
+    phys = O.Physics((P, P), cfg['energy_ev'], cfg['psize_cm'], free_prop_cm='inf')
+    return cfg, inp, probe, phys
+
+
+def measured(inp, probe, phys):
+    """|far field| of the truth slab at every position, fp64 -> [1, n_pos, P, P]"""
+    N = cases.FULLSIZE['N']
+    coords = O.rotation_coords((inp['s1'] - inp['s0'], N, N), inp['theta'], np.float64)
+    pos_s = np.round(inp['pos']).astype(int) - np.array([inp['s0'], 0])
+    rot = O.rotate_fwd(inp['truth_slab'], coords, np.float64)
+    out = []
+    for i in range(0, len(pos_s), 23):
+        tt, _ = O.extract_tiles(rot, pos_s[i:i + 23], probe.shape)
+        out.append(O.predict(tt, probe, phys, 'float64')[0])
+    return np.concatenate(out)[None]
+
+
+def run(scheme, dtype, prj=None):
+    cfg, inp, probe, phys = setup()
+    if prj is None:
+        prj = measured(inp, probe, phys)
+    N = cases.FULLSIZE['N']
+    s0, s1 = inp['s0'], inp['s1']
+    sc = (s1 - s0) / float(N)
+    pos_s = inp['pos'] - np.array([s0, 0.])
+    g = inp['guess'][s0:s1]
+    x = O.reconstruct(prj, (g[..., 0], g[..., 1]), probe, pos_s, np.array([inp['theta']], dtype='float32'), phys, n_epochs=1,
+                      minibatch_size=cfg['minibatch_size'], optimizer='adam', learning_rate=cfg['learning_rate'],
+                      alpha_d=cfg['alpha_d'] * sc, alpha_b=cfg['alpha_b'] * sc, gamma=cfg['gamma'] * sc, update_scheme=scheme, dtype=dtype)
+    return x
+
+
+if __name__ == '__main__':
+    out, scheme, dtype = sys.argv[1:4]
+    prj = np.load(sys.argv[4]) if len(sys.argv) > 4 else None
+    np.save(out, run(scheme, dtype, prj))

@@ -199,3 +199,46 @@ def c5mini_inputs():
     affine_true = np.array([[[1., 0, 0], [0, 1., 0]], [[1.02, 0.01, 0.03], [-0.01, 0.99, -0.02]], [[0.98, 0.0, -0.04], [0.015, 1.01, 0.02]]])
     dists_guess = np.array(c['dists_cm']) * np.array([1.0, 1.03, 0.97])
     return dict(truth=(mag_t, ph_t), guess=(guess_mag, guess_ph), affine_true=affine_true, dists_guess=dists_guess)
+
+
+# ---------------------------------------------------------------- full-size config 3 through the driver (tests/test_gpu_fullsize.py)
+FULLSIZE = dict(N=256, P=72, rows=(10, 13), theta=0.4, margin=4)
+
+
+def smooth_field_fast(shape, seed, cutoff=0.12):
+    """Band-limited random field in [0, 1] like smooth_field(), synthesised directly in the (half) spectrum: one inverse real
+    transform instead of a forward and an inverse complex one -- 256^3 in about a second."""
+    import scipy.fft as sfft
+    r = rng(seed)
+    f = np.zeros(shape[:-1] + (shape[-1] // 2 + 1,), dtype=np.complex64)
+    k = [max(1, int(np.ceil(cutoff * n))) for n in shape]
+    grids = np.meshgrid(np.fft.fftfreq(shape[0])[np.r_[0:k[0] + 1, -k[0]:0]], np.fft.fftfreq(shape[1])[np.r_[0:k[1] + 1, -k[1]:0]],
+                        np.fft.rfftfreq(shape[2])[:k[2] + 1], indexing='ij')
+    keep = np.sqrt(sum(g ** 2 for g in grids)) <= cutoff
+    blk = (r.standard_normal(keep.shape) + 1j * r.standard_normal(keep.shape)) * keep
+    f[np.ix_(np.r_[0:k[0] + 1, -k[0]:0], np.r_[0:k[1] + 1, -k[1]:0], np.arange(k[2] + 1))] = blk.astype(np.complex64)
+    a = sfft.irfftn(f, s=shape, workers=-1).astype(np.float64)
+    a -= a.min()
+    return a / a.max()
+
+
+def fullsize_inputs():
+    """BASELINE config 3 at its own size -- 256^3 object, 72 x 72 probe, the 23 x 23 scan with 12-pixel steps, minibatch 32,
+    L1 + TV, Adam with the configuration's learning rate -- on three rows of the scan (69 positions = three minibatches of 32
+    after the reference's random top-up) at one angle.  The object is smooth and non-zero EVERYWHERE (the deferred part of the
+    split Adam pass works on all planes).  A rotation about axis 0 never mixes y planes, so the CPU checker works on the slab of
+    planes the positions touch plus `margin` planes either side (the TV stencil reaches one plane further with every update);
+    the measured data are the fp64 forward model of a second smooth object on that slab."""
+    F = FULLSIZE
+    N, P = F['N'], F['P']
+    ys = np.arange(23) * 12 - 36
+    allpos = np.array([(y, x) for y in ys for x in ys], dtype=float)
+    pos = allpos[F['rows'][0] * 23:F['rows'][1] * 23]
+    y_lo, y_hi = int(pos[:, 0].min()), int(pos[:, 0].max()) + P
+    s0, s1 = y_lo - F['margin'], y_hi + F['margin']
+    guess = np.stack([3e-4 * smooth_field_fast((N, N, N), 271), 1.5e-5 * smooth_field_fast((N, N, N), 272)], -1)
+    shp = (s1 - s0, N, N)
+    # (the truth is related to the guess, as in a reconstruction under way: the data term then pulls on every footprint voxel)
+    truth_slab = np.stack([3e-4 * smooth_field_fast(shp, 275), 1.5e-5 * smooth_field_fast(shp, 276)], -1)
+    truth_slab = 0.6 * guess[s0:s1] + 0.4 * truth_slab
+    return dict(pos=pos, y_lo=y_lo, y_hi=y_hi, s0=s0, s1=s1, guess=guess, truth_slab=truth_slab, theta=np.float32(F['theta']))

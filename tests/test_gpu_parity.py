@@ -452,22 +452,28 @@ def test_real_imag_overhanging_tiles_vs_oracle(A, ctx):
     assert rel(d_grad.get(), g_o) < 1e-4
 
 
-@pytest.mark.parametrize('theta', [0.4, 0.7953982])
-def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta):
+@pytest.mark.parametrize('theta,full', [(0.4, True), (0.7953982, False)])
+def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
     """BASELINE's config 3 at FULL size on the GPU -- 256^3 object, 72x72 probe, 256 slices, rotation by theta (0.4 rad
     and a 45-degree-class angle), L1 + TV -- against the fp64 oracle, gradient judged on the footprint planes under the
     3x rule measured against the REFERENCE-STRUCTURED fp32 restatement (oracle/torch_structured.py, bit-identical to
     the reference's PyTorch-CPU path).  Rotation about axis 0 acts on every y plane separately, so the CPU checkers work
-    on the slab of planes the minibatch touches (+1 plane each side for the TV stencil); the minibatch is 6 positions of
-    the scan (two rows of the 23x23 grid) instead of 32 to keep the fp64 / autograd CPU work near a minute per angle --
-    the batch size only enters through the 2/(B*Py*Px) factor."""
+    on the slab of planes the minibatch touches (+1 plane each side for the TV stencil).  At 0.4 rad the minibatch is a full
+    one: 32 positions of the scan, two rows of the 23x23 grid, 16 of each (110 s of CPU checkers on the GPU box; measured
+    gradient error 7.3e-4 against 2.6e-3 for the reference's own fp32 arithmetic); at the 45-degree-class angle 6 positions of
+    the same rows (the batch size only enters through the 2/(B*Py*Px) factor).  Three consecutive minibatches and a 'per angle'
+    update through the driver, object against object: tests/test_gpu_fullsize.py."""
     from oracle import torch_structured as T
     from adorym_amd.util import rotation_lookup
     N, P = 256, 72
     theta = np.float32(theta)
     ys = np.arange(23) * 12 - 36
     allpos = np.array([(y, x) for y in ys for x in ys])
-    sel = [11 * 23 + 0, 11 * 23 + 7, 11 * 23 + 22, 12 * 23 + 3, 12 * 23 + 12, 12 * 23 + 19]      # rows y = 96 and 108, x from -36 to 228
+    if full:
+        sel = [11 * 23 + i for i in (0, 1, 2, 4, 5, 7, 8, 10, 11, 13, 14, 16, 17, 19, 21, 22)] + \
+              [12 * 23 + i for i in (0, 1, 3, 4, 6, 7, 9, 10, 12, 13, 15, 16, 18, 19, 20, 22)]  # rows y = 96 and 108, x from -36 to 228
+    else:
+        sel = [11 * 23 + 0, 11 * 23 + 7, 11 * 23 + 22, 12 * 23 + 3, 12 * 23 + 12, 12 * 23 + 19]
     pos = allpos[sel]
     y_lo, y_hi = int(pos[:, 0].min()), int(pos[:, 0].max()) + P          # footprint planes [96, 180)
     s0, s1 = y_lo - 1, y_hi + 1                                           # slab for the CPU checkers
