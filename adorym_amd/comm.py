@@ -184,10 +184,11 @@ class RcclComm(object):
         self.ctx = None
 
     def attach(self, ctx):
-        """Create the RCCL communicators of this rank on ``ctx`` (collective over all ranks).  Failure-symmetric: every
-        step that can fail on one rank only is followed by an agreement over the gloo group, so either every rank returns
+        """Create the RCCL communicators of this rank on ``ctx`` (collective over all ranks).  Every step that can fail on one
+        rank only WITHOUT blocking the others is followed by an agreement over the gloo group, so that either every rank returns
         with working communicators or every rank raises the same RuntimeError (callers such as bench.py then fall back
-        TOGETHER).  Order: (1) each rank probes its own librccl (adm_comm_available) -> agree; (2) rank 0 creates the
+        TOGETHER).  Not covered: a rank that dies INSIDE ncclCommInitRank leaves its peers blocked in theirs until RCCL's own
+        timeout -- a rendezvous cannot be made symmetric from one side.  Order: (1) each rank probes its own librccl (adm_comm_available) -> agree; (2) rank 0 creates the
         unique ids and ALWAYS broadcasts (None on failure) -> all ranks see the same outcome; (3) adm_comm_init (+ the
         side-stream communicator) -> agree, and tear down on disagreement."""
         import ctypes as C

@@ -45,7 +45,7 @@ struct adm_plan {
     bool trans_only;       // adm_plan_set_transmission_cache(plan, 2): adm_rotate_fwd writes ONLY the transmissions (obj_rot is an identity, not data)
     // adm_tile_cover_build: the cover lists in workspace `ws` are current for (pos, batch, window); a few entries, so that every
     // round of a batch launched in parts can have its lists built ahead
-    struct CoverKey { const void* ws; const void* pos; int batch, row0, nrows; } cover_keys[4];
+    struct CoverKey { const void* ws; const void* pos; int batch, row0, nrows; unsigned long long fp; } cover_keys[4];
 };
 
 namespace adm {

@@ -882,13 +882,23 @@ extern "C" int adm_plan_set_transmission_cache(adm_plan* plan, int on) {
         plan->trans_only = false;
         return ADM_OK;
     }
-    plan->trans_only = (on == 2);
-    if (d.unknown_type != 0 || d.binning != 1)
+    if (d.unknown_type != 0 || d.binning != 1)      // (validated first: a refused call leaves the plan as it was)
         return fail(ADM_ERR_UNSUPPORTED, "adm_plan_set_transmission_cache: needs unknown_type delta_beta and binning 1");
-    if (plan->trans_dev) return ADM_OK;
-    ADM_HIP(hipMalloc((void**)&plan->trans_dev, (size_t)d.obj_z * plan->Yp * plan->Xp * sizeof(float2)));
-    plan->trans_src = nullptr;
-    return transmission_fill(plan, nullptr, 0, plan->Yp);      // vacuum everywhere: the pads keep it forever
+    if (!plan->trans_dev) {
+        float2* t = nullptr;
+        ADM_HIP(hipMalloc((void**)&t, (size_t)d.obj_z * plan->Yp * plan->Xp * sizeof(float2)));
+        plan->trans_dev = t;
+        plan->trans_src = nullptr;
+        const int rc = transmission_fill(plan, nullptr, 0, plan->Yp);      // vacuum everywhere: the pads keep it forever
+        if (rc) {
+            (void)hipFree(t);
+            plan->trans_dev = nullptr;
+            plan->trans_only = false;
+            return rc;
+        }
+    }
+    plan->trans_only = (on == 2);
+    return ADM_OK;
 }
 
 extern "C" int adm_transmission_refresh(adm_plan* plan, const float* obj_rot, int y_lo, int y_hi) {
@@ -987,19 +997,26 @@ static int tile_geom(adm_plan* plan, int batch, const int32_t* pos_host, int win
 
 // what adm_tile_cover_build has built and nobody has used yet (a workspace holds one set of lists: a new build for the same
 // workspace replaces its entry)
-static void cover_key_put(adm_plan* plan, const void* ws, const void* pos, int batch, const TileGeom& g) {
+// (the key includes a fingerprint of the positions THEMSELVES: the device position buffer is reused from minibatch to minibatch, so
+// its address says nothing about its contents)
+static unsigned long long pos_fingerprint(const int32_t* pos_host, int batch) {
+    unsigned long long h = 1469598103934665603ull;                     // FNV-1a over the (y, x) pairs
+    for (int i = 0; i < 2 * batch; ++i) { h ^= (unsigned)pos_host[i]; h *= 1099511628211ull; }
+    return h;
+}
+static void cover_key_put(adm_plan* plan, const void* ws, const void* pos, const int32_t* pos_host, int batch, const TileGeom& g) {
     int slot = 0;
     for (int i = 0; i < 4; ++i) {
         if (plan->cover_keys[i].ws == ws) { slot = i; break; }
         if (!plan->cover_keys[i].ws) slot = i;
     }
-    plan->cover_keys[slot] = {ws, pos, batch, g.row0, g.nrows};
+    plan->cover_keys[slot] = {ws, pos, batch, g.row0, g.nrows, pos_fingerprint(pos_host, batch)};
 }
-static bool cover_key_take(adm_plan* plan, const void* ws, const void* pos, int batch, const TileGeom& g) {
+static bool cover_key_take(adm_plan* plan, const void* ws, const void* pos, const int32_t* pos_host, int batch, const TileGeom& g) {
     for (int i = 0; i < 4; ++i) {
         adm_plan::CoverKey& k = plan->cover_keys[i];
         if (k.ws == ws) {
-            const bool ok = k.pos == pos && k.batch == batch && k.row0 == g.row0 && k.nrows == g.nrows;
+            const bool ok = k.pos == pos && k.batch == batch && k.row0 == g.row0 && k.nrows == g.nrows && k.fp == pos_fingerprint(pos_host, batch);
             k.ws = nullptr;
             return ok;
         }
@@ -1034,7 +1051,7 @@ extern "C" int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t work
     if (rc) return rc;
     rc = cover_build(plan, workspace, pos, batch, g);
     if (rc) return rc;
-    cover_key_put(plan, workspace, pos, batch, g);
+    cover_key_put(plan, workspace, pos, pos_host, batch, g);
     return ADM_OK;
 }
 
@@ -1046,7 +1063,7 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     TileGeom g;
     int rc = tile_geom(plan, batch, pos_host, win_y_lo, win_y_hi, add, g);
     if (rc) return rc;
-    const bool prebuilt = cover_key_take(plan, workspace, pos, batch, g);     // one use: the position buffer may be rewritten later
+    const bool prebuilt = cover_key_take(plan, workspace, pos, pos_host, batch, g);     // one use: the position buffer may be rewritten later
     if (!prebuilt) {
         rc = cover_build(plan, workspace, pos, batch, g);
         if (rc) return rc;

@@ -66,12 +66,15 @@ def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_nam
 
     Every rank writes its files from its own helper thread, so a crash can leave files of different minibatches side by
     side.  To make that detectable (not part of the reference's format): every file goes through a temporary name +
-    os.replace, each rank writes stamp_rank_{r}.txt = (epoch, batch) AFTER its own files, and rank 0 writes checkpoint.txt
-    last; restore_checkpoint() only accepts a checkpoint whose stamps all equal checkpoint.txt."""
+    os.replace; each rank first INVALIDATES its stamp_rank_{r}.txt (-1, -1), then replaces its data files, then writes the
+    stamp (epoch, batch), and rank 0 writes checkpoint.txt last; restore_checkpoint() only accepts a checkpoint whose stamp
+    equals checkpoint.txt -- so a crash between two of one rank's own files (new object, old moments, old counter) is refused
+    like a crash between two ranks' saves."""
     import pickle
     path = os.path.join(output_folder, 'checkpoint')
     os.makedirs(path, exist_ok=True)
     stamp = np.array([i_epoch, i_batch])
+    _atomic_write(os.path.join(path, 'stamp_rank_{}.txt'.format(rank)), lambda f_: np.savetxt(f_, np.array([-1, -1]), fmt='%d'))
     if rank == 0:
         _atomic_write(os.path.join(path, 'obj_checkpoint.npy'), lambda f_: np.save(f_, obj_array))
     if len(moments) > 0:
@@ -102,8 +105,9 @@ def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks
     if os.path.exists(fs):
         st = [int(i) for i in np.loadtxt(fs)]
         if st != [i_epoch, i_batch]:
-            raise ValueError('torn checkpoint: rank %d wrote its files for (epoch, batch) = %s, checkpoint.txt says %s'
-                             % (rank, tuple(st), (i_epoch, i_batch)))
+            raise ValueError('torn checkpoint: rank %d %s, checkpoint.txt says %s'
+                             % (rank, 'was interrupted in the middle of a save' if st == [-1, -1] else
+                                'wrote its files for (epoch, batch) = %s' % (tuple(st),), (i_epoch, i_batch)))
     obj = np.load(os.path.join(path, 'obj_checkpoint.npy'))
     if obj_shape is not None and tuple(obj.shape) != tuple(obj_shape):
         raise ValueError('obj_checkpoint.npy has shape %s, expected %s' % (obj.shape, tuple(obj_shape)))
@@ -703,6 +707,7 @@ def reconstruct_ptychography(
     i_epoch = starting_epoch
     _ckpt_thread = [None]
     pending_log = [None]
+    straddle_warned = [False]
 
     def flush_log():
         if pending_log[0] is None:
@@ -761,6 +766,14 @@ def reconstruct_ptychography(
             # it).  Here the object is ONE sharded copy, so the step counter must be the same on every shard; the two rules
             # coincide whenever no global batch straddles angles (always in 'per angle' mode).
             is_last_batch_of_this_theta = i_batch == n_batch - 1 or ind_list_rand[i_batch + 1][0, 0] != ind_list_rand[i_batch][0, 0]
+            if n_ranks > 1 and rank == 0 and i_epoch == starting_epoch and not straddle_warned[0] and \
+                    len(np.unique(ind_list_rand[i_batch][:, 0])) > 1:
+                straddle_warned[0] = True
+                print_flush('  Note: this global batch holds positions of two angles.  adorym_amd keeps ONE optimiser step counter '
+                            'for the sharded object (decided on the angle the batch starts with); the reference keeps one per rank and '
+                            'its replicas drift apart in this case (INTEGRATION.md, "Deviations").  Use a position count that is a '
+                            'multiple of n_ranks * minibatch_size, or update_scheme="per angle", to reproduce a reference mpirun.',
+                            sto_rank, rank, **stdout_options)
             print_flush('  Current rank is processing angle ID {}.'.format(this_i_theta), sto_rank, rank, **stdout_options)
 
             # 'per angle': the minibatches of one angle see the same object, so they are fused into ONE launch

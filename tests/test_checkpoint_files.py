@@ -41,3 +41,29 @@ def test_reference_written_checkpoint_without_stamps_is_accepted(tmp_path):
     np.save(d / 'opt_obj_params_checkpoint.npy', np.zeros((2,) + obj.shape, np.float32))
     e, b, o, m, p = restore_checkpoint(str(tmp_path), 2, obj_shape=obj.shape)
     assert (e, b, p) == (2, 5, None) and np.array_equal(o, obj)
+
+
+def test_crash_inside_one_ranks_own_save_is_refused(tmp_path, monkeypatch):
+    """rank 0 dies after obj_checkpoint.npy has been replaced but before the moments, its stamp and checkpoint.txt are:
+    the old stamp and the old checkpoint.txt would still agree.  The stamp is invalidated BEFORE the first data file is
+    replaced, so the half-new checkpoint is refused."""
+    import adorym_amd.ptychography as PT
+    obj = np.zeros((2, 2, 2, 2), np.float32)
+    mom = [np.zeros(obj.size, np.float32), np.zeros(obj.size, np.float32)]
+    save_checkpoint(0, 10, str(tmp_path), obj, mom)
+    real = PT._atomic_write
+
+    def dying(path, writer):
+        if path.endswith('opt_obj_params_checkpoint.npy'):
+            raise KeyboardInterrupt('killed between two files of one save')
+        real(path, writer)
+
+    monkeypatch.setattr(PT, '_atomic_write', dying)
+    with pytest.raises(KeyboardInterrupt):
+        save_checkpoint(0, 20, str(tmp_path), obj + 1, mom)
+    monkeypatch.setattr(PT, '_atomic_write', real)
+    assert np.load(tmp_path / 'checkpoint' / 'obj_checkpoint.npy').max() == 1          # the object IS the new one
+    with pytest.raises(ValueError, match='middle of a save'):
+        restore_checkpoint(str(tmp_path), 2, obj_shape=obj.shape)
+    save_checkpoint(0, 30, str(tmp_path), obj + 2, mom)                                # the next complete save heals it
+    assert restore_checkpoint(str(tmp_path), 2, obj_shape=obj.shape)[:2] == (0, 30)
