@@ -186,7 +186,7 @@ def cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize):
     return time.perf_counter() - t1
 
 
-def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_groups, label, reps=3):
+def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_groups, label, reps=3, comm=None, rank=0, world=1):
     """Secondary figures (not `value`): steps whose global batch holds `n_groups` reference minibatches of ONE angle, fused
     into one launch so that every CU has work.  Two reference semantics give such a step:
       * update_scheme='per angle' (adorym/ptychography.py:1095-1099): the 17 minibatches of an angle (529 positions padded
@@ -195,12 +195,16 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         mean over its own minibatch, the gradients are SUMMED and every rank adds the regulariser term -- `virtual_ranks`
         R on one GPU is exactly that sum.
     One step = whole-object rotation + n_groups*32 positions fwd/adjoint + overlap-add + back-rotation + regulariser
-    gradient (x n_groups) + Adam."""
+    gradient (x n_groups) + Adam.
+    With `world` > 1 ranks every rank runs n_groups minibatches of ITS slice of each global batch (the reference's rank split,
+    :905-909), the gradients are reduce-scattered ONCE per step and the object gathered once: the regime with the fewest
+    exchanges per position.  Timed between barriers, maximum over ranks; `value` counts the positions of all ranks."""
     import time as _t
     mb = cfg['minibatch_size']
     n_pos = len(cfg['probe_pos'])
     B = n_groups * mb
-    ind = np.arange(B) % n_pos
+    # global batch j of the step = positions [j * mb * world, (j + 1) * mb * world) of the angle; rank r takes the r-th slice
+    ind = (np.arange(n_groups)[:, None] * mb * world + rank * mb + np.arange(mb)[None, :]).reshape(-1) % n_pos
     pos = cfg['probe_pos'][ind]
     Py, Px = cfg['probe_size']
     tgt = ctx.empty((B, Py, Px))
@@ -220,6 +224,8 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
                 loss = eng.loss_result(prev[0])
                 prev = None
             ctx.sync()
+            if comm is not None:
+                comm.barrier()
             t0 = _t.perf_counter()
         it = r % len(tables)
         eng.set_batch(pos, tgt)
@@ -244,11 +250,16 @@ def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_g
         prev = (token, r)
     loss = eng.loss_result(prev[0])
     kern.append(e_pairs[prev[1] & 1][0].elapsed_ms(e_pairs[prev[1] & 1][1]))
+    state.finish_update()
     ctx.sync()
+    if comm is not None:
+        comm.barrier()
     dt = (_t.perf_counter() - t0) / reps
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
     Y, X, Z = cfg['obj_size']
     alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
-    out = {'positions_per_step': B, 'value': B / dt, 'unit': 'probe-positions/s',
+    out = {'positions_per_step': B * world, 'positions_per_step_per_gpu': B, 'n_gpus': world, 'value': B * world / dt, 'unit': 'probe-positions/s',
            'ms_per_step': 1e3 * dt, 'fwd_adj_overlap_add_ms': float(np.mean(kern)),
            'fwd_adj_overlap_add_frac_of_hbm_peak': alg / (np.mean(kern) * 1e-3) / 1e9 / PEAK_HBM_GBS,
            'whole_step_frac_of_hbm_peak': alg / dt / 1e9 / PEAK_HBM_GBS, 'loss_last': loss}
@@ -341,9 +352,12 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help="weak: every rank runs --minibatch positions per step (global batch N x 32, the reference's `mpirun -n N`); "
                          "strong: ONE minibatch of --minibatch positions split over the ranks (N x 32/N)")
-    ap.add_argument('--overlap-gather', choices=('auto', '0', '1'), default='auto',
-                    help='N > 1: two-part object gather (planes the next minibatches read first, rest beside the next kernel); '
-                         'auto = check it bitwise against the plain all-gather on the running job, time both, keep the faster')
+    ap.add_argument('--overlap-gather', choices=('auto', '0', '1'), default='0',
+                    help='N > 1: two-part object gather (planes the next minibatches read first, rest beside the next kernel on a '
+                         'second communicator).  Default 0: the headline of a multi-GPU run uses the plain all-gather on ONE '
+                         'communicator -- nothing that has never run on real multi-GPU hardware sits in front of the measurement; '
+                         'auto = check the two-part gather bitwise against the plain one on the running job, time both, keep the '
+                         'faster (an experiment: ask for it explicitly)')
     args = ap.parse_args()
 
     import torch
@@ -370,6 +384,8 @@ def main():
     else:
         comm = C.RcclComm(device_index=local_rank)
     rank = comm.rank
+    if use_dist and args.overlap_gather == '0':
+        os.environ['ADM_COMM_AUX'] = '0'        # no side-stream communicator unless the two-part gather is asked for
     # libadm kernels and the RCCL collectives share one stream: the context's own (RcclComm) or torch's (TorchComm)
     ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
     comm_note = None
@@ -557,6 +573,14 @@ def main():
     phases = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()} if state.clock is not None else {}
     state.clock = None
 
+    # secondary leg on EVERY rank count: update_scheme='per angle' -- all minibatches of an angle fused, ONE exchange per step.
+    # (N > 1: the same two collectives on the same communicator as the headline loop that has just run.)
+    per_angle = None
+    if not args.no_per_angle and 'per_angle' in args.legs.split(',') and args.scaling == 'weak':
+        k_angle = -(-n_pos // (B * world))
+        per_angle = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle, {'update_scheme': 'per angle'},
+                                        comm=comm if use_dist else None, rank=rank, world=world)
+
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = B_global * args.steps / dt
@@ -588,12 +612,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
+        if per_angle is not None:
+            out['per_angle'] = per_angle
         if world == 1 and not args.no_per_angle:
             legs = args.legs.split(',')
-            k_angle = -(-n_pos // B)
-            if 'per_angle' in legs:
-                out['per_angle'] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle,
-                                                       {'update_scheme': 'per angle'})
             for R in (8, 16):
                 if 'vr%d' % R in legs:
                     out['virtual_ranks_%d' % R] = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, R,
