@@ -2,6 +2,7 @@
 # The evidence set of a round, in one go (run on the GPU box from the repo root):  tools/profile_round.sh r03a
 #   gpurun_out/<tag>_bench.json            the default `python bench.py` line
 #   gpurun_out/<tag>_stats/                rocprofv3 --kernel-trace --stats of the headline loop (kernel averages)
+#   gpurun_out/<tag>_kbench_B32/_B256_*    rocprofv3 --kernel-trace --stats of the multislice launch alone (tools/kbench.py)
 #   gpurun_out/<tag>_pmc_B32, _B256/       five --pmc passes each over tools/kbench.py (+ summary.json); traffic_latest.json refreshed
 #   gpurun_out/<tag>_timeline_*.txt        kernel timelines of the B=32 step, the per-angle step and the 16-virtual-rank step
 # Counters are collected in their own runs (no --pmc together with trace domains other than --kernel-trace).
@@ -14,6 +15,8 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-driver --no-per-angle > $ROOT/$OUT/${TAG}_stats.log 2>&1 )
 python tools/kstats.py $OUT/${TAG}_stats > $OUT/${TAG}_kernel_stats.txt 2>&1
 for B in 32 256; do
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_kbench_B${B}_stats -- python3 $ROOT/tools/kbench.py $B 8 > $ROOT/$OUT/${TAG}_kbench_B$B.log 2>&1 )
+  python tools/kstats.py $OUT/${TAG}_kbench_B${B}_stats > $OUT/${TAG}_kbench_B${B}_kernel_stats.txt 2>&1
   bash tools/pmc_sq.sh $OUT/${TAG}_pmc_B$B $B > $OUT/${TAG}_pmc_B$B.log 2>&1
 done
 python tools/traffic_update.py $OUT/${TAG}_pmc_B32 32 "profiles/${TAG}_pmc_B32.json" > $OUT/${TAG}_traffic.log 2>&1
