@@ -89,7 +89,6 @@ SIGNATURES = {
     'adm_rotation_csr_scratch_bytes': (_SZ, [_VP]),
     'adm_rotation_csr_build': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),
-    'adm_plan_set_lean_min_batch': (_I, [_VP, _I]),
     'adm_plan_set_transmission_cache': (_I, [_VP, _I]),
     'adm_transmission_refresh': (_I, [_VP, _VP, _I, _I]),
     'adm_plan_set_generic': (_I, [_VP, _I]),

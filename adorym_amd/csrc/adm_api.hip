@@ -213,10 +213,6 @@ static int upload_c(adm_ctx* ctx, const float* re, const float* im, size_t n, fl
     return ADM_OK;
 }
 
-// default of adm_plan_set_lean_min_batch: 0 = the two-workgroups-per-CU kernel (adm_ms_lean.hip) is opt-in; as measured in
-// round 2 (profiles/README.md) it does not beat the latency-oriented kernel at any batch size yet
-#define ADM_LEAN_MIN_BATCH_DEFAULT 0
-
 extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan** out) {
     if (!ctx || !desc || !out) return fail(ADM_ERR_INVALID, "adm_plan_create: null argument");
     const adm_plan_desc& d = *desc;
@@ -272,18 +268,6 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->reg_partial = nullptr;
     p->det_weight_dev = nullptr;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
-    {   // the throughput kernel reads H from a table folded along kx: exact mirror symmetry required
-        const int N = d.probe_x;
-        bool sym = tuned;
-        for (int ky = 0; ky < d.probe_y && sym; ++ky)
-            for (int kx = 1; kx < N; ++kx) {
-                const size_t i = (size_t)ky * N + kx, j = (size_t)ky * N + (N - kx);
-                if (d.h_re[i] != d.h_re[j] || d.h_im[i] != d.h_im[j]) { sym = false; break; }
-                if (d.det_mode == ADM_DET_FRESNEL && (d.hfree_re[i] != d.hfree_re[j] || d.hfree_im[i] != d.hfree_im[j])) { sym = false; break; }
-            }
-        p->h_sym = sym;
-        p->lean_min_batch = ADM_LEAN_MIN_BATCH_DEFAULT;
-    }
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
     for (int axis = 0; axis < 2 && !rc; ++axis) {
@@ -438,7 +422,7 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
         p.grad_probe = (float2*)((char*)workspace + ws_off_gprobe(plan, batch));
         p.gprobe_bstride = probe_elems;
     }
-    // cached slice transmissions: only for the buffer they were computed from (the two-per-CU kernel evaluates in the loop)
+    // cached slice transmissions: only for the buffer they were computed from
     const bool use_t = plan->trans_dev && plan->trans_src == (const void*)obj_rot && d.unknown_type == 0 && d.binning == 1;
     if (plan->trans_only && !use_t)
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: the plan keeps slice transmissions only (cache mode 2) and this obj_rot was not "
@@ -455,14 +439,8 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
             ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
         return ADM_OK;
     }
-    const bool lean = !plan->trans_only && plan->lean_min_batch > 0 && batch >= plan->lean_min_batch && plan->h_sym && !per_position && d.n_modes == 1 &&
-                      d.unknown_type == 0 && d.binning == 1 && ms_lean_supported(d.probe_x);
-    if (lean) {
-        ADM_HIP(ms_lean_launch(d.probe_x, p, batch, plan->ctx->stream));
-    } else {
-        if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
-        ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
-    }
+    if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
+    ADM_HIP(ms_launch(d.probe_x, p, batch, plan->ctx->stream));
     if (!per_position && grad_probe && want_grad)
         ADM_HIP(probe_grad_reduce(p.grad_probe, batch, probe_elems, (float2*)grad_probe, plan->ctx->stream));
     return ADM_OK;
@@ -473,12 +451,6 @@ extern "C" int adm_plan_set_generic(adm_plan* plan, int on) {
     const bool tuned = (plan->d.probe_y == plan->d.probe_x) && ms_threads_for(plan->d.probe_x) != 0;
     if (!on && !tuned) return fail(ADM_ERR_INVALID, "adm_plan_set_generic: this probe size has no tuned kernel");
     plan->generic = on != 0;
-    return ADM_OK;
-}
-
-extern "C" int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch) {
-    if (!plan || min_batch < 0) return fail(ADM_ERR_INVALID, "adm_plan_set_lean_min_batch: bad argument");
-    plan->lean_min_batch = min_batch;
     return ADM_OK;
 }
 

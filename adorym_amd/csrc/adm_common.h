@@ -38,8 +38,6 @@ struct adm_plan {
     float2* hs_dev;        // [Py*Px] H / (Py*Px), one rounding per element (generic kernel)
     float2* hfree_s_dev;   // same for the detector-plane Fresnel kernel, or nullptr
     float2* twid_y_dev;    // [Py] exp(-2 pi i j / Py)
-    bool h_sym;            // H(ky, kx) == H(ky, N - kx) for the slice and detector kernels (every get_kernel() output)
-    int lean_min_batch;    // batches of at least this many positions run the two-per-CU throughput kernel (0 = never)
     float2* trans_dev;     // [Z][Yp][Xp] slice transmissions of the voxels of trans_src, or nullptr (adm_plan_set_transmission_cache)
     const void* trans_src; // the obj_rot buffer trans_dev was last filled from (adm_rotate_fwd / adm_transmission_refresh)
     bool trans_only;       // adm_plan_set_transmission_cache(plan, 2): adm_rotate_fwd writes ONLY the transmissions (obj_rot is an identity, not data)
@@ -116,11 +114,9 @@ hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 int multislice_impl(adm_plan* plan, const float* obj_rot, const float* probe, const int32_t* pos, int batch, const float* target,
                     int want_grad, float* grad_probe, float* pred, float* loss_sum, float grad_scale, void* workspace,
                     size_t workspace_bytes, bool per_position);
-bool ms_lean_supported(int n);
 bool ms_generic_supported(int py, int px);
 int ms_generic_threads(int py, int px);
 hipError_t ms_generic_launch(const MsParams& p, int batch, hipStream_t st);
-hipError_t ms_lean_launch(int n, const MsParams& p, int batch, hipStream_t st);
 hipError_t shift_launch(int n, const ShiftParams& q, int batch, bool adjoint, hipStream_t st);
 }  // namespace adm
 

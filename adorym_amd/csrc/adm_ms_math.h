@@ -1,4 +1,4 @@
-// Device helpers shared by the multislice kernels (adm_multislice.hip, adm_ms_lean.hip): wave-local LDS ordering,
+// Device helpers of the multislice kernels (adm_multislice.hip): wave-local LDS ordering,
 // the loss terms, and the branch-free sincos / exp used by the slice modulation.  Device-only, gfx950.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -289,10 +289,6 @@ class Plan(object):
         call before the first workspace is sized."""
         check(self.ctx.lib.adm_plan_set_generic(self.handle, 1 if on else 0))
 
-    def set_lean_min_batch(self, n):
-        """Batches of at least n positions use the two-workgroups-per-CU kernel where it applies (0 = never)."""
-        check(self.ctx.lib.adm_plan_set_lean_min_batch(self.handle, int(n)))
-
     def set_transmission_cache(self, on=True):
         """adm_rotate_fwd also stores the slice transmission of every voxel it writes and the multislice kernel multiplies
         with it instead of evaluating exp / sincos per covering position (delta_beta unknowns, binning 1; bit-identical)."""

@@ -217,12 +217,6 @@ int adm_multislice_fwd_adj(adm_plan* plan, const float* obj_rot, const float* pr
                            const float* target, int want_grad, float* grad_probe, float* pred, float* loss_sum,
                            float grad_scale, void* workspace, size_t workspace_bytes);
 
-/* Kernel selection.  Two kernels implement adm_multislice_fwd_adj with the same results up to fp32 rounding order: a
- * latency-oriented one (one workgroup per compute unit; every configuration) and a throughput-oriented one (two
- * workgroups per compute unit; one probe mode, delta/beta unknowns, binning 1, a transfer function with
- * H(ky,kx) == H(ky,N-kx), probe 64 or 72).  Batches of at least `min_batch` positions use the second where it applies;
- * 0 = never (the default: opt-in).  No reference counterpart: a tuning knob of this library. */
-int adm_plan_set_lean_min_batch(adm_plan* plan, int min_batch);
 /* Slice-transmission cache (delta_beta unknowns, binning 1).  The reference evaluates exp(-k1*beta) * (cos, sin)(-sigma*k1*delta)
  * for every voxel of every tile it extracts (adorym/propagate.py:241 through wrappers.py:600-608), i.e. once per covering
  * probe position -- up to ~40 times per voxel and angle in config 3 -- and autograd once more in the backward pass.  With the

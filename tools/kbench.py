@@ -13,8 +13,6 @@ cfg = W.c3_config()
 ctx = A.Context(0)
 eng = A.MultisliceEngine(ctx, cfg['obj_size'], cfg['probe_size'], cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'], max_batch=B,
                          transmission_cache=os.environ.get('ADM_TCACHE', '1') == '1')      # ADM_TCACHE=0: exp / sincos in the slice loop
-if os.environ.get('ADM_LEAN') is not None:      # 1: throughput kernel for every batch, 0: never
-    eng.plan.set_lean_min_batch(1 if os.environ['ADM_LEAN'] == '1' else 0)
 Y, X, Z = cfg['obj_size']
 obj = ctx.array(W.random_guess((Y, X, Z), seed=1))
 probe = ctx.array(W.probe_array(cfg))
@@ -28,5 +26,5 @@ for r in range(reps + 1):
     eng.multislice(probe, accumulate=False, want_grad=not fwd_only)
     e1.record()
     ts.append(e0.elapsed_ms(e1))
-print('%s lean=%s B=%d %s: kernel ms min %.3f median %.3f  -> %.0f pos/s' % (os.environ.get('ADM_LIB_PATH', 'libadm.so'), os.environ.get('ADM_LEAN', 'auto'), B,
+print('%s B=%d %s: kernel ms min %.3f median %.3f  -> %.0f pos/s' % (os.environ.get('ADM_LIB_PATH', 'libadm.so'), B,
       'fwd' if fwd_only else 'fwd+adj', min(ts[1:]), float(np.median(ts[1:])), B / (min(ts[1:]) * 1e-3)))
