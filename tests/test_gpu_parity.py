@@ -459,8 +459,8 @@ def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
     3x rule measured against the REFERENCE-STRUCTURED fp32 restatement (oracle/torch_structured.py, bit-identical to
     the reference's PyTorch-CPU path).  Rotation about axis 0 acts on every y plane separately, so the CPU checkers work
     on the slab of planes the minibatch touches (+1 plane each side for the TV stencil).  At 0.4 rad the minibatch is a full
-    one: 32 positions of the scan, two rows of the 23x23 grid, 16 of each (110 s of CPU checkers on the GPU box; measured
-    gradient error 7.3e-4 against 2.6e-3 for the reference's own fp32 arithmetic); at the 45-degree-class angle 6 positions of
+    one: 32 positions of the scan, two rows of the 23x23 grid, 16 of each (measured gradient error 7.3e-4 against 2.6e-3 for
+    the reference-structured fp32 arithmetic and 1.4e-3 for the oracle's fp32 run, which is the yardstick here); at the 45-degree-class angle 6 positions of
     the same rows (the batch size only enters through the 2/(B*Py*Px) factor).  Three consecutive minibatches and a 'per angle'
     update through the driver, object against object: tests/test_gpu_fullsize.py."""
     from oracle import torch_structured as T
@@ -503,12 +503,24 @@ def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
 
     loss64, _, g64, _ = O.forward_adjoint_object(guess, coords, probe, pos_s, meas, phys, 'float64')
     g64 = (g64 + reg_grad(guess))[1:-1]
-    # the reference's own arithmetic in fp32: its op structure on PyTorch-CPU autograd, fp32 rotation either side
+    # the yardstick of the 3x rule: fp32 arithmetic of the same path.  6 positions: the reference's own op structure on
+    # PyTorch-CPU autograd, fp32 rotation either side; the full minibatch: the oracle's fp32 run (the autograd graph of 32
+    # positions x 256 slices takes another minute of CPU for the same kind of number)
     g32in = guess.astype(np.float32)
-    rot32 = O.rotate_fwd(g32in, coords, np.float32)
-    loss32, grot32 = T.loss_and_grad(rot32, pos_s, probe, phys.h, phys.k1, meas.astype(np.float32))
-    g32 = (O.rotate_adj(np.asarray(grot32), coords, np.float32) + reg_grad(g32in).astype(np.float32))[1:-1]
-    del rot32, grot32
+    if full:
+        loss32, _, g32, _ = O.forward_adjoint_object(g32in, coords, probe, pos_s, meas.astype(np.float32), phys, 'float32')
+        g32 = (g32 + reg_grad(g32in).astype(np.float32))[1:-1]
+    else:
+        rot32 = O.rotate_fwd(g32in, coords, np.float32)
+        import torch
+        keep = torch.get_num_threads()
+        torch.set_num_threads(min(16, keep))      # (PyTorch-CPU is fastest at ~16 threads on this path: bench.py's thread sweep)
+        try:
+            loss32, grot32 = T.loss_and_grad(rot32, pos_s, probe, phys.h, phys.k1, meas.astype(np.float32))
+        finally:
+            torch.set_num_threads(keep)
+        g32 = (O.rotate_adj(np.asarray(grot32), coords, np.float32) + reg_grad(g32in).astype(np.float32))[1:-1]
+        del rot32, grot32
     # ---- GPU: the full 256^3 object (zero outside the slab; the TV term sees that edge only on the two slab-edge planes,
     # which are not compared) ----
     obj = np.zeros((N, N, N, 2), np.float32)
@@ -522,9 +534,16 @@ def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
     from adorym_amd._lib import check
     check(ctx.lib.adm_reg_grad(eng.plan.handle, d_obj.ptr, a_d, a_b, gam, d_grad.ptr, None))
     g = d_grad.get()[y_lo:y_hi]
-    assert abs(loss - loss64) <= 3 * abs(loss32 - loss64) + 1e-5 * abs(loss64), (loss, loss64, loss32)
     e, e32 = rel(g, g64), rel(g32, g64)
-    print('full-size C3 minibatch, theta %.4f: gradient rel-L2 vs fp64 %.2e (reference-structured fp32: %.2e)' % (theta, e, e32))
+    print('   loss rel. error %.2e (fp32 yardstick: %.2e)' % (abs(loss - loss64) / abs(loss64), abs(loss32 - loss64) / abs(loss64)))
+    if full:
+        # NumPy's fp32 transforms drift less with depth than the reference's (torch / pocketfft): the oracle's fp32 loss is
+        # within 5e-6 here, the reference's own fp32 loss error at this depth is 9.8e-5 (golden F17) -- that is the bar
+        assert abs(loss - loss64) <= 1.5e-4 * abs(loss64), (loss, loss64, loss32)
+    else:
+        assert abs(loss - loss64) <= 3 * abs(loss32 - loss64) + 1e-5 * abs(loss64), (loss, loss64, loss32)
+    print('full-size C3 minibatch, theta %.4f, %d positions: gradient rel-L2 vs fp64 %.2e (%s fp32: %.2e)'
+          % (theta, len(pos), e, 'oracle' if full else 'reference-structured', e32))
     assert e <= 3 * e32 + 1e-5 and e < 5e-3, (e, e32)
     # outside the footprint the data term is exactly zero: only the regulariser (of the zero object: sign(0) = 0) remains
     assert not d_grad.get()[:max(0, s0 - 1)].any()
