@@ -8,10 +8,10 @@
 // F.grid_sample, bilinear, border padding, align_corners=False), and the hand-derived gradients w.r.t. the object, the
 // probe, every distance d and every affine matrix.
 //
-// The fields are far larger than the LDS-resident tiles of the multislice kernel (512^2 * 8 B = 2 MB), so the
-// 2-D transforms run as two passes of a batched row FFT (Stockham radix-8/4/2 in LDS, rows of N = 16 ... 2048) whose
-// store is transposed: rows -> [kx][y], then "rows" of that -> [ky][kx].  All traffic stays in L2 / Infinity Cache
-// at these sizes; the path is launch-latency bound, not bandwidth bound.
+// The fields are far larger than the LDS-resident tiles of the multislice kernel (512^2 * 8 B = 2 MB), so the 2-D transforms
+// run as line transforms (Stockham radix-8/4/2 in LDS, lines of N = 16 ... 2048) with transposed stores between the x and the y
+// stage.  All traffic stays in L2 / Infinity Cache at these sizes; the path is bound by launch latency, so the element-wise
+// stages are fused into the transforms: five kernels per minibatch (below).
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -22,9 +22,10 @@ struct adm_holo {
     adm_ctx* ctx;
     adm_holo_desc d;
     float2 *tw_y, *tw_x;      // exp(-2 pi i j / N) for N = ny, nx
-    float* uv2;               // [ny][nx] u^2 + v^2 (nm^-2), fp32 like the reference's tensors
-    float2 *psi, *F, *W, *T;  // psi [ny][nx]; F = FFT2(psi); W, T: [n_dists][ny][nx] work fields
-    float* partial;           // [n_dists][256 blocks][8] per-block partial sums
+    float* uv2t;              // [nx][ny]: u^2 + v^2 (nm^-2) of frequency (ky, kx) at [kx][ky], fp32 like the reference's tensors
+    float2 *T14, *Ft;         // T14 [nx][ny] x spectra of the rows (K1 -> K2), later [ny][nx] (K4 -> K5); Ft [nx][ny] = FFT2(psi)
+    float2 *Wq, *T3;          // [n_dists][ny][nx] / [n_dists][nx][ny] work fields
+    float *part3, *part4;     // per-line partial sums: [n_dists][ny][8], [n_dists][nx]
 };
 
 namespace adm {
@@ -72,57 +73,41 @@ template <int N, bool INV, int TPR> struct Passes<N, N, INV, TPR> {
     static __device__ __forceinline__ int run(cf*, cf*, const float2*, int) { return 0; }
 };
 
-// in [nrows_total][N] -> out [b][N][rows] (b = row / rows), values multiplied by `scale`
-template <int N, bool INV>
-__global__ __launch_bounds__(256) void fft_rows_t_kernel(const float2* __restrict__ in, float2* __restrict__ out,
-                                                         const float2* __restrict__ tw, int rows, int nrows_total, float scale) {
-    constexpr int TPR = N / 8;
-    constexpr int RPW = 256 / TPR;
-    __shared__ cf buf[2][RPW * N];
-    const int rl = threadIdx.x / TPR, t = threadIdx.x % TPR;
-    const int gr = blockIdx.x * RPW + rl;
-    const bool ok = gr < nrows_total;
-    cf* a = buf[0] + rl * N;
-    cf* b = buf[1] + rl * N;
-    for (int n = t; n < N; n += TPR) a[n] = ok ? in[(size_t)gr * N + n] : make_float2(0.f, 0.f);
-    __syncthreads();
-    const int np = Passes<N, 1, INV, TPR>::run(a, b, tw, t);
-    const cf* res = (np & 1) ? b : a;
-    if (ok) {
-        const int bi = gr / rows, r = gr % rows;
-        for (int k = t; k < N; k += TPR) out[((size_t)bi * N + k) * rows + r] = cscale(res[k], scale);
-    }
-}
-
-template <bool INV> static hipError_t fft_rows_t(int n, const float2* in, float2* out, const float2* tw, int rows, int nb, float scale,
-                                                 hipStream_t st) {
-    const int total = rows * nb;
-#define ADM_CASE(N_)                                                                                                        \
-    case N_: {                                                                                                              \
-        constexpr int RPW = 256 / (N_ / 8);                                                                                 \
-        hipLaunchKernelGGL((fft_rows_t_kernel<N_, INV>), dim3((total + RPW - 1) / RPW), dim3(256), 0, st, in, out, tw, rows, total, \
-                           scale);                                                                                          \
-        break;                                                                                                              \
-    }
-    switch (n) {
-        ADM_CASE(16) ADM_CASE(32) ADM_CASE(64) ADM_CASE(128) ADM_CASE(256) ADM_CASE(512) ADM_CASE(1024) ADM_CASE(2048)
-        default: return hipErrorInvalidValue;
-    }
-#undef ADM_CASE
-    return hipGetLastError();
-}
-
-// [nb][ny][nx] -> [nb][ny][nx] spectrum (natural order); `tmp` is scratch of the same size
-template <bool INV> static hipError_t fft2(const adm_holo* h, const float2* in, float2* out, float2* tmp, int nb, float scale) {
-    hipStream_t st = h->ctx->stream;
-    hipError_t e = fft_rows_t<INV>(h->d.nx, in, tmp, h->tw_x, h->d.ny, nb, 1.0f, st);
-    if (e != hipSuccess) return e;
-    return fft_rows_t<INV>(h->d.ny, tmp, out, h->tw_y, h->d.nx, nb, scale, st);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// elementwise stages
+// Five kernels per minibatch.  Every stage is "lines of length N through LDS": a block of 256 threads works on LPB = 256 / (N / 8)
+// lines at once (N / 8 threads per line, Stockham passes above), and everything element-wise -- slice modulation, transfer
+// functions of all distances, loss and its derivative, the sums over distances, the object / probe gradient -- runs on the line
+// while it is in LDS, between two transforms:
+//   K1  rows y      : psi = probe * c(obj)                      -> FFT_x                       -> T1[kx][y]
+//   K2  lines kx    : FFT_y -> F (kept: Ft[kx][ky])  ; per d: x H_d -> IFFT_y                  -> Wq[d][y][kx]
+//   K3  rows (d, y) : IFFT_x / n -> Psi_d, loss, affine-gradient sums, dL/dPsi -> FFT_x        -> T3[d][kx][y]
+//   K4  lines kx    : per d: FFT_y / n -> Gh_d, distance-gradient sums, GF += conj(H_d) Gh_d ; IFFT_y -> T4[y][kx]
+//   K5  rows y      : IFFT_x -> dL/dpsi -> dL/dobj (+=), dL/dprobe (=) ; block 0: the sums of K3 / K4 in fixed order
+// (17 launches of 4.5-13 us each before round 4, back to back: the path is bound by the NUMBER of launches.)
+// Partial sums: one slot per line (K3: per (d, y), 8 floats; K4: per (d, kx)), summed by K5's block 0 -- or by
+// holo_sums_kernel when no gradient is wanted -- in a fixed order: bit-reproducible.
 // ---------------------------------------------------------------------------------------------------------------
+template <int N> struct LineGeo {
+    static constexpr int TPR = N / 8;             // threads per line
+    static constexpr int LPB = 256 / TPR;         // lines per block
+};
+// The passes read 7 twiddles per butterfly: from an LDS copy of the table (N <= 1024; the caller's next barrier orders the copy
+// before the first pass), from global memory otherwise (the line buffers of N = 2048 leave no room).
+template <int N> struct TwLds {
+    static constexpr bool USE = (N <= 1024);
+    static constexpr int SIZE = USE ? N : 1;
+};
+template <int N> __device__ __forceinline__ const float2* stage_twiddles(float2* lds, const float2* __restrict__ tw) {
+    if (!TwLds<N>::USE) return tw;
+    for (int j = threadIdx.x; j < N; j += 256) lds[j] = tw[j];
+    return lds;
+}
+// transform the line in `a` (filled, block synchronised); returns the buffer that holds the result (block synchronised)
+template <int N, bool INV> __device__ __forceinline__ cf* line_fft(cf* a, cf* b, const float2* __restrict__ tw, int t) {
+    const int np = Passes<N, 1, INV, LineGeo<N>::TPR>::run(a, b, tw, t);
+    return (np & 1) ? b : a;
+}
+
 __device__ __forceinline__ cf holo_transmission(float2 o, int real_imag, float k1, float sigma) {
     if (real_imag) return o;
     const float e = expf(-k1 * o.y);
@@ -130,13 +115,6 @@ __device__ __forceinline__ cf holo_transmission(float2 o, int real_imag, float k
     sincosf(-sigma * k1 * o.x, &sn, &cs);
     return make_float2(e * cs, e * sn);
 }
-
-__global__ __launch_bounds__(256) void holo_modulate_kernel(const float2* __restrict__ obj, const float2* __restrict__ probe,
-                                                            float2* __restrict__ psi, size_t n, int real_imag, float k1, float sigma) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        psi[i] = cmul(probe[i], holo_transmission(obj[i], real_imag, k1, sigma));
-}
-
 __device__ __forceinline__ cf holo_h(float uv2, float dist_cm, float c1) {
     // -sigma*PI*lambda (c1, rounded once on the host) * dist_nm * (u^2+v^2), every product in fp32 like the reference
     const float arg = (c1 * (dist_cm * 1e7f)) * uv2;
@@ -144,18 +122,6 @@ __device__ __forceinline__ cf holo_h(float uv2, float dist_cm, float c1) {
     sincosf(arg, &sn, &cs);
     return make_float2(cs, sn);
 }
-
-// W[d] = F * H_d
-__global__ __launch_bounds__(256) void holo_apply_h_kernel(const float2* __restrict__ F, const float* __restrict__ uv2,
-                                                           const float* __restrict__ dists, float2* __restrict__ W, size_t n, int nd,
-                                                           float c1) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nd; i += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i / n);
-        const size_t k = i % n;
-        W[i] = cmul(F[k], holo_h(uv2[k], dists[d], c1));
-    }
-}
-
 // torch's affine_grid base coordinate (see oracle/adorym_oracle.py::affine_sample for the derivation)
 __device__ __forceinline__ float base_coord(int i, int n) {
     const float step = 2.0f / (float)(n - 1);
@@ -163,152 +129,324 @@ __device__ __forceinline__ float base_coord(int i, int n) {
     return (lin * (float)(n - 1)) / (float)n;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
+struct HoloArgs {
+    const float2 *obj, *probe;
+    const float *dists, *affine, *data, *uv2t;      // uv2t: [nx][ny] (u^2 + v^2 of (ky, kx) at [kx][ky])
+    float2 *T1, *Ft, *Wq, *T3, *T4;                  // T1 [nx][ny], Ft [nx][ny], Wq [nd][ny][nx], T3 [nd][nx][ny], T4 [ny][nx]
+    const float2 *tw_x, *tw_y;
+    float *pred, *part3, *part4;                    // part3 [nd][ny][8], part4 [nd][nx]
+    float2 *grad_obj, *grad_probe;
+    float *loss_sum, *grad_affine, *grad_dists;
+    int ny, nx, nd, real_imag, intensity, want_affine, want_dists, set_obj;
+    float k1, sigma, c1, inv_n, gscale;
+};
+
+// sum of v over the TPR threads of a line group (TPR a power of two <= 256); red: [256] floats of LDS; every thread of the
+// block calls it
+template <int TPR> __device__ __forceinline__ float line_sum(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int s = TPR / 2; s > 0; s >>= 1) {
+        if ((tid % TPR) < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float r = red[tid - tid % TPR];
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    return r;
 }
 
-// per (distance, pixel): registered target, loss term, dL/dPsi (in place of Psi), affine-matrix gradient partial sums.
-// grid = (blocks, n_dists): one distance per blockIdx.y so that the reductions are per distance.
-__global__ __launch_bounds__(256) void holo_loss_kernel(float2* __restrict__ Psi, const float* __restrict__ data,
-                                                        const float* __restrict__ affine, int ny, int nx, int intensity, float gscale,
-                                                        float* __restrict__ pred_out, float* __restrict__ partial,
-                                                        int want_affine) {
-    __shared__ float red[4];
-    const int d = blockIdx.y;
-    const size_t n = (size_t)ny * nx;
-    float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-    if (affine) {
+// the same for Q quantities at once (one set of barriers); red: [Q][256]
+template <int TPR, int Q> __device__ __forceinline__ void line_sums(float (&v)[Q], float (*red)[256]) {
+    const int tid = threadIdx.x;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) th[q] = affine[d * 6 + q];
+    for (int q = 0; q < Q; ++q) red[q][tid] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int s = TPR / 2; s > 0; s >>= 1) {
+        if ((tid % TPR) < s) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) red[q][tid] += red[q][tid + s];
+        }
+        __syncthreads();
     }
-    const float* img = data + (size_t)d * n;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = red[q][tid - tid % TPR];
+    __syncthreads();
+}
+
+template <int NX> __global__ __launch_bounds__(256) void holo_k1(HoloArgs A) {
+    using LG = LineGeo<NX>;
+    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ float2 twl[TwLds<NX>::SIZE];
+    const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int y = blockIdx.x * LG::LPB + ll;
+    const bool ok = y < A.ny;
+    cf* a = buf[0] + ll * NX;
+    cf* b = buf[1] + ll * NX;
+    for (int x = t; x < NX; x += LG::TPR) {
+        const size_t i = (size_t)y * NX + x;
+        a[x] = ok ? cmul(A.probe[i], holo_transmission(A.obj[i], A.real_imag, A.k1, A.sigma)) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const cf* res = line_fft<NX, false>(a, b, tw, t);
+    if (ok)
+        for (int k = t; k < NX; k += LG::TPR) A.T1[(size_t)k * A.ny + y] = res[k];
+}
+
+// LPB adjacent lines kx per block (so that the transposed stores are LPB x 8 bytes long) and one distance per blockIdx.y: the
+// forward transform of a line is repeated for every distance (cheaper than a kernel boundary); blockIdx.y == 0 keeps F
+template <int NY> __global__ __launch_bounds__(256) void holo_k2(HoloArgs A) {
+    using LG = LineGeo<NY>;
+    __shared__ cf buf[2][LG::LPB * NY];
+    __shared__ float2 twl[TwLds<NY>::SIZE];
+    const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int kx = blockIdx.x * LG::LPB + ll, d = blockIdx.y;
+    const bool ok = kx < A.nx;
+    cf* a = buf[0] + ll * NY;
+    cf* b = buf[1] + ll * NY;
+    for (int j = t; j < NY; j += LG::TPR) a[j] = ok ? A.T1[(size_t)kx * NY + j] : make_float2(0.f, 0.f);
+    __syncthreads();
+    cf* F = line_fft<NY, false>(a, b, tw, t);
+    cf* p = (F == a) ? b : a;
+    if (ok && d == 0)
+        for (int k = t; k < NY; k += LG::TPR) A.Ft[(size_t)kx * NY + k] = F[k];
+    const float dist = A.dists[d];
+    for (int k = t; k < NY; k += LG::TPR) p[k] = ok ? cmul(F[k], holo_h(A.uv2t[(size_t)kx * NY + k], dist, A.c1)) : make_float2(0.f, 0.f);
+    __syncthreads();
+    const cf* res = line_fft<NY, true>(p, F, tw, t);      // (F's buffer is free once p is filled)
+    if (ok)
+        for (int y = t; y < NY; y += LG::TPR) A.Wq[((size_t)d * NY + y) * A.nx + kx] = res[y];
+}
+
+template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(HoloArgs A) {
+    using LG = LineGeo<NX>;
+    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ float red[7][256];
+    __shared__ float2 twl[TwLds<NX>::SIZE];
+    const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int job = blockIdx.x * LG::LPB + ll;        // job = d * ny + y
+    const bool ok = job < A.nd * A.ny;
+    const int d = ok ? job / A.ny : 0, y = ok ? job % A.ny : 0;
+    cf* a = buf[0] + ll * NX;
+    cf* b = buf[1] + ll * NX;
+    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.Wq[((size_t)d * A.ny + y) * NX + k] : make_float2(0.f, 0.f);
+    __syncthreads();
+    cf* res = line_fft<NX, true>(a, b, tw, t);
+    cf* oth = (res == a) ? b : a;
+    float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (A.affine) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) th[q] = A.affine[d * 6 + q];
+    }
+    const int ny = A.ny;
+    const size_t n = (size_t)ny * NX;
+    const float* img = A.data + (size_t)d * n;
     float lsum = 0.f, ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(i / nx), x = (int)(i % nx);
-        const float X = base_coord(x, nx), Y = base_coord(y, ny);
+    const float Y = base_coord(y, ny);
+    for (int x = t; x < NX; x += LG::TPR) {
+        const float X = base_coord(x, NX);
         const float gx = th[0] * X + th[1] * Y + th[2];
         const float gy = th[3] * X + th[4] * Y + th[5];
-        float ix = ((gx + 1.f) * (float)nx - 1.f) * 0.5f;
+        float ix = ((gx + 1.f) * (float)NX - 1.f) * 0.5f;
         float iy = ((gy + 1.f) * (float)ny - 1.f) * 0.5f;
-        const float mx = (ix > 0.f && ix < (float)(nx - 1)) ? 1.f : 0.f;     // grid_sampler's clip_coordinates_set_grad
+        const float mx = (ix > 0.f && ix < (float)(NX - 1)) ? 1.f : 0.f;     // grid_sampler's clip_coordinates_set_grad
         const float my = (iy > 0.f && iy < (float)(ny - 1)) ? 1.f : 0.f;
-        ix = fminf(fmaxf(ix, 0.f), (float)(nx - 1));
+        ix = fminf(fmaxf(ix, 0.f), (float)(NX - 1));
         iy = fminf(fmaxf(iy, 0.f), (float)(ny - 1));
         const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
         const float wx = ix - (float)x0, wy = iy - (float)y0;
-        const int x1 = min(x0 + 1, nx - 1), y1 = min(y0 + 1, ny - 1);
-        const float v00 = img[(size_t)y0 * nx + x0], v01 = img[(size_t)y0 * nx + x1];
-        const float v10 = img[(size_t)y1 * nx + x0], v11 = img[(size_t)y1 * nx + x1];
+        const int x1 = min(x0 + 1, NX - 1), y1 = min(y0 + 1, ny - 1);
+        const float v00 = img[(size_t)y0 * NX + x0], v01 = img[(size_t)y0 * NX + x1];
+        const float v10 = img[(size_t)y1 * NX + x0], v11 = img[(size_t)y1 * NX + x1];
         const float samp = v00 * (1.f - wx) * (1.f - wy) + v01 * wx * (1.f - wy) + v10 * (1.f - wx) * wy + v11 * wx * wy;
         const float as = fabsf(samp);
-        const float tgt = intensity ? sqrtf(as) : as;
-        const float2 ps = Psi[(size_t)d * n + i];
+        const float tgt = A.intensity ? sqrtf(as) : as;
+        const float2 ps = cscale(res[x], A.inv_n);                  // Psi_d(y, x): normalised inverse
         const float mag = sqrtf(ps.x * ps.x + ps.y * ps.y);
         const float diff = mag - tgt;
-        lsum += diff * diff;
-        if (pred_out) pred_out[(size_t)d * n + i] = mag;
-        const float g = (mag > 0.f) ? gscale * diff / mag : 0.f;
-        Psi[(size_t)d * n + i] = cscale(ps, g);
-        if (want_affine) {
-            const float sg = (float)((samp > 0.f) - (samp < 0.f));
-            float cot = -gscale * diff * (intensity ? sg / (2.f * sqrtf(as)) : sg);
-            if (!(fabsf(cot) <= 3.0e38f)) cot = 0.f;               // 0/0 at an exactly zero sample
-            const float dix = ((v01 - v00) * (1.f - wy) + (v11 - v10) * wy) * mx * (0.5f * (float)nx) * cot;
-            const float diy = ((v10 - v00) * (1.f - wx) + (v11 - v01) * wx) * my * (0.5f * (float)ny) * cot;
-            ga[0] += dix * X; ga[1] += dix * Y; ga[2] += dix;
-            ga[3] += diy * X; ga[4] += diy * Y; ga[5] += diy;
+        if (ok) {
+            lsum += diff * diff;
+            if (A.pred) A.pred[(size_t)d * n + (size_t)y * NX + x] = mag;
+        }
+        if (GRAD) {
+            const float g = (mag > 0.f) ? A.gscale * diff / mag : 0.f;
+            oth[x] = cscale(ps, g);                                  // dL/dPsi_d
+            if (A.want_affine && ok) {
+                const float sg = (float)((samp > 0.f) - (samp < 0.f));
+                float cot = -A.gscale * diff * (A.intensity ? sg / (2.f * sqrtf(as)) : sg);
+                if (!(fabsf(cot) <= 3.0e38f)) cot = 0.f;             // 0/0 at an exactly zero sample
+                const float dix = ((v01 - v00) * (1.f - wy) + (v11 - v10) * wy) * mx * (0.5f * (float)NX) * cot;
+                const float diy = ((v10 - v00) * (1.f - wx) + (v11 - v01) * wx) * my * (0.5f * (float)ny) * cot;
+                ga[0] += dix * X; ga[1] += dix * Y; ga[2] += dix;
+                ga[3] += diy * X; ga[4] += diy * Y; ga[5] += diy;
+            }
         }
     }
-    // per-block partial sums (slot 0: loss, 1..6: affine gradient); summed by holo_reduce_kernel -- hundreds of float
-    // atomics on one address serialise in L2 and made this kernel 10x slower than its arithmetic
-    float* out = partial + ((size_t)d * gridDim.x + blockIdx.x) * 8;
-    const float ls = block_sum(lsum, red);
-    if (threadIdx.x == 0) out[0] = ls;
-    if (want_affine) {
+    // one slot of 8 floats per line (slot 0: loss, 1..6: affine gradient)
+    if (GRAD && A.want_affine) {
+        float v[7] = {lsum, ga[0], ga[1], ga[2], ga[3], ga[4], ga[5]};
+        line_sums<LG::TPR, 7>(v, red);
+        if (ok && t == 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const float s = block_sum(ga[q], red);
-            if (threadIdx.x == 0) out[1 + q] = s;
+            for (int q = 0; q < 7; ++q) A.part3[(size_t)job * 8 + q] = v[q];
         }
+    } else {
+        const float ls = line_sum<LG::TPR>(lsum, red[0]);
+        if (ok && t == 0) A.part3[(size_t)job * 8] = ls;
     }
+    if (!GRAD) return;
+    __syncthreads();
+    const cf* G = line_fft<NX, false>(oth, res, tw, t);
+    if (ok)
+        for (int k = t; k < NX; k += LG::TPR) A.T3[((size_t)d * NX + k) * ny + y] = G[k];
 }
 
-// dst[d*stride + q] (=|+=) scale * sum_b partial[(d*nb + b)*8 + off + q]   for q < nq;  one wave per distance
-__global__ __launch_bounds__(64) void holo_reduce_kernel(const float* __restrict__ partial, int nb, int off, int nq, float scale,
-                                                         float* __restrict__ dst, int stride, int accumulate) {
-    const int d = blockIdx.x;
-    for (int q = 0; q < nq; ++q) {
+// Gh_d = FFT2(dL/dPsi_d) / n.  GF = sum_d conj(H_d) Gh_d;  dL/dd_cm = 1e7 * Re sum_k conj(Gh_d) (-i sigma PI lambda uv2) H_d F
+template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
+    using LG = LineGeo<NY>;
+    __shared__ cf buf[3][LG::LPB * NY];
+    __shared__ float red[256];
+    __shared__ float2 twl[TwLds<NY>::SIZE];
+    const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int kx = blockIdx.x;                        // one line per block, slot s works on distances s, s + LPB, ...
+    cf* a = buf[0] + ll * NY;
+    cf* b = buf[1] + ll * NY;
+    cf* GF = buf[2] + ll * NY;
+    for (int k = t; k < NY; k += LG::TPR) GF[k] = make_float2(0.f, 0.f);
+    for (int d0 = 0; d0 < A.nd; d0 += LG::LPB) {
+        const int d = d0 + ll;
+        const bool ok = d < A.nd;
+        for (int j = t; j < NY; j += LG::TPR) a[j] = ok ? A.T3[((size_t)d * A.nx + kx) * NY + j] : make_float2(0.f, 0.f);
+        __syncthreads();
+        const cf* res = line_fft<NY, false>(a, b, tw, t);
+        const float dist = ok ? A.dists[d] : 0.f;
         float acc = 0.f;
-        for (int b = threadIdx.x; b < nb; b += 64) acc += partial[((size_t)d * nb + b) * 8 + off + q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-        if (threadIdx.x == 0) {
-            if (accumulate) dst[d * stride + q] += scale * acc;
-            else dst[d * stride + q] = scale * acc;
+        for (int k = t; k < NY; k += LG::TPR) {
+            const size_t e = (size_t)kx * NY + k;
+            const float u2 = A.uv2t[e];
+            const cf h = holo_h(u2, dist, A.c1);
+            const cf g = cscale(res[k], A.inv_n);
+            GF[k] = cadd(GF[k], cmulc(g, h));
+            if (A.want_dists && ok) {
+                const cf hf = cmul(h, A.Ft[e]);
+                acc += -A.c1 * u2 * (g.x * hf.y - g.y * hf.x);      // Re( conj(g) (i c1 u2) hf ) = -c1 u2 Im(conj(g) hf)
+            }
         }
+        if (A.want_dists) {
+            const float sd = line_sum<LG::TPR>(acc, red);
+            if (ok && t == 0) A.part4[(size_t)d * A.nx + kx] = sd;
+        }
+        __syncthreads();                              // a / b are refilled by the next round of distances
     }
+    // the slots' sums over their distances, added in slot order into slot 0, which transforms back
+    if (LG::LPB > 1) {
+        for (int k = threadIdx.x; k < NY; k += 256) {
+            cf sum = buf[2][k];
+#pragma unroll
+            for (int s_ = 1; s_ < LG::LPB; ++s_) sum = cadd(sum, buf[2][s_ * NY + k]);
+            buf[2][k] = sum;
+        }
+        __syncthreads();
+    }
+    const cf* gy = line_fft<NY, true>(GF, a, tw, t);      // (every slot runs it -- the barriers inside are the block's -- slot 0's counts)
+    if (ll == 0)
+        for (int y = t; y < NY; y += LG::TPR) A.T4[(size_t)y * A.nx + kx] = gy[y];
 }
 
-// Gh[d] = FFT2(dL/dPsi_d) / (ny nx) (already scaled).  GF = sum_d conj(H_d) Gh_d;
-// dL/dd_cm = 1e7 * Re sum_k conj(Gh_d) (-i sigma PI lambda uv2) H_d F     (one distance per blockIdx.y)
-__global__ __launch_bounds__(256) void holo_adjoint_kernel(const float2* __restrict__ Gh, const float2* __restrict__ F,
-                                                           const float* __restrict__ uv2, const float* __restrict__ dists, size_t n, int nd,
-                                                           float c1, float* __restrict__ partial) {
-    __shared__ float red[4];
-    const int d = blockIdx.y;
-    float acc = 0.f;
-    const float dist = dists[d];
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
-        const float u2 = uv2[k];
-        const cf h = holo_h(u2, dist, c1);
-        const cf g = Gh[(size_t)d * n + k];
-        const cf hf = cmul(h, F[k]);
-        // Re( conj(g) * (i c1 u2) * hf ) = -c1 u2 * Im(conj(g) hf)
-        acc += -c1 * u2 * (g.x * hf.y - g.y * hf.x);
-    }
-    const float s = block_sum(acc, red);
-    if (threadIdx.x == 0) partial[((size_t)d * gridDim.x + blockIdx.x) * 8] = s;
-}
-
-__global__ __launch_bounds__(256) void holo_sum_conj_h_kernel(const float2* __restrict__ Gh, const float* __restrict__ uv2,
-                                                              const float* __restrict__ dists, float2* __restrict__ GF, size_t n, int nd,
-                                                              float c1) {
-    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
-        cf acc = make_float2(0.f, 0.f);
-        const float u2 = uv2[k];
-        for (int d = 0; d < nd; ++d) acc = cadd(acc, cmulc(Gh[(size_t)d * n + k], holo_h(u2, dists[d], c1)));
-        GF[k] = acc;
+// the per-line sums of K3 / K4 in a fixed order: loss_sum[d] =, grad_affine[d][q] +=, grad_dists[d] += 1e7 * ...
+// One wave per output: lanes stride over the lines, then a fixed shuffle tree.
+__device__ __forceinline__ void holo_sum_one(const HoloArgs& A, bool grad, int o) {      // called by one whole wave
+    const int lane = threadIdx.x & 63;
+    const int d = o >> 3, q = o & 7;
+    const bool want = (q == 0) || (q < 7 ? (grad && A.want_affine) : (grad && A.want_dists));
+    if (!want) return;
+    float s = 0.f;
+    if (q < 7) { for (int y = lane; y < A.ny; y += 64) s += A.part3[((size_t)d * A.ny + y) * 8 + q]; }
+    else { for (int x = lane; x < A.nx; x += 64) s += A.part4[(size_t)d * A.nx + x]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        if (q == 0) A.loss_sum[d] = s;
+        else if (q < 7) A.grad_affine[d * 6 + q - 1] = (A.set_obj ? 0.f : A.grad_affine[d * 6 + q - 1]) + s;
+        else A.grad_dists[d] = (A.set_obj ? 0.f : A.grad_dists[d]) + 1e7f * s;
     }
 }
+__global__ __launch_bounds__(64) void holo_sums_kernel(HoloArgs A) { holo_sum_one(A, false, blockIdx.x); }
 
 // dL/dpsi -> dL/dobj (accumulated) and dL/dprobe (written)
-__global__ __launch_bounds__(256) void holo_obj_grad_kernel(const float2* __restrict__ gpsi, const float2* __restrict__ obj,
-                                                            const float2* __restrict__ probe, float2* __restrict__ grad_obj,
-                                                            float2* __restrict__ grad_probe, size_t n, int real_imag, float k1,
-                                                            float sigma) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const cf g = gpsi[i];
-        const cf c = holo_transmission(obj[i], real_imag, k1, sigma);
-        const cf p = probe[i];
-        if (grad_probe) grad_probe[i] = cmulc(g, c);
-        float2 go = grad_obj[i];
-        if (real_imag) {
-            const cf z = cmulc(g, p);                  // G conj(probe)
-            go.x += z.x;
-            go.y += z.y;
-        } else {
-            const cf pm = cmul(p, c);                  // post-modulation field psi'
-            const float wre = g.x * pm.x + g.y * pm.y, wim = g.x * pm.y - g.y * pm.x;     // w = conj(G) psi'
-            go.y += -k1 * wre;                         // d/dbeta
-            go.x += sigma * k1 * wim;                  // d/ddelta
+template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
+    using LG = LineGeo<NX>;
+    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ float2 twl[TwLds<NX>::SIZE];
+    const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int y = blockIdx.x * LG::LPB + ll;
+    const bool ok = y < A.ny;
+    cf* a = buf[0] + ll * NX;
+    cf* b = buf[1] + ll * NX;
+    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.T4[(size_t)y * NX + k] : make_float2(0.f, 0.f);
+    __syncthreads();
+    const cf* res = line_fft<NX, true>(a, b, tw, t);
+    if (ok)
+        for (int x = t; x < NX; x += LG::TPR) {
+            const size_t i = (size_t)y * NX + x;
+            const cf g = res[x];
+            const cf c = holo_transmission(A.obj[i], A.real_imag, A.k1, A.sigma);
+            const cf p = A.probe[i];
+            if (A.grad_probe) A.grad_probe[i] = cmulc(g, c);
+            float2 go = A.set_obj ? make_float2(0.f, 0.f) : A.grad_obj[i];
+            if (A.real_imag) {
+                const cf z = cmulc(g, p);                  // G conj(probe)
+                go.x += z.x;
+                go.y += z.y;
+            } else {
+                const cf pm = cmul(p, c);                  // post-modulation field psi'
+                const float wre = g.x * pm.x + g.y * pm.y, wim = g.x * pm.y - g.y * pm.x;     // w = conj(G) psi'
+                go.y += -A.k1 * wre;                       // d/dbeta
+                go.x += A.sigma * A.k1 * wim;              // d/ddelta
+            }
+            A.grad_obj[i] = go;
         }
-        grad_obj[i] = go;
+    // the sums of K3 / K4: output o by wave 0 of block o % gridDim.x (a handful of blocks carry one or two each)
+    if (threadIdx.x < 64)
+        for (int o = blockIdx.x; o < A.nd * 8; o += gridDim.x) holo_sum_one(A, true, o);
+}
+
+#define ADM_HOLO_SIZES(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
+template <int N> static int blocks_for(int lines) { return (lines + LineGeo<N>::LPB - 1) / LineGeo<N>::LPB; }
+
+static hipError_t holo_run(const HoloArgs& A, bool want_grad, hipStream_t st) {
+#define K_X(KERNEL, N_, LINES) case N_: hipLaunchKernelGGL((KERNEL<N_>), dim3(blocks_for<N_>(LINES)), dim3(256), 0, st, A); break;
+#define K1(N_) K_X(holo_k1, N_, A.ny)
+#define K2(N_) case N_: hipLaunchKernelGGL((holo_k2<N_>), dim3(blocks_for<N_>(A.nx), A.nd), dim3(256), 0, st, A); break;
+#define K4(N_) case N_: hipLaunchKernelGGL((holo_k4<N_>), dim3(A.nx), dim3(256), 0, st, A); break;
+#define K5(N_) K_X(holo_k5, N_, A.ny)
+#define K3G(N_) case N_: hipLaunchKernelGGL((holo_k3<N_, true>), dim3(blocks_for<N_>(A.nd * A.ny)), dim3(256), 0, st, A); break;
+#define K3N(N_) case N_: hipLaunchKernelGGL((holo_k3<N_, false>), dim3(blocks_for<N_>(A.nd * A.ny)), dim3(256), 0, st, A); break;
+    switch (A.nx) { ADM_HOLO_SIZES(K1) default: return hipErrorInvalidValue; }
+    switch (A.ny) { ADM_HOLO_SIZES(K2) default: return hipErrorInvalidValue; }
+    if (want_grad) {
+        switch (A.nx) { ADM_HOLO_SIZES(K3G) default: return hipErrorInvalidValue; }
+        switch (A.ny) { ADM_HOLO_SIZES(K4) default: return hipErrorInvalidValue; }
+        switch (A.nx) { ADM_HOLO_SIZES(K5) default: return hipErrorInvalidValue; }
+    } else {
+        switch (A.nx) { ADM_HOLO_SIZES(K3N) default: return hipErrorInvalidValue; }
+        hipLaunchKernelGGL(holo_sums_kernel, dim3(A.nd * 8), dim3(64), 0, st, A);
     }
+#undef K_X
+#undef K1
+#undef K2
+#undef K4
+#undef K5
+#undef K3G
+#undef K3N
+    return hipGetLastError();
 }
 
 }  // namespace adm
@@ -351,17 +489,20 @@ extern "C" int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo
             for (int x = 0; x < d.nx; ++x) {
                 const int kx = x < (d.nx + 1) / 2 ? x : x - d.nx;
                 const float v = (float)(((double)kx / d.nx) / d.voxel_nm_x);
-                uv[(size_t)y * d.nx + x] = u * u + v * v;
+                uv[(size_t)x * d.ny + y] = u * u + v * v;
             }
         }
-        rc = adm_malloc(ctx, n * sizeof(float), (void**)&h->uv2);
-        if (!rc) rc = adm_h2d(ctx, h->uv2, uv.data(), n * sizeof(float));
+        rc = adm_malloc(ctx, n * sizeof(float), (void**)&h->uv2t);
+        if (!rc) rc = adm_h2d(ctx, h->uv2t, uv.data(), n * sizeof(float));
     }
-    if (!rc) rc = adm_malloc(ctx, n * sizeof(float2), (void**)&h->psi);
-    if (!rc) rc = adm_malloc(ctx, n * sizeof(float2), (void**)&h->F);
-    if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->W);
-    if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->T);
-    if (!rc) rc = adm_malloc(ctx, (size_t)d.n_dists * 256 * 8 * sizeof(float), (void**)&h->partial);
+    if (!rc) rc = adm_malloc(ctx, n * sizeof(float2), (void**)&h->T14);
+    if (!rc) rc = adm_malloc(ctx, n * sizeof(float2), (void**)&h->Ft);
+    if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->Wq);
+    if (!rc) rc = adm_malloc(ctx, n * d.n_dists * sizeof(float2), (void**)&h->T3);
+    if (!rc) rc = adm_malloc(ctx, (size_t)d.n_dists * d.ny * 8 * sizeof(float), (void**)&h->part3);
+    if (!rc) rc = adm_malloc(ctx, (size_t)d.n_dists * d.nx * sizeof(float), (void**)&h->part4);
+    // (the affine-gradient slots of part3 are summed only when they were written: zero once for the others)
+    if (!rc) rc = adm_memset(ctx, h->part3, 0, (size_t)d.n_dists * d.ny * 8 * sizeof(float));
     if (rc) {
         adm_holo_destroy(h);
         return rc;
@@ -372,7 +513,7 @@ extern "C" int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo
 
 extern "C" int adm_holo_destroy(adm_holo* h) {
     if (!h) return ADM_OK;
-    void* bufs[] = {h->tw_y, h->tw_x, h->uv2, h->psi, h->F, h->W, h->T, h->partial};
+    void* bufs[] = {h->tw_y, h->tw_x, h->uv2t, h->T14, h->Ft, h->Wq, h->T3, h->part3, h->part4};
     for (void* b : bufs)
         if (b) adm_free(h->ctx, b);
     delete h;
@@ -385,40 +526,24 @@ extern "C" int adm_holo_fwd_adj(adm_holo* h, const float* obj, const float* prob
     if (!h || !obj || !probe || !dists_cm || !data || !loss_sum) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj: null argument");
     if (want_grad && !grad_obj) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj: want_grad needs grad_obj");
     const adm_holo_desc& d = h->d;
-    hipStream_t st = h->ctx->stream;
     const size_t n = (size_t)d.ny * d.nx;
-    const int nd = d.n_dists;
-    const float sigma = (float)d.sign_convention;
-    const float c1 = (float)(-(double)d.sign_convention * 3.14159265359 * d.lambda_nm);
-    const float inv_n = (float)(1.0 / (double)n);
-    hipLaunchKernelGGL(holo_modulate_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)obj, (const float2*)probe, h->psi, n,
-                       d.unknown_type, d.k1, sigma);
-    ADM_HIP(fft2<false>(h, h->psi, h->F, h->T, 1, 1.0f));
-    hipLaunchKernelGGL(holo_apply_h_kernel, dim3(grid_for(n * nd)), dim3(256), 0, st, (const float2*)h->F, (const float*)h->uv2, dists_cm,
-                       h->W, n, nd, c1);
-    ADM_HIP(fft2<true>(h, h->W, h->W, h->T, nd, inv_n));            // Psi_d (normalised inverse), in place via T
-    const float gscale = want_grad ? (float)(2.0 / ((double)n * nd)) : 0.f;
-    int nb = grid_for(n);
-    if (nb > 256) nb = 256;
-    const int want_affine = (want_grad && grad_affine) ? 1 : 0;
-    hipLaunchKernelGGL(holo_loss_kernel, dim3(nb, nd), dim3(256), 0, st, h->W, data, affine, d.ny, d.nx, d.raw_intensity, gscale, pred,
-                       h->partial, want_affine);
-    hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 0, 1, 1.0f, loss_sum, 1, 0);
-    if (want_affine)
-        hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 1, 6, 1.0f, grad_affine, 6, 1);
-    ADM_HIP(hipGetLastError());
-    if (!want_grad) return ADM_OK;
-    ADM_HIP(fft2<false>(h, h->W, h->W, h->T, nd, inv_n));           // Gh_d = FFT2(dL/dPsi_d) / N
-    if (grad_dists) {
-        hipLaunchKernelGGL(holo_adjoint_kernel, dim3(nb, nd), dim3(256), 0, st, (const float2*)h->W, (const float2*)h->F,
-                           (const float*)h->uv2, dists_cm, n, nd, c1, h->partial);
-        hipLaunchKernelGGL(holo_reduce_kernel, dim3(nd), dim3(64), 0, st, (const float*)h->partial, nb, 0, 1, 1e7f, grad_dists, 1, 1);
-    }
-    hipLaunchKernelGGL(holo_sum_conj_h_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)h->W, (const float*)h->uv2, dists_cm,
-                       h->psi, n, nd, c1);
-    ADM_HIP(fft2<true>(h, h->psi, h->psi, h->T, 1, 1.0f));          // dL/dpsi = unnormalised inverse of GF
-    hipLaunchKernelGGL(holo_obj_grad_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const float2*)h->psi, (const float2*)obj,
-                       (const float2*)probe, (float2*)grad_obj, (float2*)grad_probe, n, d.unknown_type, d.k1, sigma);
-    ADM_HIP(hipGetLastError());
+    HoloArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.obj = (const float2*)obj; A.probe = (const float2*)probe;
+    A.dists = dists_cm; A.affine = affine; A.data = data; A.uv2t = h->uv2t;
+    A.T1 = h->T14; A.Ft = h->Ft; A.Wq = h->Wq; A.T3 = h->T3; A.T4 = h->T14;
+    A.tw_x = h->tw_x; A.tw_y = h->tw_y;
+    A.pred = pred; A.part3 = h->part3; A.part4 = h->part4;
+    A.grad_obj = (float2*)grad_obj; A.grad_probe = (float2*)grad_probe;
+    A.loss_sum = loss_sum; A.grad_affine = grad_affine; A.grad_dists = grad_dists;
+    A.ny = d.ny; A.nx = d.nx; A.nd = d.n_dists; A.real_imag = d.unknown_type; A.intensity = d.raw_intensity;
+    A.want_affine = (want_grad && grad_affine) ? 1 : 0;
+    A.want_dists = (want_grad && grad_dists) ? 1 : 0;
+    A.set_obj = (want_grad == 2) ? 1 : 0;
+    A.k1 = d.k1; A.sigma = (float)d.sign_convention;
+    A.c1 = (float)(-(double)d.sign_convention * 3.14159265359 * d.lambda_nm);
+    A.inv_n = (float)(1.0 / (double)n);
+    A.gscale = want_grad ? (float)(2.0 / ((double)n * d.n_dists)) : 0.f;
+    ADM_HIP(holo_run(A, want_grad != 0, h->ctx->stream));
     return ADM_OK;
 }

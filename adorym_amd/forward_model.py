@@ -516,7 +516,7 @@ class MultiDistModel(PtychographyModel):
         return self._data_dev
 
     def _run(self, obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad, grad_obj=None, grads=None,
-             want_pred=False):
+             want_pred=False, overwrite=False):
         nd = self.holo.n_dists
         probe = self._probe(probe_real, probe_imag)          # [1, ny, nx, 2]
         dists = self._dev('free_prop_cm', free_prop_cm, (nd,))
@@ -526,7 +526,7 @@ class MultiDistModel(PtychographyModel):
         g = grads or {}
         self.holo.forward_adjoint(obj, probe, dists, self._data(this_i_theta), affine=aff, want_grad=want_grad, grad_obj=grad_obj,
                                   grad_probe=g.get('probe'), grad_dists=g.get('dists'), grad_affine=g.get('affine') if aff is not None else None,
-                                  want_pred=want_pred)
+                                  want_pred=want_pred, overwrite=overwrite)
 
     def predict(self, obj, probe_real, probe_imag, probe_defocus_mm, probe_pos_offset, this_i_theta, this_pos_batch, prj,
                 probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa, prj_pos_offset):
@@ -556,8 +556,8 @@ class MultiDistModel(PtychographyModel):
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         if _side_hook is not None:
             _side_hook()
-        if _init_grad:
-            grad_obj.zero_()
+        # _init_grad: the object-gradient buffer holds garbage -> the engine overwrites every gradient ('=' instead of '+=': no
+        # zero fills on a path that is bound by the number of launches); otherwise it accumulates into zeroed small buffers
         nd = self.holo.n_dists
         idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls')}
         grads = {}
@@ -569,12 +569,13 @@ class MultiDistModel(PtychographyModel):
         if idx['free_prop_cm'] in opt_args_ls:
             if getattr(self, '_gd', None) is None:
                 self._gd = self.device.empty((nd,))
-            grads['dists'] = self._gd.zero_()
+            grads['dists'] = self._gd if _init_grad else self._gd.zero_()
         if idx['prj_affine_ls'] in opt_args_ls:
             if getattr(self, '_ga', None) is None:
                 self._ga = self.device.empty((nd, 2, 3))
-            grads['affine'] = self._ga.zero_()
-        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=True, grad_obj=grad_obj, grads=grads)
+            grads['affine'] = self._ga if _init_grad else self._ga.zero_()
+        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=True, grad_obj=grad_obj, grads=grads,
+                  overwrite=bool(_init_grad))
         # loss and regulariser value are read back lazily (the driver looks at them after the next minibatch has been queued)
         regv = self._reg_value_async(self._regularize_launch(obj, grad_obj))
         datav = self.holo.loss_async()

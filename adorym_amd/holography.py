@@ -38,13 +38,14 @@ class HolographyEngine(object):
             pass
 
     def forward_adjoint(self, obj, probe, dists_cm, data, affine=None, want_grad=True, grad_obj=None, grad_probe=None,
-                        grad_dists=None, grad_affine=None, want_pred=False):
+                        grad_dists=None, grad_affine=None, want_pred=False, overwrite=False):
         """All arguments are DeviceArrays: obj [ny,nx,(1,)2], probe [ny,nx,2], dists_cm [n_dists], data [n_dists,ny,nx] (raw),
-        affine [n_dists,2,3] or None.  Gradients are accumulated (+=) except grad_probe (overwritten)."""
+        affine [n_dists,2,3] or None.  Gradients are accumulated (+=) except grad_probe (overwritten); ``overwrite=True``:
+        all of them are overwritten (no zero fills needed)."""
         if want_pred and self._pred is None:
             self._pred = DeviceArray(self.ctx, (self.n_dists, self.ny, self.nx), np.float32)
         p = lambda a: a.ptr if a is not None else None
-        check(self.ctx.lib.adm_holo_fwd_adj(self.handle, obj.ptr, probe.ptr, dists_cm.ptr, p(affine), data.ptr, 1 if want_grad else 0,
+        check(self.ctx.lib.adm_holo_fwd_adj(self.handle, obj.ptr, probe.ptr, dists_cm.ptr, p(affine), data.ptr, (2 if overwrite else 1) if want_grad else 0,
                                             p(grad_obj), p(grad_probe), p(grad_dists), p(grad_affine),
                                             self._pred.ptr if want_pred else None, self._loss.ptr))
 

@@ -367,8 +367,10 @@ int adm_holo_destroy(adm_holo* holo);
 /* obj [ny][nx][2], probe [ny][nx][2], dists_cm [n_dists] (the reference's free_prop_cm), affine [n_dists][2][3]
  * (prj_affine_ls; NULL = identity), data [n_dists][ny][nx] raw measurements: all device pointers.
  * loss_sum [n_dists] (overwritten) = per-distance sum of squared residuals; loss = sum / (n_dists*ny*nx).
- * want_grad: grad_obj [ny][nx][2] += dL/dobj; grad_probe [ny][nx][2] = dL/dprobe (NULL ok);
+ * want_grad = 1: grad_obj [ny][nx][2] += dL/dobj; grad_probe [ny][nx][2] = dL/dprobe (NULL ok);
  * grad_dists [n_dists] += dL/dfree_prop_cm (NULL ok); grad_affine [n_dists][2][3] += dL/dprj_affine_ls (NULL ok);
+ * want_grad = 2: the same with '=' instead of '+=' (the buffers need no zero fill: three launches less per minibatch on a
+ * path that is bound by the number of launches);
  * pred [n_dists][ny][nx] = |Psi_d| (NULL ok). */
 int adm_holo_fwd_adj(adm_holo* holo, const float* obj, const float* probe, const float* dists_cm, const float* affine,
                      const float* data, int want_grad, float* grad_obj, float* grad_probe, float* grad_dists,

@@ -107,10 +107,9 @@ def bench_c5(ctx, steps=50):
     pending = [None]
 
     def step():
-        g.zero_()
-        eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd, grad_affine=ga)
+        eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd, grad_affine=ga, overwrite=True)
         check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
-        apply_small_params(ctx, [dict(opt=o_d, x=dists, g=gd, zero_grad=True), dict(opt=o_a, x=aff, g=ga, pin=ident, zero_grad=True)], 0)
+        apply_small_params(ctx, [dict(opt=o_d, x=dists, g=gd), dict(opt=o_a, x=aff, g=ga, pin=ident)], 0)
         tok = eng.loss_async()
         out = pending[0]() if pending[0] is not None else None           # the PREVIOUS minibatch's loss
         pending[0] = tok
