@@ -81,6 +81,38 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restric
     }
 }
 
+// No rotation (coords == nullptr) on a thin object -- the 2-D modes, Z = 1: the general kernels above would keep one thread in
+// sixteen busy (their 16 x 16 patches span (x', z')).  One thread per voxel, z fastest like the object: the same numbers (weights
+// 1, 0, 0, 0), 13-14 us -> a plain copy's time on the config-1 shape.
+__global__ __launch_bounds__(256) void identity_fwd_kernel(const float2* __restrict__ obj, float2* __restrict__ rot, float2* __restrict__ trans,
+                                                           float k1, float sigma, RotGeom g, int y_lo, int y_hi) {
+    const size_t n = (size_t)(y_hi - y_lo) * g.X * g.Z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % g.Z);
+        const size_t yx = i / g.Z;
+        const int x = (int)(yx % g.X), y = y_lo + (int)(yx / g.X);
+        const float2 r = obj[((size_t)y * g.X + x) * g.Z + z];
+        const size_t o_rot = ((size_t)z * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + x;
+        if (rot) rot[o_rot] = r;
+        if (trans) trans[o_rot] = slice_transmission(r, k1, sigma);
+    }
+}
+__global__ __launch_bounds__(256) void identity_adj_kernel(const float2* __restrict__ grot, float2* __restrict__ gobj, RotGeom g, int y_lo,
+                                                           int y_hi) {
+    const size_t n = (size_t)(y_hi - y_lo) * g.X * g.Z;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int z = (int)(i % g.Z);
+        const size_t yx = i / g.Z;
+        const int x = (int)(yx % g.X), y = y_lo + (int)(yx / g.X);
+        const float2 v = grot[((size_t)z * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + x];
+        float2* o = gobj + ((size_t)y * g.X + x) * g.Z + z;
+        float2 c = *o;
+        c.x += v.x;
+        c.y += v.y;
+        *o = c;
+    }
+}
+
 // slice transmissions of rows [row_lo, row_hi) of every slice of a rotated-frame buffer (pads included): the cache's
 // initial fill (obj_rot == nullptr: vacuum, 1 + 0i) and adm_transmission_refresh
 __global__ __launch_bounds__(256) void transmission_kernel(const float2* __restrict__ rot, float2* __restrict__ trans, float k1,
@@ -736,23 +768,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const 
 // asked -- the drift guard of the position corrections (center_rows_kernel's sums), the pin of the first entries to fixed values,
 // and the zero fill of the gradient accumulator for the next minibatch.  These paths are launch-bound (4-5 us per launch whatever
 // its size): config-5 shape 24 -> 17 launches per minibatch, config-1 shape 17 -> 10.
-struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; };
+// An array without a drift guard is element-wise, so it is spread over ceil(n / SMALL_CHUNK) workgroups (five probe modes of
+// 64 x 64 took 77 us in ONE workgroup, 40 % of a config-1-shape minibatch); an array with one stays in a single workgroup
+// (its column means need every element).  first_block[i]: the first workgroup of array i; first_block[count] = grid size.
+#define SMALL_CHUNK 2048
+struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; int first_block[ADM_SMALL_PARAMS_MAX + 1]; int count; };
 
 __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamScalars a) {
     __shared__ float red[4];
     __shared__ float mean;
-    const adm_small_param q = sp.p[blockIdx.x];
+    int k = 0;
+    while (k + 1 < sp.count && (int)blockIdx.x >= sp.first_block[k + 1]) ++k;
+    const adm_small_param q = sp.p[k];
+    const bool whole = q.center_cols > 0;
+    const size_t lo = whole ? 0 : (size_t)(blockIdx.x - sp.first_block[k]) * SMALL_CHUNK;
+    const size_t hi = whole ? q.n : (lo + SMALL_CHUNK < q.n ? lo + SMALL_CHUNK : q.n);
     a.step = (float)q.step_size;
-    for (size_t i = threadIdx.x; i < q.n; i += blockDim.x) {
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         float mv, vv;
-        const float xn = adam_value(q.x[i], q.g[i], q.m[i], q.v[i], a, i, mv, vv);
+        float xn = adam_value(q.x[i], q.g[i], q.m[i], q.v[i], a, i, mv, vv);
         q.m[i] = mv;
         q.v[i] = vv;
+        if (!whole && q.pin && i < q.pin_n) xn = q.pin[i];       // (with a drift guard the pin follows the re-centring, below)
         q.x[i] = xn;
         if (q.zero_grad) q.g[i] = 0.f;
     }
+    if (!whole) return;
     __syncthreads();
-    if (q.center_cols > 0) center_rows_block(q.x, q.n / (size_t)q.center_cols, q.center_cols, red, &mean);
+    center_rows_block(q.x, q.n / (size_t)q.center_cols, q.center_cols, red, &mean);
     if (q.pin) {
         for (size_t i = threadIdx.x; i < q.pin_n; i += blockDim.x) q.x[i] = q.pin[i];
     }
@@ -851,9 +894,13 @@ extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* 
     const int y_chunk = 32;
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
     // cache mode 2: only the transmissions are written (half the stores); obj_rot then merely names the image the cache holds
-    hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords,
-                       (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot, plan->trans_dev, d.k1,
-                       (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
+    float2* rot_out = (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot;
+    if (!coords && d.obj_z < 16)
+        hipLaunchKernelGGL(identity_fwd_kernel, dim3(stream_grid((size_t)(y_hi - y_lo) * d.obj_x * d.obj_z)), dim3(256), 0, plan->ctx->stream,
+                           (const float2*)obj, rot_out, plan->trans_dev, d.k1, (float)d.sign_convention, g, y_lo, y_hi);
+    else
+        hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, rot_out, plan->trans_dev,
+                           d.k1, (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
     ADM_HIP(hipGetLastError());
     if (plan->trans_dev) plan->trans_src = obj_rot;
     return ADM_OK;
@@ -919,8 +966,12 @@ extern "C" int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint1
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
     const int y_chunk = 32;
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
-    hipLaunchKernelGGL(rotate_adj_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, coords, grad_obj, g, y_lo,
-                       y_hi, y_chunk);
+    if (!coords && d.obj_z < 16)
+        hipLaunchKernelGGL(identity_adj_kernel, dim3(stream_grid((size_t)(y_hi - y_lo) * d.obj_x * d.obj_z)), dim3(256), 0, plan->ctx->stream,
+                           (const float2*)grad_rot, (float2*)grad_obj, g, y_lo, y_hi);
+    else
+        hipLaunchKernelGGL(rotate_adj_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, coords, grad_obj, g, y_lo,
+                           y_hi, y_chunk);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }
@@ -1179,14 +1230,20 @@ extern "C" int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, 
     if (count > ADM_SMALL_PARAMS_MAX) return fail(ADM_ERR_INVALID, "adm_adam_step_small: too many arrays in one call");
     SmallParams sp;
     std::memset(&sp, 0, sizeof(sp));
+    int nblocks = 0;
     for (int k = 0; k < count; ++k) {
         const adm_small_param& q = params[k];
         if (!q.x || !q.g || !q.m || !q.v) return fail(ADM_ERR_INVALID, "adm_adam_step_small: null array");
         if (q.center_cols > 0 && q.n % (uint64_t)q.center_cols) return fail(ADM_ERR_INVALID, "adm_adam_step_small: n is not a multiple of center_cols");
         if (q.pin && q.pin_n > q.n) return fail(ADM_ERR_INVALID, "adm_adam_step_small: pin_n exceeds n");
         sp.p[k] = q;
+        sp.first_block[k] = nblocks;
+        nblocks += q.center_cols > 0 ? 1 : (int)((q.n + SMALL_CHUNK - 1) / SMALL_CHUNK);
     }
-    hipLaunchKernelGGL(small_adam_kernel, dim3(count), dim3(256), 0, ctx->stream, sp, adam_scalars(i_batch, 0.0, b1, b2, eps, 0, nullptr));
+    sp.first_block[count] = nblocks;
+    sp.count = count;
+    if (nblocks == 0) return ADM_OK;
+    hipLaunchKernelGGL(small_adam_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, sp, adam_scalars(i_batch, 0.0, b1, b2, eps, 0, nullptr));
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }
