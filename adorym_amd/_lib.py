@@ -75,6 +75,7 @@ SIGNATURES = {
     'adm_all_gather': (_I, [_VP, _VP, _VP, _SZ]),
     'adm_all_reduce': (_I, [_VP, _VP, _SZ, _I]),
     'adm_broadcast': (_I, [_VP, _VP, _SZ, _I]),
+    'adm_reduce': (_I, [_VP, _VP, _SZ, _I]),
     'adm_comm_group_start': (_I, [_VP]),
     'adm_comm_group_end': (_I, [_VP]),
     'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     'adm_tile_cover_build': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _I, _I, _I]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
+    'adm_reg_grad_range': (_I, [_VP, _VP, _F, _F, _F, _VP, _SZ, _SZ, _SZ, _SZ]),
     'adm_reg_grad_set': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_adam_step': (_I, [_VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
     'adm_adam_step_small': (_I, [_VP, C.POINTER(SmallParam), _I, _I, _D, _D, _D]),

@@ -133,6 +133,11 @@ class TorchComm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t
 
+    def reduce_tensor(self, t, root):
+        """t (a tensor or a view of one) of rank ``root`` = sum over ranks of their ``t``, in place."""
+        self.dist.reduce(t, dst=int(root), op=self.dist.ReduceOp.SUM)
+        return t
+
     def all_reduce_device(self, dev):
         """In-place sum over ranks of a libadm device array, through a torch tensor (host bounce: this backend has no
         view of libadm's memory; RcclComm reduces in place on the device)."""
@@ -257,6 +262,12 @@ class RcclComm(object):
         check(self.ctx.lib.adm_broadcast(self.ctx.handle, dev.ptr, dev.nbytes, int(root)))
         return dev
 
+    def reduce(self, dev, root):
+        """dev (a libadm device array / view) of rank ``root`` = sum over ranks of their ``dev``; the others' are left alone."""
+        from ._lib import check
+        check(self.ctx.lib.adm_reduce(self.ctx.handle, dev.ptr, dev.size, int(root)))
+        return dev
+
     def group(self):
         """Context manager: the collectives issued inside are launched as one operation (ncclGroupStart / End)."""
         import contextlib
@@ -341,6 +352,13 @@ class HostStagedComm(RcclComm):
         t = self.torch.from_numpy(dev.get())
         self.dist.broadcast(t, src=int(root))
         if self.rank != int(root):
+            dev.set(t.numpy())
+        return dev
+
+    def reduce(self, dev, root):
+        t = self.torch.from_numpy(dev.get())
+        self.dist.reduce(t, dst=int(root), op=self.dist.ReduceOp.SUM)
+        if self.rank == int(root):
             dev.set(t.numpy())
         return dev
 

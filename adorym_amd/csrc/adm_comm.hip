@@ -34,6 +34,7 @@ struct Api {
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -88,6 +89,7 @@ void load_api(Api& a) {
     ADM_SYM(AllGather, "ncclAllGather")
     ADM_SYM(AllReduce, "ncclAllReduce")
     ADM_SYM(Broadcast, "ncclBroadcast")
+    ADM_SYM(Reduce, "ncclReduce")
     ADM_SYM(GetErrorString, "ncclGetErrorString")
 #undef ADM_SYM
 }
@@ -220,6 +222,15 @@ extern "C" int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root) {
     if (!buf) return fail(ADM_ERR_INVALID, "adm_broadcast: null argument");
     rc = api()->Broadcast(buf, buf, bytes, kUint8, root, comm_for(ctx), ctx->stream);
     return rc ? nccl_fail(rc, "ncclBroadcast") : ADM_OK;
+}
+
+// buf[0 .. count) of rank `root` = sum over ranks of their buf[0 .. count), in place (the other ranks' buffers are left as they are)
+extern "C" int adm_reduce(adm_ctx* ctx, float* buf, size_t count, int root) {
+    int rc = need(ctx, "adm_reduce", true);
+    if (rc) return rc;
+    if (!buf) return fail(ADM_ERR_INVALID, "adm_reduce: null argument");
+    rc = api()->Reduce(buf, buf, count, kFloat32, kSum, root, comm_for(ctx), ctx->stream);
+    return rc ? nccl_fail(rc, "ncclReduce") : ADM_OK;
 }
 
 // Several collectives of one communicator issued between the two calls are launched as ONE operation (ncclGroupStart /

@@ -474,7 +474,8 @@ __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 
 // SET: g = regulariser gradient (replaces a zero fill + accumulate when the gradient buffer is being initialised).
 // One thread per voxel (both channels, float2), threads along z (the fastest axis), blockIdx = (x, y): no integer divisions,
 // every load an 8-byte coalesced access (the y / x neighbours are whole rows one plane / one row away).
-template <bool SET>
+// MODE 0: g += gradient; 1: g = gradient; 2: value only (g untouched)
+template <int SET>
 __global__ __launch_bounds__(256) void reg_grad_kernel(const float2* __restrict__ x, float2* __restrict__ g, int Y, int X, int Z,
                                                        float a_d, float a_b, float gamma, float* reg_partial) {
     const float invV = 1.0f / (float)((size_t)Y * X * Z);
@@ -498,8 +499,8 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float2* __restrict_
             val += gamma * invV * (fabsf(zm.x - v.x) + fabsf(xm.x - v.x) + fabsf(ym.x - v.x));
             val += gamma * invV * (fabsf(zm.y - v.y) + fabsf(xm.y - v.y) + fabsf(ym.y - v.y));
         }
-        if (SET) g[row + z] = gr;
-        else { float2 o = g[row + z]; o.x += gr.x; o.y += gr.y; g[row + z] = o; }
+        if (SET == 1) g[row + z] = gr;
+        else if (SET == 0) { float2 o = g[row + z]; o.x += gr.x; o.y += gr.y; g[row + z] = o; }
     }
     if (reg_partial) {
         // one partial per (y, x) row, summed in a fixed order by reg_value_reduce_kernel: 65 536 atomics on ONE address
@@ -514,6 +515,38 @@ __global__ __launch_bounds__(256) void reg_grad_kernel(const float2* __restrict_
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
             reg_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
         }
+    }
+}
+
+// The same gradient for the flat fp32 elements [lo, hi) of the object only (a rank's shard of a sharded update), ADDED where the
+// element lies in [add_lo, add_hi) and WRITTEN elsewhere: the footprint-restricted exchange reduces the data term over the planes
+// the global batch touched and leaves everything else of the gradient buffer undefined -- the regulariser term, the same on every
+// rank, is put in afterwards by the owner with R-fold weights.  blockIdx.y counts planes from y0.
+__global__ __launch_bounds__(256) void reg_grad_range_kernel(const float2* __restrict__ x, float* __restrict__ g, int Y, int X, int Z,
+                                                             float a_d, float a_b, float gamma, int y0, size_t lo, size_t hi, size_t add_lo,
+                                                             size_t add_hi) {
+    const float invV = 1.0f / (float)((size_t)Y * X * Z);
+    const int xx = blockIdx.x, y = y0 + blockIdx.y;
+    const size_t sx = (size_t)Z, sy = (size_t)Z * X;
+    const size_t row = (size_t)y * sy + (size_t)xx * sx;
+    const size_t row_xm = (size_t)y * sy + (size_t)((xx + X - 1) % X) * sx, row_xp = (size_t)y * sy + (size_t)((xx + 1) % X) * sx;
+    const size_t row_ym = (size_t)((y + Y - 1) % Y) * sy + (size_t)xx * sx, row_yp = (size_t)((y + 1) % Y) * sy + (size_t)xx * sx;
+    for (int z = threadIdx.x; z < Z; z += blockDim.x) {
+        const size_t e = 2 * (row + z);
+        if (e + 1 < lo || e >= hi) continue;
+        const float2 v = x[row + z];
+        float2 gr = make_float2(0.f, 0.f);
+        if (a_d != 0.f) gr.x += a_d * sgn(v.x) * invV;
+        if (a_b != 0.f) gr.y += a_b * sgn(v.y) * invV;
+        if (gamma != 0.f) {
+            const float2 zm = x[row + (z + Z - 1) % Z], zp = x[row + (z + 1) % Z];
+            const float2 xm = x[row_xm + z], xp = x[row_xp + z];
+            const float2 ym = x[row_ym + z], yp = x[row_yp + z];
+            gr.x += gamma * invV * ((sgn(v.x - zp.x) - sgn(zm.x - v.x)) + (sgn(v.x - xp.x) - sgn(xm.x - v.x)) + (sgn(v.x - yp.x) - sgn(ym.x - v.x)));
+            gr.y += gamma * invV * ((sgn(v.y - zp.y) - sgn(zm.y - v.y)) + (sgn(v.y - xp.y) - sgn(xm.y - v.y)) + (sgn(v.y - yp.y) - sgn(ym.y - v.y)));
+        }
+        if (e >= lo && e < hi) g[e] = (e >= add_lo && e < add_hi) ? g[e] + gr.x : gr.x;
+        if (e + 1 >= lo && e + 1 < hi) g[e + 1] = (e + 1 >= add_lo && e + 1 < add_hi) ? g[e + 1] + gr.y : gr.y;
     }
 }
 
@@ -1146,7 +1179,8 @@ extern "C" int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t work
 
 static int reg_grad_impl(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
                          float* reg_value, bool set) {
-    if (!plan || !obj || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad: null argument");
+    if (!plan || !obj || (!grad_obj && !reg_value)) return fail(ADM_ERR_INVALID, "adm_reg_grad: null argument");
+    if (!grad_obj && plan->d.unknown_type == 1) return fail(ADM_ERR_UNSUPPORTED, "adm_reg_grad: value-only evaluation is built for delta_beta unknowns");
     const adm_plan_desc& d = plan->d;
     const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2;
     hipStream_t st = plan->ctx->stream;
@@ -1172,11 +1206,14 @@ static int reg_grad_impl(adm_plan* plan, const float* obj, float alpha_d, float 
         if (!plan->reg_partial) ADM_HIP(hipMalloc((void**)&plan->reg_partial, (size_t)d.obj_x * d.obj_y * sizeof(float)));
         partial = plan->reg_partial;
     }
-    if (set)
-        hipLaunchKernelGGL(reg_grad_kernel<true>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
+    if (!grad_obj)
+        hipLaunchKernelGGL(reg_grad_kernel<2>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)nullptr, d.obj_y, d.obj_x, d.obj_z,
+                           alpha_d, alpha_b, gamma, partial);
+    else if (set)
+        hipLaunchKernelGGL(reg_grad_kernel<1>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
                            alpha_d, alpha_b, gamma, partial);
     else
-        hipLaunchKernelGGL(reg_grad_kernel<false>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
+        hipLaunchKernelGGL(reg_grad_kernel<0>, grid, dim3(nt), 0, st, (const float2*)obj, (float2*)grad_obj, d.obj_y, d.obj_x, d.obj_z,
                            alpha_d, alpha_b, gamma, partial);
     if (reg_value)
         hipLaunchKernelGGL(reg_value_reduce_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial, d.obj_x * d.obj_y, reg_value);
@@ -1192,6 +1229,22 @@ extern "C" int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, flo
 extern "C" int adm_reg_grad_set(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
                                 float* reg_value) {
     return reg_grad_impl(plan, obj, alpha_d, alpha_b, gamma, grad_obj, reg_value, true);
+}
+
+extern "C" int adm_reg_grad_range(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
+                                  size_t lo, size_t hi, size_t add_lo, size_t add_hi) {
+    if (!plan || !obj || !grad_obj) return fail(ADM_ERR_INVALID, "adm_reg_grad_range: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (d.unknown_type != 0) return fail(ADM_ERR_UNSUPPORTED, "adm_reg_grad_range: built for delta_beta unknowns");
+    const size_t n = (size_t)d.obj_y * d.obj_x * d.obj_z * 2, plane = (size_t)d.obj_x * d.obj_z * 2;
+    if (hi > n) hi = n;
+    if (lo >= hi) return ADM_OK;
+    const int y0 = (int)(lo / plane), y1 = (int)((hi + plane - 1) / plane);
+    const int nt = d.obj_z >= 192 ? 256 : (d.obj_z >= 96 ? 128 : 64);
+    hipLaunchKernelGGL(reg_grad_range_kernel, dim3(d.obj_x, y1 - y0), dim3(nt), 0, plan->ctx->stream, (const float2*)obj, grad_obj, d.obj_y,
+                       d.obj_x, d.obj_z, alpha_d, alpha_b, gamma, y0, lo, hi, add_lo, add_hi);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
 }
 
 extern "C" int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols) {

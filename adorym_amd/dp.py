@@ -136,7 +136,7 @@ class DataParallelObject(object):
         else:
             raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
 
-    def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None, first=None):
+    def exchange_and_update(self, optimizer, i_batch, options, flags=0, mask=None, first=None, touched=None, reg_shard=None):
         """optimizer: 'adam' | 'gd' | 'momentum'.  options: dict(step_size=..., b1=..., ...) as the reference's options_dict.
 
         ``first=(lo, hi)`` (flat element range): the part of the object the NEXT minibatch reads (its y-planes).  Nothing
@@ -147,10 +147,33 @@ class DataParallelObject(object):
           * several ranks, in-place RCCL exchange: every rank updates its whole shard (1/R of the object), then the part of
             EVERY shard inside ``first`` is broadcast from its owner (a fraction of the object, from a few owners) and the full
             all-gather is deferred to finish_update().  ``first`` must then be the SAME on every rank -- the union of the planes
-            the next minibatches of ALL ranks read -- because it shapes a collective."""
+            the next minibatches of ALL ranks read -- because it shapes a collective.
+
+        ``touched=(lo, hi)`` + ``reg_shard`` (several ranks; opt-in): the footprint-restricted exchange.  The gradient buffers
+        hold the DATA term only, and only on [lo, hi) -- the y-planes the global batch touched, the same range on every rank;
+        everything else of the buffers is undefined.  Instead of reduce-scattering the whole buffer, the part of every shard
+        inside [lo, hi) is summed onto its owner (one grouped launch of <= R reductions), and the owner then calls
+        ``reg_shard(shard_lo, shard_hi, lo, hi)``, which ADDS the regulariser gradient -- identical on every rank in the
+        reference, hence R-fold -- inside [lo, hi) and WRITES it elsewhere on the shard.  Same sums as the full exchange up to
+        the order of two fp32 additions per element."""
         self.finish_update()
         self._tic('reduce_scatter')
-        if self.inplace:
+        if touched is not None and self.dist and self.comm.size > 1:
+            if reg_shard is None:
+                raise ValueError('exchange_and_update: touched= needs reg_shard=')
+            t_lo, t_hi = max(0, int(touched[0])), min(self.n, int(touched[1]))
+            import contextlib
+            with (self.comm.group() if hasattr(self.comm, 'group') else contextlib.nullcontext()):
+                for r in range(self.comm.size):
+                    s_lo, s_hi = max(r * self.per, t_lo), min((r + 1) * self.per, t_hi)
+                    if s_hi > s_lo:
+                        if self.inplace:
+                            self.comm.reduce(self.grad.view(s_lo, (s_hi - s_lo,)), r)
+                        else:
+                            self.comm.reduce_tensor(self.t_grad[s_lo:s_hi], r)
+            reg_shard(self.lo, self.hi, t_lo, t_hi)
+            g, g_base = self.grad, 0
+        elif self.inplace:
             self.comm.reduce_scatter_sum(self.grad, self.grad.view(self.lo, (self.per,)))
             g, g_base = self.grad, 0
         elif self.dist:

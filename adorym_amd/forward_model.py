@@ -275,9 +275,18 @@ class PtychographyModel(ForwardModel):
         if side_hook is not None:
             side_hook()
         # init_grad: grad_obj is uninitialised -- the regulariser kernel writes it (one pass) or it is zero-filled
-        self._reg_pending = self._regularize_launch(obj, grad_obj if want_grad else None, init_grad and want_grad) if regularize else False
-        if init_grad and want_grad and not regularize:
-            grad_obj.zero_()
+        rx = getattr(self, 'restricted_planes', None) if (want_grad and init_grad) else None
+        if rx is not None:
+            # footprint-restricted exchange (DataParallelObject.exchange_and_update(touched=...)): the gradient buffer carries
+            # the DATA term only, on the planes the global batch touches -- zero those; the regulariser's gradient is added by
+            # the shard owners after the reduction, only its VALUE (for the loss log) is evaluated here
+            plane = int(np.prod(eng.obj_size[1:])) * 2 * 4
+            check(ctx.lib.adm_memset(ctx.handle, grad_obj.ptr + rx[0] * plane, 0, (rx[1] - rx[0]) * plane))
+            self._reg_pending = self._regularize_launch(obj, None, False, value_only=True) if regularize else False
+        else:
+            self._reg_pending = self._regularize_launch(obj, grad_obj if want_grad else None, init_grad and want_grad) if regularize else False
+            if init_grad and want_grad and not regularize:
+                grad_obj.zero_()
         if want_grad and isinstance(coords, RotationTable):
             # first minibatch of an angle: its rotation-adjoint tables are built here, on the side stream beside the
             # multislice kernel (0.4 ms of emit + sort), not on the main stream when the back-rotation asks for them
@@ -317,10 +326,10 @@ class PtychographyModel(ForwardModel):
             eng.rotate_adjoint(grad_obj, coords, yr)
         return gp, gsh
 
-    def _regularize_launch(self, obj, grad_obj, init_grad=False):
+    def _regularize_launch(self, obj, grad_obj, init_grad=False, value_only=False):
         """Queue the regulariser kernels (value into a device scalar, gradient added to grad_obj if given) on the
         current stream.  ``init_grad``: grad_obj holds garbage and is initialised here (regulariser kernel in 'set' mode,
-        or a zero fill).  Returns True if a value is pending."""
+        or a zero fill).  ``value_only``: no gradient at all (plain L1 / TV).  Returns True if a value is pending."""
         from .regularizers import ReweightedL1Regularizer
         ad, ab, gm = combined_weights(self.reg_list)
         rw = [r for r in self.reg_list if isinstance(r, ReweightedL1Regularizer)]
@@ -332,6 +341,12 @@ class PtychographyModel(ForwardModel):
         if self._reg_val is None:
             self._reg_val = self.device.zeros((1,))
         self._reg_val.zero_()
+        if value_only:
+            if rw:
+                raise NotImplementedError('value-only regulariser evaluation with a reweighted L1 term')
+            k = float(self.batch_group)
+            check(self.device.lib.adm_reg_grad(self.engine.plan.handle, obj.ptr, ad * k, ab * k, gm * k, None, self._reg_val.ptr))
+            return True
         if grad_obj is None:
             if getattr(self, '_scratch_grad', None) is None or self._scratch_grad.size != obj.size:
                 self._scratch_grad = self.device.empty((obj.size,))

@@ -358,6 +358,9 @@ def main():
                          'communicator -- nothing that has never run on real multi-GPU hardware sits in front of the measurement; '
                          'auto = check the two-part gather bitwise against the plain one on the running job, time both, keep the '
                          'faster (an experiment: ask for it explicitly)')
+    ap.add_argument('--restricted-exchange', action='store_true',
+                    help='N > 1 experiment: sum only the y-planes the global batch touches, each part onto its owner; the owners add '
+                         'the regulariser term N-fold (DESIGN.md section 6; tests/test_gpu_world2.py).  Off by default.')
     args = ap.parse_args()
 
     import torch
@@ -484,6 +487,12 @@ def main():
             loss_box[0] = eng.loss_result(token)
             pending[0] = None
 
+    restricted = bool(args.restricted_exchange and use_dist)
+
+    def reg_shard(lo_, hi_, alo_, ahi_):      # the regulariser term of all `world` ranks, on this rank's shard [lo_, hi_)
+        check(ctx.lib.adm_reg_grad_range(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * world, cfg['alpha_b'] * world,
+                                         cfg['gamma'] * world, state.grad.ptr, lo_, hi_, alo_, ahi_))
+
     def step(k, timed):
         it, ind = plan_batches[k]
         pos = pos_all[ind]
@@ -495,8 +504,14 @@ def main():
         ctx.fork()
         eng.flush_loss_copy()       # the previous step's loss read-back, off the main stream
         state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
-        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
-                                       state.grad.ptr, None))      # initialises the gradient buffer: no separate zero fill
+        if restricted:
+            # only the planes the GLOBAL batch touches are initialised (zero) and exchanged; the regulariser comes in after the sum
+            ty0, ty1 = eng.y_footprint(pos_all[plan_all[k]])
+            touched = (ty0 * X * Z * 2, ty1 * X * Z * 2)
+            state.grad.view(touched[0], (touched[1] - touched[0],)).zero_()
+        else:
+            check(ctx.lib.adm_reg_grad_set(eng.plan.handle, state.obj.ptr, cfg['alpha_d'], cfg['alpha_b'], cfg['gamma'],
+                                           state.grad.ptr, None))      # initialises the gradient buffer: no separate zero fill
         eng.build_cover()           # cover lists of the overlap-add: positions only, built beside the kernel
         ctx.end_fork()
         evs = ev_ms[k & 1] if timed else None
@@ -515,7 +530,10 @@ def main():
         if k + 1 < len(plan_batches):
             ny0, ny1 = eng.y_footprint(pos_all[plan_all[k + 1]])
             first = (ny0 * X * Z * 2, ny1 * X * Z * 2)
-        state.exchange_and_update('adam', k, opt_options, first=first)
+        if restricted:
+            state.exchange_and_update('adam', k, opt_options, first=first, touched=touched, reg_shard=reg_shard)
+        else:
+            state.exchange_and_update('adam', k, opt_options, first=first)
         token = eng.loss_async()
         resolve()                       # the PREVIOUS step's kernel time and loss
         pending[0] = (token, evs)
@@ -608,7 +626,7 @@ def main():
                           'first_gather_ms': phases.get('first_gather', 0.0), 'deferred_gather_ms': phases.get('deferred_gather', 0.0)},
             'comm': {'backend': getattr(comm, 'backend', 'local'), 'size': comm.size, 'adm_comm_size': abi_size, 'expected': world,
                      'side_stream_communicator': getattr(comm, 'backend', '') == 'rccl' and os.environ.get('ADM_COMM_AUX', '1') == '1',
-                     'gather': gather, 'note': comm_note},
+                     'gather': gather, 'restricted_exchange': restricted, 'note': comm_note},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)

@@ -114,6 +114,10 @@ int adm_reduce_scatter(adm_ctx* ctx, const float* send, float* recv, size_t recv
 int adm_all_gather(adm_ctx* ctx, const float* send, float* recv, size_t send_count);
 int adm_all_reduce(adm_ctx* ctx, float* buf, size_t count, int op_max);
 int adm_broadcast(adm_ctx* ctx, void* buf, size_t bytes, int root);
+/* buf[0 .. count) of rank `root` = the sum over ranks of their buf[0 .. count) (in place; other ranks' buffers unchanged): the
+ * data term of `comm.allreduce(gradient.arr)` (adorym/ptychography.py:1113-1114) delivered to the rank that owns those elements
+ * of a sharded update, for the part of the gradient the global batch touched (adm_reg_grad_range supplies the rest). */
+int adm_reduce(adm_ctx* ctx, float* buf, size_t count, int root);
 /* Collectives issued between the two calls are launched together (ncclGroupStart / ncclGroupEnd). */
 int adm_comm_group_start(adm_ctx* ctx);
 int adm_comm_group_end(adm_ctx* ctx);
@@ -298,6 +302,13 @@ int adm_reg_grad_set(adm_plan* plan, const float* obj, float alpha_d, float alph
                      float* reg_value);
 int adm_reg_grad(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj,
                  float* reg_value);
+/* (grad_obj == NULL with reg_value != NULL: the value only; delta_beta unknowns.)
+ * adm_reg_grad_range: the same gradient for the flat fp32 elements [lo, hi) of the object only -- a rank's shard of a sharded
+ * update -- ADDED where the element lies in [add_lo, add_hi) and WRITTEN elsewhere.  Every rank of the reference adds its own,
+ * identical, regulariser term before the all-reduce (adorym/forward_model.py:138-139); with the exchange restricted to the planes
+ * the global batch touched, the owner adds it here instead, with R-fold weights (delta_beta unknowns, plain L1 / TV). */
+int adm_reg_grad_range(adm_plan* plan, const float* obj, float alpha_d, float alpha_b, float gamma, float* grad_obj, size_t lo,
+                       size_t hi, size_t add_lo, size_t add_hi);
 
 /* ---- R13-R15  fused optimiser step + constraints on elements [lo, hi) of flat arrays -----
  * AdamOptimizer.apply_gradient math (adorym/optimizers.py:309-318), then non-negativity clip,

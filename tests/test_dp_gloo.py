@@ -306,3 +306,75 @@ def test_product_task_split_matches_reference_golden_both_ranks():
     # config 3's padded minibatch is the deterministic set SURVEY R17 describes
     last = epoch_task_list(0, 2, 529, 32, 1)[16]
     assert sorted(last[:, 1].tolist()) == list(range(0, 15)) + list(range(512, 529))
+
+
+# ------------------------------------------------------------------------------------------ footprint-restricted exchange
+def _worker_restricted(rank, world, port, shape, out_q):
+    """Two updates on a [Y,X,Z,2] object: every rank's DATA gradient lives on its own footprint planes inside the union
+    [t0, t1) of the ranks' footprints, the regulariser term (the same on every rank: it depends on the replicated object only)
+    everywhere.  Full exchange: buffers = regulariser + data, reduce-scatter.  Restricted: buffers = data on [t0, t1) and
+    garbage elsewhere, per-owner reductions over [t0, t1), regulariser added R-fold by the owner."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from adorym_amd.comm import TorchComm
+    from adorym_amd.dp import DataParallelObject
+    from oracle import adorym_oracle as O
+    comm = TorchComm('gloo')
+    try:
+        Y, X, Z, _ = shape
+        plane = X * Z * 2
+        n = int(np.prod(shape))
+        x0 = (np.random.default_rng(3).standard_normal(n) * 1e-3).astype(np.float32)
+        a_d, a_b, gam = 1e-2, 1e-3, 1e-2
+
+        def reg(x):
+            o = x[:n].reshape(shape).astype(np.float32)
+            return (O.l1_value_grad(o, a_d, a_b)[1] + O.tv_value_grad(o, gam)[1]).astype(np.float32).reshape(-1)
+
+        res = {}
+        for mode in ('full', 'restricted'):
+            st = DataParallelObject(NumpyOps(), comm, shape)
+            st.obj[:n] = x0
+            for it in range(2):
+                foot = [(1 + it, 4 + it), (3 + it, 6 + it)]                   # rank footprints (planes), overlapping
+                t0, t1 = min(f[0] for f in foot) * plane, max(f[1] for f in foot) * plane
+                data = np.zeros(n, np.float32)
+                lo, hi = foot[rank][0] * plane, foot[rank][1] * plane
+                data[lo:hi] = np.random.default_rng(50 * it + rank).standard_normal(hi - lo).astype(np.float32) * 1e-3
+                if mode == 'full':
+                    st.grad[:n] = reg(st.obj) + data
+                    st.exchange_and_update('adam', it, {'step_size': 1e-4})
+                else:
+                    st.grad[:] = np.float32(np.nan)                            # whatever is outside [t0, t1) must not matter
+                    st.grad[t0:t1] = data[t0:t1]
+                    r_now = reg(st.obj) * np.float32(world)
+
+                    def reg_shard(s_lo, s_hi, a_lo, a_hi, r_now=r_now, st=st):
+                        s_hi = min(s_hi, n)
+                        idx = np.arange(s_lo, s_hi)
+                        add = (idx >= a_lo) & (idx < a_hi)
+                        st.grad[idx[add]] += r_now[idx[add]]
+                        st.grad[idx[~add]] = r_now[idx[~add]]
+                    st.exchange_and_update('adam', it, {'step_size': 1e-4}, touched=(t0, t1), reg_shard=reg_shard)
+            res[mode] = np.array(st.obj[:n])
+        out_q.put((rank, res['full'], res['restricted']))
+    finally:
+        comm.close()
+
+
+def test_restricted_exchange_equals_full_exchange_world2():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    shape = (9, 4, 5, 2)            # n = 360: shard boundaries fall inside a plane (40 elements per plane)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_restricted, args=(r, world, port, shape, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, full, restricted in res:
+        assert np.all(np.isfinite(restricted))
+        # same sums up to the order of two fp32 additions per element: Adam (lr 1e-4) turns that into <= a few 1e-10
+        assert np.abs(restricted - full).max() <= 2e-3 * 1e-4, np.abs(restricted - full).max()
+    assert np.array_equal(res[0][2], res[1][2])                  # replicas identical

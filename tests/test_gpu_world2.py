@@ -56,6 +56,16 @@ def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate):
             return orig(self, **kw)
 
         DF.Differentiator.get_gradients = rec
+        from adorym_amd import dp as DP
+        restricted = []
+        orig_x = DP.DataParallelObject.exchange_and_update
+
+        def rec_x(self, *a, **kw):
+            if kw.get('touched') is not None:
+                restricted.append(tuple(int(v) for v in kw['touched']))
+            return orig_x(self, *a, **kw)
+
+        DP.DataParallelObject.exchange_and_update = rec_x
         comm = C.from_env()
         assert isinstance(comm, C.HostStagedComm) and comm.size == world and comm.device_index == 0
         params = _params(n_use, extra, tmp)
@@ -65,7 +75,7 @@ def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate):
             params['fname'] = params['fname'][:1]
         st = A.reconstruct_ptychography(comm=comm, **params)
         out = dict(rank=rank, delta=st['delta'], beta=st['beta'], losses=np.array(st['losses']), probe=st['probe_real'] + 1j * st['probe_imag'],
-                   theta=np.array([s_[0] for s_ in seen]), ind=[s_[1] for s_ in seen])
+                   theta=np.array([s_[0] for s_ in seen]), ind=[s_[1] for s_ in seen], restricted=restricted)
         if emulate and rank == 0:
             out['emulated'] = _serial_two_rank_update(A, params, seen, world)
         comm.close()
@@ -256,3 +266,38 @@ def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg
     emu = res[0]['emulated']
     for r in res:
         assert np.array_equal(r['delta'], emu[..., 0]) and np.array_equal(r['beta'], emu[..., 1])
+
+
+@pytest.mark.parametrize('run', ['immediate6_reg', 'immediate', 'perangle'])
+def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
+    """ADM_RESTRICTED_EXCHANGE=1 (adorym_amd/dp.py, exchange_and_update(touched=...)): only the y-planes the GLOBAL batch touches
+    are summed over the ranks -- each part onto the rank that owns it (adm_reduce) -- and the regulariser term, which every rank of
+    the reference adds to its own gradient (adorym/forward_model.py:138-139), is added R-fold by the owners afterwards
+    (adm_reg_grad_range); outside the touched planes the gradient buffers are never initialised (NaN here would poison the
+    update).  Against the full exchange of the same run: the same sums up to the order of two fp32 additions per element, so
+    the objects agree to a rounding of the update except where Adam's sign-like first steps amplify it (counted), the losses
+    agree, both ranks hold the same bits.  'immediate' has global batches that straddle two angles; 'perangle' touches the
+    whole object."""
+    n_use, extra = cases.W2_RUNS[run]
+    if run != 'immediate6_reg':
+        extra = dict(extra, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)      # (the regulariser is what the owners add back)
+    full = run_world2(tmp_path / 'a', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '0'})
+    rest = run_world2(tmp_path / 'b', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '1'})
+    lr = extra['learning_rate']
+    n_obj = 2 * cases.E2E['N'] ** 3
+    assert not full[0]['restricted'] and len(rest[0]['restricted']) > 0 and rest[0]['restricted'] == rest[1]['restricted']
+    frac = np.mean([(hi - lo) / n_obj for lo, hi in rest[0]['restricted']])
+    print('%s: %d restricted exchanges, mean touched fraction of the object %.2f' % (run, len(rest[0]['restricted']), frac))
+    assert (frac == 1.0) if run == 'perangle' else (frac < 1.0)
+    for a, b in zip(full, rest):
+        xa = np.stack([a['delta'], a['beta']], -1).astype(np.float64)
+        xb = np.stack([b['delta'], b['beta']], -1).astype(np.float64)
+        assert np.all(np.isfinite(xb))
+        d = np.abs(xb - xa)
+        flipped = d > 0.5 * lr
+        print('%s rank %d: restricted vs full exchange: max |dx| %.2e (lr %.0e), voxels off by > lr/2: %d of %d'
+              % (run, a['rank'], d.max(), lr, flipped.sum(), d.size))
+        assert flipped.mean() < 1e-3 and d.max() < 1e-4
+        assert np.linalg.norm(d[~flipped]) <= 1e-3 * np.linalg.norm(xa - np.stack(cases.e2e_inputs()['guess'], -1))
+        assert np.allclose(a['losses'], b['losses'], rtol=1e-5)
+    assert np.array_equal(rest[0]['delta'], rest[1]['delta']) and np.array_equal(rest[0]['beta'], rest[1]['beta'])
