@@ -33,17 +33,23 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return C(V(a) * s); }
 __device__ __forceinline__ cf caxpy(cf a, float s, cf b) { return C(__builtin_elementwise_fma(V(b), (v2f){s, s}, V(a))); }
 
 // a * b:  t = (a.x b.x, a.x b.y);  r = (-a.y b.y + t.x, a.y b.x + t.y)
+// (ONE asm statement for the two instructions, and no temporary shared between consecutive products: between two asm
+// statements of which the second reads or writes a register the first writes, the compiler's gfx950 hazard recogniser puts
+// an s_nop -- it cannot see that a v_pk_* has no dst_sel forwarding hazard -- which was ~45 wasted issue slots per wave and
+// propagation.)
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(V(a)), "v"(V(b)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(V(a)), "v"(V(b)), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r) : "v"(V(a)), "v"(V(b)));
     return C(r);
 }
 // a * conj(b):  t = (a.x b.x, -a.x b.y);  r = (a.y b.y + t.x, a.y b.x + t.y)
 __device__ __forceinline__ cf cmulc(cf a, cf b) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(V(a)), "v"(V(b)));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(V(a)), "v"(V(b)), "v"(t));
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r) : "v"(V(a)), "v"(V(b)));
     return C(r);
 }
 template <bool CONJ> __device__ __forceinline__ cf cmul_t(cf a, cf b) { return CONJ ? cmulc(a, b) : cmul(a, b); }
