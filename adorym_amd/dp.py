@@ -158,7 +158,7 @@ class DataParallelObject(object):
         the order of two fp32 additions per element."""
         self.finish_update()
         self._tic('reduce_scatter')
-        if touched is not None and self.dist and self.comm.size > 1:
+        if touched is not None and self.dist:
             if reg_shard is None:
                 raise ValueError('exchange_and_update: touched= needs reg_shard=')
             t_lo, t_hi = max(0, int(touched[0])), min(self.n, int(touched[1]))

@@ -109,6 +109,52 @@ def test_driver_refuses_overcovered_fused_angle(A, ctx, tmp_path):
                                    random_theta=False, store_checkpoint=False, use_checkpoint=False, cpu_only=False)
 
 
+def test_rccl_restricted_exchange_world1_equals_local_bitwise(A, ctx, rccl_world1):
+    """The footprint-restricted exchange through RCCL itself (grouped ncclReduce onto the owner, adm_reduce) at world size 1:
+    the gradient buffer holds the data term on the touched range only and NaN elsewhere, the owner's `reg_shard` callback writes
+    the (here zero) regulariser term outside the range -- the result equals, bit for bit, the local update with a gradient that
+    is zero outside the range."""
+    from adorym_amd import comm as C
+    from adorym_amd.dp import DataParallelObject, HipOps
+    shape = (5, 6, 7, 2)
+    r = cases.rng(19)
+    n = int(np.prod(shape))
+    x0 = (r.standard_normal(n) * 1e-3).astype(np.float32)
+    grads = [r.standard_normal(n).astype(np.float32) for _ in range(3)]
+    t_lo, t_hi = 84, 336                    # planes 1..3 of 5
+    rc = rccl_world1.attach(ctx)
+    try:
+        out = []
+        for comm in (C.LocalComm(), rc):
+            st = DataParallelObject(HipOps(ctx), comm, shape)
+            st.obj.view(0, (n,)).set(x0)
+            for it in range(3):
+                g = grads[it].copy()
+                if comm is rc:
+                    g[:t_lo] = np.nan
+                    g[t_hi:] = np.nan
+
+                    def reg_shard(lo, hi, alo, ahi):
+                        assert (lo, alo, ahi) == (0, t_lo, t_hi) and hi >= n
+                        st.grad.view(0, (alo,)).zero_()
+                        st.grad.view(ahi, (n - ahi,)).zero_()
+                    st.grad.view(0, (n,)).set(g)
+                    st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1, touched=(t_lo, t_hi), reg_shard=reg_shard)
+                else:
+                    g[:t_lo] = 0
+                    g[t_hi:] = 0
+                    st.grad.view(0, (n,)).set(g)
+                    st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1)
+            st.finish_update()
+            out.append((st.obj.view(0, (n,)).get(), st.moments[0].get(), st.moments[1].get()))
+        for a, b in zip(out[0], out[1]):
+            assert np.all(np.isfinite(b[:n])) and np.array_equal(a[:n], b[:n])
+    finally:
+        ctx.sync()
+        ctx.lib.adm_comm_destroy(ctx.handle)
+        rc.ctx = None
+
+
 def test_rccl_comm_world1_equals_local_bitwise(A, ctx, rccl_world1):
     """The multi-GPU code path (adm_comm_init, in-place adm_reduce_scatter / adm_all_gather through RCCL, sharded update) at
     world size 1 gives bit for bit what the single-GPU path gives after 3 Adam steps and a GD step; the small-gradient
