@@ -52,6 +52,17 @@ __device__ __forceinline__ cf cmulc(cf a, cf b) {
         : "=&v"(r) : "v"(V(a)), "v"(V(b)));
     return C(r);
 }
+// (z.y * c.x, z.x * c.y): the halves of z swapped on the way into a packed multiply; and the same added to g
+__device__ __forceinline__ cf mul_swapped(cf z, v2f c) {
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(V(z)), "v"(c));
+    return C(r);
+}
+__device__ __forceinline__ cf fma_swapped(cf z, v2f c, cf g) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(V(z)), "v"(c), "v"(V(g)));
+    return C(r);
+}
 template <bool CONJ> __device__ __forceinline__ cf cmul_t(cf a, cf b) { return CONJ ? cmulc(a, b) : cmul(a, b); }
 
 // multiply by -i (forward) or +i (inverse)

@@ -308,7 +308,7 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
                                           float2* gtile, const float2* tile_base, size_t slice_stride) {
     using GE = Geo<N, R1, R2>;
     constexpr bool RI = (MODE == 1);
-    const float sk1 = p.sigma * p.k1;
+    const v2f gw = {p.sigma * p.k1, -p.k1};
     const int tid = threadIdx.x;
     ADM_STAMP_DECL;
     float2 db[R1];
@@ -330,12 +330,16 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
             for (int k = 0; k < R1; ++k) {
                 // z = conj(G) * psi'  (delta_beta: psi' is the post-modulation field; real_imag: the stash holds the
                 // pre-modulation field and (d/dre, d/dim) = G * conj(psi) = (Re z, -Im z))
-                const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
-                const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
-                const float gd = RI ? zr : sk1 * zi;
-                const float gb = RI ? -zi : -p.k1 * zr;
-                g[k] = ACC ? make_float2(g[k].x + gd, g[k].y + gb) : make_float2(gd, gb);
-                if (RI) a[k] = cmulc(a[k], db[k]);
+                if (RI) {
+                    const float zr = a[k].x * psi[k].x + a[k].y * psi[k].y;
+                    const float zi = a[k].x * psi[k].y - a[k].y * psi[k].x;
+                    g[k] = ACC ? make_float2(g[k].x + zr, g[k].y - zi) : make_float2(zr, -zi);
+                    a[k] = cmulc(a[k], db[k]);
+                } else {
+                    // (d/ddelta, d/dbeta) = (sigma k1 Im z, -k1 Re z): three packed instructions per pixel
+                    const cf z = cmulc(psi[k], a[k]);
+                    g[k] = ACC ? fma_swapped(z, gw, g[k]) : mul_swapped(z, gw);
+                }
             }
             ws_store<R1>(grow, GE::NT, tid, g);
             ADM_STAMP(9);
