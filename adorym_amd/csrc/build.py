@@ -51,7 +51,8 @@ if __name__ == '__main__':
     # experiment builds: python build.py --variant NAME -DFLAG ...  -> adorym_amd/libadm_NAME.so
     if '--variant' in sys.argv:
         name = sys.argv[sys.argv.index('--variant') + 1]
-        flags = [a for a in sys.argv[1:] if a.startswith('-D') or a.startswith('-m') or a.startswith('-f') or a.startswith('-amdgpu')]
+        flags = [a for i_, a in enumerate(sys.argv[1:]) if a.startswith('-D') or a.startswith('-m') or a.startswith('-f') or a.startswith('-amdgpu')
+                 or sys.argv[i_] == '-mllvm']          # (the value that follows -mllvm)
         print(build(force=True, extra=flags, out=os.path.join(PKG, 'libadm_%s.so' % name), tag='_' + name))
     else:
         extra = ['-DADM_SAFE_SYNC'] if '--safe-sync' in sys.argv else []
