@@ -268,7 +268,7 @@ def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg
         assert np.array_equal(r['delta'], emu[..., 0]) and np.array_equal(r['beta'], emu[..., 1])
 
 
-@pytest.mark.parametrize('run', ['immediate6_reg', 'immediate', 'perangle'])
+@pytest.mark.parametrize('run', ['immediate6_reg', 'immediate', 'perangle', 'probe6'])
 def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
     """ADM_RESTRICTED_EXCHANGE=1 (adorym_amd/dp.py, exchange_and_update(touched=...)): only the y-planes the GLOBAL batch touches
     are summed over the ranks -- each part onto the rank that owns it (adm_reduce) -- and the regulariser term, which every rank of
@@ -300,4 +300,5 @@ def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
         assert flipped.mean() < 1e-3 and d.max() < 1e-4
         assert np.linalg.norm(d[~flipped]) <= 1e-3 * np.linalg.norm(xa - np.stack(cases.e2e_inputs()['guess'], -1))
         assert np.allclose(a['losses'], b['losses'], rtol=1e-5)
+        assert np.allclose(a['probe'], b['probe'], rtol=0, atol=1e-6 * np.abs(a['probe']).max())      # (probe6: the probe is optimised too)
     assert np.array_equal(rest[0]['delta'], rest[1]['delta']) and np.array_equal(rest[0]['beta'], rest[1]['beta'])
