@@ -41,6 +41,7 @@ _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 SIGNATURES = {
     'adm_version': (_I, []),
     'adm_last_error': (C.c_char_p, []),
+    'adm_device_count': (_I, []),
     'adm_ctx_create': (_I, [_I, _VP, C.POINTER(_VP)]),
     'adm_ctx_destroy': (_I, [_VP]),
     'adm_ctx_sync': (_I, [_VP]),

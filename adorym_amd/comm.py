@@ -11,16 +11,17 @@ Backends (all expose the same methods to adorym_amd/dp.py and the driver):
   RcclComm             the product's multi-GPU backend.  Data plane: RCCL over xGMI behind libadm's C ABI
                        (adm_reduce_scatter / adm_all_gather / adm_all_reduce / adm_broadcast, librccl dlopen'ed), enqueued on
                        the context's own streams, IN PLACE on libadm's own device buffers -- two communicators, one per
-                       stream (main; side stream for the deferred part of the object all-gather).  Control plane: a
-                       torch.distributed *gloo* group, used only for the rendezvous (unique ids), seeds, barriers and the
-                       resume agreement.  No torch tensor ever touches the data path;
+                       stream (main; side stream for the deferred part of the object all-gather).  Control plane: the
+                       TCP star of adorym_amd/rendezvous.py (rank 0 listens next to MASTER_PORT): RCCL unique ids, seeds,
+                       barriers, the resume agreement.  No framework anywhere in this path;
   HostStagedComm       validation backend (ADM_COMM=host): the same in-place contract on the same libadm buffers, but every
-                       collective is staged through host memory (adm_d2h -> gloo -> adm_h2d).  It exists so that the PRODUCT
+                       collective is staged through host memory (adm_d2h -> TCP star -> adm_h2d).  It exists so that the PRODUCT
                        -- driver, HIP kernels, sharded optimiser, two-part gather -- can run at world size > 1 with several
                        ranks on ONE GPU, where RCCL refuses duplicate devices.  Slow by construction; never the default;
-  TorchComm('nccl')    the same collectives through torch.distributed tensors (kept as the fallback bench.py agrees on, on
-                       all ranks together, if the C-ABI communicator cannot come up);
-  TorchComm('gloo')    host buffers, for CPU tests of the sharding logic with a NumPy stand-in for the kernels.
+  TorchComm            NOT part of the product path -- the only class here that imports torch.  ('gloo'): host buffers, for CPU
+                       tests of the sharding logic with a NumPy stand-in for the kernels; ('nccl'): the same collectives
+                       through torch.distributed tensors, the fallback bench.py agrees on, on all ranks together, if the
+                       C-ABI communicator cannot come up (such a line says so in `comm.note`).
 """
 import os
 import numpy as np
@@ -167,31 +168,25 @@ class TorchComm(object):
 
 
 class RcclComm(object):
-    """One process per GPU; data plane = RCCL behind the C ABI, control plane = a gloo group (env:// rendezvous:
-    RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run).  ``attach(ctx)`` must be
-    called once with the rank's Context before the first device collective (the driver does)."""
+    """One process per GPU; data plane = RCCL behind the C ABI, control plane = the TCP star of adorym_amd/rendezvous.py
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run, an mpirun wrapper or
+    bench.py's own launcher) -- no framework in the product's multi-GPU path (the reference's seam: mpi4py,
+    adorym/ptychography.py:39-50).  ``attach(ctx)`` must be called once with the rank's Context before the first device
+    collective (the driver does)."""
     backend = 'rccl'
 
-    def __init__(self, device_index=None, init=True):
-        import torch
-        import torch.distributed as dist
-        self.torch = torch
-        self.dist = dist
-        if init and not dist.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29511')
-            os.environ.setdefault('RANK', '0')
-            os.environ.setdefault('WORLD_SIZE', '1')
-            dist.init_process_group(backend='gloo')
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
+    def __init__(self, device_index=None, group=None):
+        from .rendezvous import TcpGroup
+        self.group_ = group if group is not None else TcpGroup.from_env()
+        self.rank = self.group_.rank
+        self.size = self.group_.size
         self.device_index = int(os.environ.get('LOCAL_RANK', '0')) if device_index is None else int(device_index)
         self.ctx = None
 
     def attach(self, ctx):
         """Create the RCCL communicators of this rank on ``ctx`` (collective over all ranks).  Every step that can fail on one
-        rank only WITHOUT blocking the others is followed by an agreement over the gloo group, so that either every rank returns
-        with working communicators or every rank raises the same RuntimeError (callers such as bench.py then fall back
+        rank only WITHOUT blocking the others is followed by an agreement over the control plane, so that either every rank
+        returns with working communicators or every rank raises the same RuntimeError (callers such as bench.py then fall back
         TOGETHER).  Not covered: a rank that dies INSIDE ncclCommInitRank leaves its peers blocked in theirs until RCCL's own
         timeout -- a rendezvous cannot be made symmetric from one side.  Order: (1) each rank probes its own librccl (adm_comm_available) -> agree; (2) rank 0 creates the
         unique ids and ALWAYS broadcasts (None on failure) -> all ranks see the same outcome; (3) adm_comm_init (+ the
@@ -286,96 +281,87 @@ class RcclComm(object):
     def barrier(self):
         if self.ctx is not None:
             self.ctx.sync()
-        self.dist.barrier()
+        self.group_.barrier()
 
     def shard_range(self, n):
         return shard_bounds(n, self.size, self.rank)
 
-    def _host_reduce(self, value, op):
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=op)
-        return float(t.item())
-
     def max_over_ranks(self, value):
-        return self._host_reduce(value, self.dist.ReduceOp.MAX)
+        return self.group_.max_over_ranks(value)
 
     def sum_over_ranks(self, value):
-        return self._host_reduce(value, self.dist.ReduceOp.SUM)
+        return self.group_.sum_over_ranks(value)
 
     def bcast_object(self, obj, root=0):
-        lst = [obj]
-        self.dist.broadcast_object_list(lst, src=root)
-        return lst[0]
+        return self.group_.bcast_object(obj, root)
 
-    def close(self):
+    def close(self, keep_group=False):
+        """``keep_group``: leave the control plane up (bench.py hands it to the fallback transport)."""
         if self.ctx is not None:
             self.ctx.sync()
             self.ctx.lib.adm_comm_destroy(self.ctx.handle)
             self.ctx = None
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        if not keep_group:
+            self.group_.close()
 
 
 class HostStagedComm(RcclComm):
     """VALIDATION backend: RcclComm's interface and in-place buffer contract with every device collective staged through
-    host memory -- blocking adm_d2h, a gloo collective on the host copy, blocking adm_h2d -- so that several ranks can share
-    ONE GPU (RCCL refuses two ranks on one device).  The driver, the HIP kernels, the sharded optimiser and the two-part
-    gather of DataParallelObject run unchanged; only the transport differs.  A collective issued between Context.fork()
-    and end_fork() stages through the side stream, like RcclComm's would run on it.  Selected with ADM_COMM=host."""
+    host memory -- blocking adm_d2h, the control plane's array collective on the host copy (sums in rank order), blocking
+    adm_h2d -- so that several ranks can share ONE GPU (RCCL refuses two ranks on one device).  The driver, the HIP kernels,
+    the sharded optimiser and the two-part gather of DataParallelObject run unchanged; only the transport differs.  A
+    collective issued between Context.fork() and end_fork() stages through the side stream, like RcclComm's would run on it.
+    Selected with ADM_COMM=host."""
     backend = 'host'
 
     def attach(self, ctx):
         self.ctx = ctx
         return self
 
-    def _sum(self, host):
-        t = self.torch.from_numpy(host)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return host
-
     def reduce_scatter_sum(self, full, shard_out):
         n = shard_out.size
-        host = self._sum(full.view(0, (n * self.size,)).get())
+        host = self.group_.all_reduce_sum(full.view(0, (n * self.size,)).get())
         shard_out.set(host[self.rank * n:(self.rank + 1) * n])
 
     def all_gather(self, full_out, shard_in):
-        mine = self.torch.from_numpy(shard_in.get())
-        parts = [self.torch.empty_like(mine) for _ in range(self.size)]
-        self.dist.all_gather(parts, mine)
-        full_out.view(0, (shard_in.size * self.size,)).set(self.torch.cat(parts).numpy())
+        full_out.view(0, (shard_in.size * self.size,)).set(self.group_.all_gather(shard_in.get().reshape(-1)))
 
     def all_reduce_device(self, dev):
-        dev.set(self._sum(dev.get()))
+        dev.set(self.group_.all_reduce_sum(dev.get()))
         return dev
 
     def broadcast(self, dev, root):
-        t = self.torch.from_numpy(dev.get())
-        self.dist.broadcast(t, src=int(root))
+        host = self.group_.broadcast(dev.get(), int(root))
         if self.rank != int(root):
-            dev.set(t.numpy())
+            dev.set(host)
         return dev
 
     def reduce(self, dev, root):
-        t = self.torch.from_numpy(dev.get())
-        self.dist.reduce(t, dst=int(root), op=self.dist.ReduceOp.SUM)
+        host = self.group_.reduce_sum(dev.get(), int(root))
         if self.rank == int(root):
-            dev.set(t.numpy())
+            dev.set(host)
         return dev
 
     def group(self):
         import contextlib
         return contextlib.nullcontext()
 
-    def close(self):
+    def close(self, keep_group=False):
         if self.ctx is not None:
             self.ctx.sync()
             self.ctx = None
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        if not keep_group:
+            self.group_.close()
+
+
+def device_count():
+    """Number of GPUs libadm sees (adm_device_count: hipGetDeviceCount, no context is created)."""
+    from . import _lib
+    return int(_lib.load().adm_device_count())
 
 
 def from_env():
-    """LocalComm unless launched under torch.distributed.run with WORLD_SIZE > 1; then ADM_COMM selects the data plane:
+    """LocalComm unless launched with WORLD_SIZE > 1 (torch.distributed.run, an mpirun wrapper, bench.py); then ADM_COMM selects the data plane:
     'rccl' (default: RCCL through the C ABI), 'torch' (torch.distributed's nccl backend), 'host' (validation: staged
     through host memory, several ranks may share a GPU)."""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
@@ -383,8 +369,6 @@ def from_env():
         if kind == 'torch':
             return TorchComm('nccl')
         if kind == 'host':
-            import torch
-            n_dev = max(1, torch.cuda.device_count())       # counting devices does not initialise the GPU
-            return HostStagedComm(device_index=int(os.environ.get('LOCAL_RANK', '0')) % n_dev)
+            return HostStagedComm(device_index=int(os.environ.get('LOCAL_RANK', '0')) % max(1, device_count()))
         return RcclComm()
     return LocalComm()

@@ -105,6 +105,10 @@ extern "C" int adm_ctx_sync(adm_ctx* ctx) {
 }
 extern "C" void* adm_ctx_stream(adm_ctx* ctx) { return ctx ? (void*)ctx->main_stream : nullptr; }
 extern "C" int adm_ctx_device(adm_ctx* ctx) { return ctx ? ctx->device : -1; }
+extern "C" int adm_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 extern "C" int adm_malloc(adm_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(ADM_ERR_INVALID, "adm_malloc: null argument");

@@ -158,19 +158,22 @@ class DataParallelObject(object):
         the order of two fp32 additions per element."""
         self.finish_update()
         self._tic('reduce_scatter')
-        if touched is not None and self.dist:
+        if touched is not None:
             if reg_shard is None:
                 raise ValueError('exchange_and_update: touched= needs reg_shard=')
             t_lo, t_hi = max(0, int(touched[0])), min(self.n, int(touched[1]))
-            import contextlib
-            with (self.comm.group() if hasattr(self.comm, 'group') else contextlib.nullcontext()):
-                for r in range(self.comm.size):
-                    s_lo, s_hi = max(r * self.per, t_lo), min((r + 1) * self.per, t_hi)
-                    if s_hi > s_lo:
-                        if self.inplace:
-                            self.comm.reduce(self.grad.view(s_lo, (s_hi - s_lo,)), r)
-                        else:
-                            self.comm.reduce_tensor(self.t_grad[s_lo:s_hi], r)
+            if self.dist:
+                import contextlib
+                with (self.comm.group() if hasattr(self.comm, 'group') else contextlib.nullcontext()):
+                    for r in range(self.comm.size):
+                        s_lo, s_hi = max(r * self.per, t_lo), min((r + 1) * self.per, t_hi)
+                        if s_hi > s_lo:
+                            if self.inplace:
+                                self.comm.reduce(self.grad.view(s_lo, (s_hi - s_lo,)), r)
+                            else:
+                                self.comm.reduce_tensor(self.t_grad[s_lo:s_hi], r)
+            # (one local rank: nothing to sum, but the contract is the same -- the buffer holds the data term on [t_lo, t_hi)
+            # only and the owner, this rank, completes it with the regulariser term)
             reg_shard(self.lo, self.hi, t_lo, t_hi)
             g, g_base = self.grad, 0
         elif self.inplace:

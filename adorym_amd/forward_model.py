@@ -275,7 +275,12 @@ class PtychographyModel(ForwardModel):
         if side_hook is not None:
             side_hook()
         # init_grad: grad_obj is uninitialised -- the regulariser kernel writes it (one pass) or it is zero-filled
-        rx = getattr(self, 'restricted_planes', None) if (want_grad and init_grad) else None
+        rx = getattr(self, 'restricted_planes', None) if want_grad else None
+        if rx is not None and not init_grad:
+            # the restricted exchange defers the regulariser gradient to the shard owners (R-fold, after the reduction): an
+            # evaluation that ACCUMULATES into a buffer initialised elsewhere would add it here as well and count it twice
+            raise RuntimeError('restricted_planes is set but the gradient buffer is not initialised by this evaluation '
+                               '(init_grad=False): the regulariser term would be counted twice')
         if rx is not None:
             # footprint-restricted exchange (DataParallelObject.exchange_and_update(touched=...)): the gradient buffer carries
             # the DATA term only, on the planes the global batch touches -- zero those; the regulariser's gradient is added by

@@ -1,0 +1,98 @@
+"""
+One process per GPU without a framework launcher:  ``python -m adorym_amd.launch -n 8 script.py [args ...]``.
+
+The reference is started as ``mpirun -n R python script.py`` (adorym/ptychography.py:39-50 reads rank and size from
+mpi4py).  Here the ranks are plain child processes of this one, each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR and
+the exact port of the control plane (ADM_RDV_PORT, adorym_amd/rendezvous.py) in its environment; adorym_amd.comm.from_env()
+picks them up.  The parent never touches the GPU (no HIP call, no library load), so starting children from it is safe on
+hosts where an exec from a GPU-initialised process is not.  bench.py uses run() when it is called as ``bench.py --gpus N``
+without a launcher around it.
+
+Rank 0's stdout is relayed to this process's stdout line by line (a benchmark's one JSON line arrives unchanged); the other
+ranks' stdout goes to stderr.  The exit code is the first non-zero child code, else 0; when one rank fails the others are
+given a grace period and then terminated (they would otherwise wait in a collective for ever).
+"""
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_envs(n, base=None, port=None, job=None):
+    """The environment of each of the n ranks (dicts), derived from ``base`` (default os.environ)."""
+    base = dict(os.environ if base is None else base)
+    port = int(port) if port is not None else free_port()
+    job = job or 'adm-%d-%d' % (os.getpid(), port)
+    envs = []
+    for r in range(int(n)):
+        e = dict(base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                 MASTER_PORT=str(port), ADM_RDV_PORT=str(port), ADM_RDV_JOB=job)
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+        e.pop('TORCHELASTIC_RUN_ID', None)
+        envs.append(e)
+    return envs
+
+
+def run(n, argv, grace_s=20.0, out=None, err=None):
+    """Start ``argv`` n times (one rank each), wait for all, return (exit code, rank 0's stdout lines)."""
+    out = out or sys.stdout
+    err = err or sys.stderr
+    envs = rank_envs(n)
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+    lines0 = []
+
+    def pump(r, p):
+        for line in p.stdout:
+            if r == 0:
+                lines0.append(line.rstrip('\n'))
+                out.write(line)
+                out.flush()
+            else:
+                err.write('[rank %d] %s' % (r, line))
+                err.flush()
+
+    threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    [t.start() for t in threads]
+    rc, t_fail = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and rc == 0:
+            rc, t_fail = bad[0], time.time()
+        if all(c is not None for c in codes):
+            break
+        if t_fail is not None and time.time() - t_fail > grace_s:
+            for p in procs:             # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            t_fail = time.time() + 1e9
+        time.sleep(0.05)
+    [t.join(5) for t in threads]
+    return rc, lines0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) < 3 or argv[0] not in ('-n', '--nproc'):
+        sys.stderr.write('usage: python -m adorym_amd.launch -n N script.py [args ...]\n')
+        return 2
+    n = int(argv[1])
+    rc, _ = run(n, [sys.executable] + argv[2:])
+    return rc
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -55,7 +55,17 @@ def _atomic_write(path, writer):
     tmp = path + '.tmp'
     with open(tmp, 'wb') as f_tmp:
         writer(f_tmp)
+        f_tmp.flush()
+        os.fsync(f_tmp.fileno())        # the invalidate -> data -> stamp order must also hold on the disk (power loss)
     os.replace(tmp, path)
+    try:
+        dfd = os.open(os.path.dirname(path) or '.', os.O_RDONLY)
+        try:
+            os.fsync(dfd)
+        finally:
+            os.close(dfd)
+    except OSError:
+        pass
 
 
 def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_name='obj', rank=0, n_ranks=1, params=None):
@@ -94,20 +104,25 @@ def save_checkpoint(i_epoch, i_batch, output_folder, obj_array, moments, opt_nam
 
 def restore_checkpoint(output_folder, n_moments, opt_name='obj', rank=0, n_ranks=1, obj_shape=None, shard_size=None):
     """adorym/misc.py:197-211 + load_params_checkpoint (adorym/ptychography.py:462).  Everything is read and shape-checked
-    BEFORE anything is returned, so a partial checkpoint cannot leave a run half restored; this rank's stamp must equal
+    BEFORE anything is returned, so a partial checkpoint cannot leave a run half restored; the stamps of ALL ranks must equal
     checkpoint.txt (a checkpoint torn by a crash in the middle of a save is refused; checkpoints written by the reference
     itself carry no stamps and are accepted as they are).
     Returns (i_epoch, i_batch, obj [Y,X,Z,2], moments or None, params dict or None)."""
     import pickle
     path = os.path.join(output_folder, 'checkpoint')
     i_epoch, i_batch = [int(i) for i in np.loadtxt(os.path.join(path, 'checkpoint.txt'))]
-    fs = os.path.join(path, 'stamp_rank_{}.txt'.format(rank))
-    if os.path.exists(fs):
-        st = [int(i) for i in np.loadtxt(fs)]
-        if st != [i_epoch, i_batch]:
-            raise ValueError('torn checkpoint: rank %d %s, checkpoint.txt says %s'
-                             % (rank, 'was interrupted in the middle of a save' if st == [-1, -1] else
-                                'wrote its files for (epoch, batch) = %s' % (tuple(st),), (i_epoch, i_batch)))
+    # EVERY rank's stamp is checked by every rank: ranks > 0 load the object rank 0 wrote, so a save that rank 0 did not finish
+    # must be refused by them too, not only by rank 0 (the driver then agrees on the verdict over the communicator)
+    if os.path.exists(os.path.join(path, 'stamp_rank_{}.txt'.format(rank))):
+        for r_ in range(n_ranks):
+            fs = os.path.join(path, 'stamp_rank_{}.txt'.format(r_))
+            if not os.path.exists(fs):
+                raise ValueError('torn checkpoint: rank %d never wrote a stamp (checkpoint written with fewer ranks?)' % r_)
+            st = [int(i) for i in np.loadtxt(fs)]
+            if st != [i_epoch, i_batch]:
+                raise ValueError('torn checkpoint: rank %d %s, checkpoint.txt says %s'
+                                 % (r_, 'was interrupted in the middle of a save' if st == [-1, -1] else
+                                    'wrote its files for (epoch, batch) = %s' % (tuple(st),), (i_epoch, i_batch)))
     obj = np.load(os.path.join(path, 'obj_checkpoint.npy'))
     if obj_shape is not None and tuple(obj.shape) != tuple(obj_shape):
         raise ValueError('obj_checkpoint.npy has shape %s, expected %s' % (obj.shape, tuple(obj_shape)))

@@ -1,0 +1,270 @@
+"""
+Control plane of the data-parallel mode without any framework: a TCP star on MASTER_ADDR / MASTER_PORT.
+
+The reference's control plane is mpi4py's COMM_WORLD (adorym/ptychography.py:39-50: ``comm.Get_rank()``, ``comm.bcast``,
+``comm.Barrier``); its replacement here carries only what the multi-GPU driver needs besides the RCCL data plane of
+libadm: the hand-over of the 128-byte RCCL unique ids, agreement flags, seeds / time stamps, barriers, and -- for the
+host-staged validation transport only -- whole arrays.  Rank 0 listens, every other rank connects once and keeps its
+socket; every operation is a collective issued in the same order on every rank, carried as length-prefixed frames that name
+the operation, so a mismatched sequence raises instead of deadlocking silently.
+
+Environment (the variables torch.distributed.run, mpirun wrappers and bench.py's own launcher set): RANK, WORLD_SIZE,
+MASTER_ADDR, MASTER_PORT; optional ADM_RDV_PORT (exact port of the star), ADM_RDV_TIMEOUT (seconds, default 300).
+Under torch.distributed.run MASTER_PORT itself belongs to the launcher's own store, so the star takes the first free
+port ABOVE it; peers find it by a handshake that carries the job id (TORCHELASTIC_RUN_ID or the port number).
+"""
+import os
+import pickle
+import socket
+import struct
+import time
+
+import numpy as np
+
+_MAGIC = b'ADMRDV1\0'
+_SCAN = 32            # ports tried above the base port
+
+
+def _send_frame(sock, tag, payload):
+    head = tag.encode('ascii')
+    sock.sendall(struct.pack('!HQ', len(head), len(payload)) + head)
+    if len(payload):
+        sock.sendall(payload)
+
+
+def _recv_exact(sock, n, into=None):
+    buf = into if into is not None else bytearray(n)
+    view = memoryview(buf).cast('B')
+    got = 0
+    while got < n:
+        k = sock.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError('rendezvous: peer closed the connection')
+        got += k
+    return buf
+
+
+def _recv_frame(sock, tag, into=None):
+    nh, nb = struct.unpack('!HQ', bytes(_recv_exact(sock, 10)))
+    head = bytes(_recv_exact(sock, nh)).decode('ascii')
+    if head != tag:
+        raise RuntimeError("rendezvous: collective mismatch -- this rank is in '%s', the peer sent '%s'" % (tag, head))
+    if into is not None:
+        if nb != memoryview(into).nbytes:
+            raise RuntimeError("rendezvous: '%s' carries %d bytes, expected %d" % (tag, nb, memoryview(into).nbytes))
+        return _recv_exact(sock, nb, into)
+    return bytes(_recv_exact(sock, nb)) if nb else b''
+
+
+class TcpGroup(object):
+    """rank / size + the collectives of the control plane.  ``TcpGroup.from_env()`` reads the launcher's variables."""
+
+    def __init__(self, rank, size, addr='127.0.0.1', port=29511, job='', exact_port=False, timeout=None):
+        self.rank, self.size = int(rank), int(size)
+        self.timeout = float(timeout if timeout is not None else os.environ.get('ADM_RDV_TIMEOUT', '300'))
+        self._peers = {}          # rank 0: {rank: socket}
+        self._root = None         # other ranks: socket to rank 0
+        self._closed = False
+        if self.size == 1:
+            return
+        hello = _MAGIC + struct.pack('!I', len(job)) + job.encode('utf-8')
+        ports = [int(port)] if exact_port else [int(port) + k for k in range(_SCAN)]
+        deadline = time.time() + self.timeout
+        if self.rank == 0:
+            srv, err = None, None
+            for p in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind(('127.0.0.1' if addr in ('127.0.0.1', 'localhost') else '', p))
+                    break
+                except OSError as e:
+                    err = e
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError('rendezvous: rank 0 found no free port in %s (%r)' % (ports, err))
+            srv.listen(self.size)
+            self.port = srv.getsockname()[1]
+            while len(self._peers) < self.size - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    raise RuntimeError('rendezvous: only %d of %d ranks connected within %.0f s'
+                                       % (len(self._peers) + 1, self.size, self.timeout))
+                try:
+                    c.settimeout(5.0)
+                    got = bytes(_recv_exact(c, len(hello)))
+                    r = struct.unpack('!I', bytes(_recv_exact(c, 4)))[0]
+                    if got != hello or not (0 < r < self.size) or r in self._peers:
+                        raise ConnectionError('foreign connection')
+                    c.sendall(_MAGIC)
+                except Exception:
+                    c.close()           # not one of this job's ranks (a port scanner, another job): ignore it
+                    continue
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(self.timeout)
+                self._peers[r] = c
+            srv.close()
+        else:
+            sock = None
+            while sock is None:
+                for p in ports:
+                    try:
+                        s = socket.create_connection((addr, p), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        s.settimeout(5.0)
+                        s.sendall(hello + struct.pack('!I', self.rank))
+                        if bytes(_recv_exact(s, len(_MAGIC))) == _MAGIC:
+                            sock, self.port = s, p
+                            break
+                    except Exception:
+                        pass
+                    s.close()
+                if sock is None:
+                    if time.time() > deadline:
+                        raise RuntimeError('rendezvous: rank %d could not reach rank 0 at %s:%s within %.0f s'
+                                           % (self.rank, addr, ports, self.timeout))
+                    time.sleep(0.05)
+            sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            sock.settimeout(self.timeout)
+            self._root = sock
+
+    @classmethod
+    def from_env(cls):
+        rank = int(os.environ.get('RANK', '0'))
+        size = int(os.environ.get('WORLD_SIZE', '1'))
+        addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+        if 'ADM_RDV_PORT' in os.environ:
+            return cls(rank, size, addr, int(os.environ['ADM_RDV_PORT']), job=os.environ.get('ADM_RDV_JOB', ''), exact_port=True)
+        port = int(os.environ.get('MASTER_PORT', '29511'))
+        job = os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + str(port)
+        if 'TORCHELASTIC_RUN_ID' in os.environ or 'TORCHELASTIC_RESTART_COUNT' in os.environ:
+            port += 1           # MASTER_PORT is the launcher's own store
+        return cls(rank, size, addr, port, job=job)
+
+    # ---- generic pattern: everything goes through rank 0 ---------------------------------------------------------------
+    def _gather(self, tag, payload):
+        """rank 0: [payload of rank 0, 1, ...]; others: None."""
+        if self.rank == 0:
+            return [payload] + [_recv_frame(self._peers[r], tag) for r in range(1, self.size)]
+        _send_frame(self._root, tag, payload)
+        return None
+
+    def _scatter_same(self, tag, payload):
+        if self.rank == 0:
+            for r in range(1, self.size):
+                _send_frame(self._peers[r], tag, payload)
+            return payload
+        return _recv_frame(self._root, tag)
+
+    def barrier(self):
+        if self.size > 1:
+            self._gather('barrier', b'')
+            self._scatter_same('barrier.', b'')
+
+    def bcast_object(self, obj, root=0):
+        if self.size == 1:
+            return obj
+        if root != 0:           # the owner hands it to rank 0 first
+            if self.rank == root:
+                _send_frame(self._root, 'bcast>', pickle.dumps(obj))
+            elif self.rank == 0:
+                obj = pickle.loads(_recv_frame(self._peers[root], 'bcast>'))
+        return pickle.loads(self._scatter_same('bcast', pickle.dumps(obj) if self.rank == 0 else b''))
+
+    def _reduce_scalar(self, value, fn, tag):
+        if self.size == 1:
+            return float(value)
+        parts = self._gather(tag, struct.pack('!d', float(value)))
+        out = struct.pack('!d', fn(struct.unpack('!d', p_)[0] for p_ in parts)) if self.rank == 0 else b''
+        return struct.unpack('!d', self._scatter_same(tag + '.', out))[0]
+
+    def sum_over_ranks(self, value):
+        return self._reduce_scalar(value, lambda it: float(sum(it)), 'sum')
+
+    def max_over_ranks(self, value):
+        return self._reduce_scalar(value, max, 'max')
+
+    # ---- whole arrays (host-staged validation transport only; slow by construction) ------------------------------------
+    def all_reduce_sum(self, arr):
+        """In-place sum over ranks of a contiguous NumPy array, added in rank order (0 + 1 + ...) on rank 0: deterministic."""
+        if self.size == 1:
+            return arr
+        if self.rank == 0:
+            tmp = np.empty_like(arr)
+            for r in range(1, self.size):
+                _recv_frame(self._peers[r], 'allreduce', into=tmp)
+                arr += tmp
+            for r in range(1, self.size):
+                _send_frame(self._peers[r], 'allreduce.', memoryview(arr).cast('B'))
+        else:
+            _send_frame(self._root, 'allreduce', memoryview(arr).cast('B'))
+            _recv_frame(self._root, 'allreduce.', into=arr)
+        return arr
+
+    def reduce_sum(self, arr, root):
+        """arr of rank ``root`` = sum over ranks (rank order); the others' arrays are left alone."""
+        if self.size == 1:
+            return arr
+        if self.rank == 0:
+            acc = arr.copy()
+            tmp = np.empty_like(arr)
+            for r in range(1, self.size):
+                _recv_frame(self._peers[r], 'reduce', into=tmp)
+                acc += tmp
+            if root == 0:
+                arr[...] = acc
+            else:
+                _send_frame(self._peers[root], 'reduce.', memoryview(acc).cast('B'))
+        else:
+            _send_frame(self._root, 'reduce', memoryview(arr).cast('B'))
+            if self.rank == root:
+                _recv_frame(self._root, 'reduce.', into=arr)
+        return arr
+
+    def broadcast(self, arr, root):
+        if self.size == 1:
+            return arr
+        if root != 0:
+            if self.rank == root:
+                _send_frame(self._root, 'bc>', memoryview(arr).cast('B'))
+            elif self.rank == 0:
+                _recv_frame(self._peers[root], 'bc>', into=arr)
+        if self.rank == 0:
+            for r in range(1, self.size):
+                if r != root:
+                    _send_frame(self._peers[r], 'bc', memoryview(arr).cast('B'))
+        elif self.rank != root:
+            _recv_frame(self._root, 'bc', into=arr)
+        return arr
+
+    def all_gather(self, mine):
+        """Concatenation over ranks of equally sized contiguous arrays."""
+        if self.size == 1:
+            return mine.copy()
+        full = np.empty((self.size,) + mine.shape, mine.dtype)
+        if self.rank == 0:
+            full[0] = mine
+            for r in range(1, self.size):
+                _recv_frame(self._peers[r], 'allgather', into=full[r])
+            for r in range(1, self.size):
+                _send_frame(self._peers[r], 'allgather.', memoryview(full).cast('B'))
+        else:
+            _send_frame(self._root, 'allgather', memoryview(mine).cast('B'))
+            _recv_frame(self._root, 'allgather.', into=full)
+        return full.reshape((self.size * mine.shape[0],) + mine.shape[1:]) if mine.ndim else full
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        for s in list(self._peers.values()) + ([self._root] if self._root is not None else []):
+            try:
+                s.close()
+            except Exception:
+                pass
+        self._peers, self._root = {}, None

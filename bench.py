@@ -4,8 +4,9 @@ Benchmark of the hot path on BASELINE.json's metric: probe-positions/s (forward 
 256^3 multislice ptychotomography (config 3), minibatch 32 per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks as child processes: adorym_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W          (or any launcher that sets RANK / WORLD_SIZE / MASTER_*)
 
 One "step" = one minibatch iteration of reconstruct_ptychography (update_scheme='immediate'):
 rotate object to theta (footprint planes) -> multislice forward + far-field LSQ loss + adjoint for the
@@ -363,7 +364,13 @@ def main():
                          'the regulariser term N-fold (DESIGN.md section 6; tests/test_gpu_world2.py).  Off by default.')
     args = ap.parse_args()
 
-    import torch
+    # `bench.py --gpus N` without a launcher around it: THIS process -- which has not loaded libadm or touched the GPU --
+    # starts the N ranks as child processes, relays rank 0's JSON line and exits with their code (adorym_amd/launch.py)
+    if args.gpus > 1 and 'RANK' not in os.environ and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        from adorym_amd import launch
+        rc, _ = launch.run(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        raise SystemExit(rc)
+
     import adorym_amd as A
     from adorym_amd import comm as C, workloads as W
     from adorym_amd.dp import DataParallelObject, HipOps
@@ -372,11 +379,10 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.comm == 'host':
-        local_rank %= max(1, torch.cuda.device_count())     # validation transport: several ranks may share a GPU
-    torch.cuda.set_device(local_rank)
+        local_rank %= max(1, C.device_count())     # validation transport: several ranks may share a GPU
     use_dist = world > 1 or args.force_dist
     if not use_dist:
         comm = C.LocalComm()
@@ -401,7 +407,7 @@ def main():
             comm_note = 'RCCL through the C ABI failed (%r): fell back to torch.distributed nccl' % (e,)
             sys.stderr.write('bench.py: rank %d: %s\n' % (rank, comm_note))
             comm.ctx = None
-            comm.close()                        # leaves the gloo group; TorchComm opens an nccl one on the same rendezvous
+            comm.close()                        # leaves the TCP star; TorchComm opens an nccl group on MASTER_ADDR / MASTER_PORT
             ctx.close()
             comm = C.TorchComm('nccl', device_index=local_rank)
             ctx = A.Context(local_rank, stream=comm.stream_handle())
@@ -487,7 +493,9 @@ def main():
             loss_box[0] = eng.loss_result(token)
             pending[0] = None
 
-    restricted = bool(args.restricted_exchange and use_dist)
+    # --restricted-exchange makes the footprint-restricted exchange the HEADLINE's; with several ranks it is timed as a second
+    # leg of the same line either way (`immediate_restricted`)
+    leg = {'restricted': bool(args.restricted_exchange and use_dist)}
 
     def reg_shard(lo_, hi_, alo_, ahi_):      # the regulariser term of all `world` ranks, on this rank's shard [lo_, hi_)
         check(ctx.lib.adm_reg_grad_range(eng.plan.handle, state.obj.ptr, cfg['alpha_d'] * world, cfg['alpha_b'] * world,
@@ -504,6 +512,7 @@ def main():
         ctx.fork()
         eng.flush_loss_copy()       # the previous step's loss read-back, off the main stream
         state.finish_update()       # the part of the previous Adam pass that was deferred (planes this minibatch does not read)
+        restricted = leg['restricted']
         if restricted:
             # only the planes the GLOBAL batch touches are initialised (zero) and exchanged; the regulariser comes in after the sum
             ty0, ty1 = eng.y_footprint(pos_all[plan_all[k]])
@@ -572,24 +581,48 @@ def main():
                   'plain_ms_per_step': ms[False], 'two_part_ms_per_step': ms[True], 'check_steps': n_chk}
         reset_state()
 
-    for k in range(args.warmup):
-        step(k, False)
-    resolve()
     from adorym_amd.device import PhaseClock
-    if use_dist:        # (one GPU: nothing to explain, and the event records would sit between the kernels of the step's tail)
-        state.clock = PhaseClock(ctx)
-    comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, total):
-        step(k, True)
-    resolve()
-    comm.barrier()
-    torch.cuda.synchronize()
-    dt = comm.max_over_ranks(time.perf_counter() - t0)
-    state.finish_update()
-    phases = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()} if state.clock is not None else {}
-    state.clock = None
+
+    def timed_loop():
+        """W untimed + exactly K timed steps between barriers (device idle on both sides), maximum over ranks."""
+        ms_kernel_total[0] = 0.0
+        for k in range(args.warmup):
+            step(k, False)
+        resolve()
+        if use_dist:        # (one GPU: nothing to explain, and the event records would sit between the kernels of the step's tail)
+            state.clock = PhaseClock(ctx)
+        ctx.sync()
+        comm.barrier()
+        t0 = time.perf_counter()
+        for k in range(args.warmup, total):
+            step(k, True)
+        resolve()
+        ctx.sync()
+        comm.barrier()
+        dt_ = comm.max_over_ranks(time.perf_counter() - t0)
+        state.finish_update()
+        ph = {n_: t_ / args.steps for n_, (t_, c_) in state.clock.totals().items()} if state.clock is not None else {}
+        state.clock = None
+        return dt_, ms_kernel_total[0] / args.steps, ph
+
+    def phases_dict(kern_ms_, ph):
+        return {'kernel_ms': kern_ms_, 'reduce_scatter_ms': ph.get('reduce_scatter', 0.0), 'update_ms': ph.get('update', 0.0),
+                'first_gather_ms': ph.get('first_gather', 0.0), 'deferred_gather_ms': ph.get('deferred_gather', 0.0)}
+
+    dt, kern_ms, phases = timed_loop()
+    loss_headline = loss_box[0]
+
+    # second leg with several ranks: the same loop with the footprint-restricted exchange (or, if that was asked for as the
+    # headline, with the full exchange), from the same initial state
+    other_leg = None
+    if use_dist and world > 1 and args.scaling == 'weak':
+        leg['restricted'] = not leg['restricted']
+        reset_state()
+        dt2, kern2, ph2 = timed_loop()
+        other_leg = {'restricted_exchange': leg['restricted'], 'value': B_global * args.steps / dt2, 'unit': 'probe-positions/s',
+                     'ms_per_step': 1e3 * dt2 / args.steps, 'phases_ms': phases_dict(kern2, ph2), 'loss_last': loss_box[0]}
+        leg['restricted'] = not leg['restricted']
+    restricted = leg['restricted']
 
     # secondary leg on EVERY rank count: update_scheme='per angle' -- all minibatches of an angle fused, ONE exchange per step.
     # (N > 1: the same two collectives on the same communicator as the headline loop that has just run.)
@@ -602,7 +635,6 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = B_global * args.steps / dt
-        kern_ms = ms_kernel_total[0] / args.steps
         alg = algorithmic_bytes_fwd_grad(B, Py, Px, Z, Y * X * Z)
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source = read_traffic(B)
@@ -619,17 +651,18 @@ def main():
                          'unit': 'GB/s', 'frac': achieved / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': alg, 'kernel_ms': kern_ms,
                          'whole_step_frac': alg / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS},
-            'loss_last': loss_box[0],
+            'loss_last': loss_headline,
             # device time per step of the exchange's phases (HIP events on the stream each phase is queued on; rank 0):
             # where an N-GPU step's time goes beyond the multislice kernel
-            'phases_ms': {'kernel_ms': kern_ms, 'reduce_scatter_ms': phases.get('reduce_scatter', 0.0), 'update_ms': phases.get('update', 0.0),
-                          'first_gather_ms': phases.get('first_gather', 0.0), 'deferred_gather_ms': phases.get('deferred_gather', 0.0)},
+            'phases_ms': phases_dict(kern_ms, phases),
             'comm': {'backend': getattr(comm, 'backend', 'local'), 'size': comm.size, 'adm_comm_size': abi_size, 'expected': world,
                      'side_stream_communicator': getattr(comm, 'backend', '') == 'rccl' and os.environ.get('ADM_COMM_AUX', '1') == '1',
                      'gather': gather, 'restricted_exchange': restricted, 'note': comm_note},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
+        if other_leg is not None:
+            out['immediate_restricted' if other_leg['restricted_exchange'] else 'immediate_full_exchange'] = other_leg
         if per_angle is not None:
             out['per_angle'] = per_angle
         if world == 1 and not args.no_per_angle:

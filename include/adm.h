@@ -41,6 +41,9 @@ typedef struct adm_plan adm_plan;
 /* ---- library / context ------------------------------------------------------------ */
 int adm_version(void);
 const char* adm_last_error(void);
+/* Number of GPUs visible to the process (0 if none / on error); creates no context.  Replaces the device enumeration
+ * behind `gpu_index` (adorym/ptychography.py:203-205) for launchers that map local ranks to devices. */
+int adm_device_count(void);
 
 /* One context = one GPU + one stream.  `stream` may be an existing hipStream_t (e.g.
  * torch.cuda.current_stream().cuda_stream) or NULL to let the context own a new one.

@@ -16,9 +16,8 @@ import pytest
 
 @pytest.fixture(scope='session')
 def rccl_world1():
-    """ONE RcclComm (gloo control plane + RCCL behind the C ABI) at world size 1 for the whole session: tearing the process
-    group down and bringing it up again inside one process costs minutes, so the GPU tests that walk the multi-GPU code
-    path share it.  attach(ctx) gives every context its own RCCL communicator."""
+    """ONE RcclComm (TCP control plane + RCCL behind the C ABI) at world size 1 for the whole session, shared by the GPU tests
+    that walk the multi-GPU code path.  attach(ctx) gives every context its own RCCL communicator."""
     import socket
     from adorym_amd import comm as C
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()

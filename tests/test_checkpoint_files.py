@@ -19,17 +19,42 @@ def test_round_trip_and_no_temporaries(tmp_path):
 
 
 def test_torn_checkpoint_is_refused(tmp_path):
-    """Rank 1 wrote its shard for batch 20, rank 0 never got that far (checkpoint.txt still says 10): every rank's own stamp is
-    compared with checkpoint.txt, so rank 1 refuses and the driver's agreement step drops the checkpoint on all ranks."""
+    """Rank 1 wrote its shard for batch 20, rank 0 never got that far (checkpoint.txt still says 10): every rank compares
+    EVERY rank's stamp with checkpoint.txt, so both refuse (and the driver's agreement step drops the checkpoint on all ranks)."""
     obj = np.zeros((2, 2, 2, 2), np.float32)
     shard = [np.zeros(8, np.float32), np.zeros(8, np.float32)]
     save_checkpoint(0, 10, str(tmp_path), obj, shard, rank=0, n_ranks=2)
     save_checkpoint(0, 10, str(tmp_path), None, shard, rank=1, n_ranks=2)
     restore_checkpoint(str(tmp_path), 2, rank=1, n_ranks=2, obj_shape=obj.shape, shard_size=8)       # consistent: accepted
     save_checkpoint(0, 20, str(tmp_path), None, shard, rank=1, n_ranks=2)                              # rank 0 "crashed" before its save
-    restore_checkpoint(str(tmp_path), 2, rank=0, n_ranks=2, obj_shape=obj.shape, shard_size=8)       # rank 0 alone looks fine ...
-    with pytest.raises(ValueError, match='torn checkpoint'):
-        restore_checkpoint(str(tmp_path), 2, rank=1, n_ranks=2, obj_shape=obj.shape, shard_size=8)   # ... rank 1 does not
+    for r in (0, 1):                  # every rank checks every rank's stamp: both refuse, not only the one whose own stamp is off
+        with pytest.raises(ValueError, match='torn checkpoint'):
+            restore_checkpoint(str(tmp_path), 2, rank=r, n_ranks=2, obj_shape=obj.shape, shard_size=8)
+
+
+def test_rank0_dying_inside_its_save_is_refused_by_the_other_ranks_too(tmp_path, monkeypatch):
+    """rank 0 dies after replacing obj_checkpoint.npy and before checkpoint.txt; rank 1 has not started its save, so
+    ITS stamp still equals checkpoint.txt -- yet it would load rank 0's NEW object with its own OLD moments.  Rank 1 reads rank
+    0's invalidated stamp and refuses as well: a clean refusal on all ranks instead of an asymmetric failure."""
+    import adorym_amd.ptychography as PT
+    obj = np.zeros((2, 2, 2, 2), np.float32)
+    shard = [np.zeros(8, np.float32), np.zeros(8, np.float32)]
+    save_checkpoint(0, 10, str(tmp_path), obj, shard, rank=0, n_ranks=2)
+    save_checkpoint(0, 10, str(tmp_path), None, shard, rank=1, n_ranks=2)
+    real = PT._atomic_write
+
+    def dying(path, writer):
+        if 'opt_obj_params_checkpoint_rank_0' in path:
+            raise KeyboardInterrupt('rank 0 killed after the object, before its moments')
+        real(path, writer)
+
+    monkeypatch.setattr(PT, '_atomic_write', dying)
+    with pytest.raises(KeyboardInterrupt):
+        save_checkpoint(0, 20, str(tmp_path), obj + 1, shard, rank=0, n_ranks=2)
+    monkeypatch.setattr(PT, '_atomic_write', real)
+    for r in (0, 1):
+        with pytest.raises(ValueError, match='rank 0 was interrupted in the middle of a save'):
+            restore_checkpoint(str(tmp_path), 2, rank=r, n_ranks=2, obj_shape=obj.shape, shard_size=8)
 
 
 def test_reference_written_checkpoint_without_stamps_is_accepted(tmp_path):

@@ -152,7 +152,7 @@ def test_deferred_update_equals_full_update():
 # ------------------------------------------------------------------------------------------------------------------
 # The in-place exchange of the RCCL backend (adorym_amd/dp.py, `inplace`): the reduced shard lands in its slot of the gradient
 # buffer and the updated shard is gathered from its slot of the object.  A stand-in with RcclComm's interface (backend
-# 'rccl', buffers with .view(offset, shape)) runs the SAME DataParallelObject code over gloo on host buffers.
+# 'rccl', buffers with .view(offset, shape)) runs the SAME DataParallelObject code on host buffers, its control plane being the product's TCP star.
 class HostBuf(object):
     def __init__(self, a):
         self.a = a
@@ -190,31 +190,25 @@ def _worker_inplace(rank, world, port, shape, seed, out_q, first=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     if first is not None:
         os.environ['ADM_OVERLAP_GATHER'] = '1'      # the two-part gather is opt-in at world size > 1
-    import torch
     from adorym_amd.comm import RcclComm
     from adorym_amd.dp import DataParallelObject
 
-    class GlooAsRccl(RcclComm):          # control plane = the real RcclComm code; data plane = gloo on host buffers
+    class HostAsRccl(RcclComm):          # control plane = the real RcclComm code (TCP star); data plane = the star's array collectives on host buffers
         def reduce_scatter_sum(self, full, shard_out):
-            t = torch.from_numpy(full.a.copy())
-            self.dist.all_reduce(t)
-            shard_out.a[...] = t.numpy()[self.rank * shard_out.size:(self.rank + 1) * shard_out.size]
+            t = self.group_.all_reduce_sum(full.a.copy())
+            shard_out.a[...] = t[self.rank * shard_out.size:(self.rank + 1) * shard_out.size]
 
         def all_gather(self, full_out, shard_in):
-            parts = [torch.empty(shard_in.size) for _ in range(self.size)]
-            self.dist.all_gather(parts, torch.from_numpy(shard_in.a.copy()))
-            full_out.a[...] = torch.cat(parts).numpy()
+            full_out.a[...] = self.group_.all_gather(np.ascontiguousarray(shard_in.a))
 
         def group(self):
             import contextlib
-            return contextlib.nullcontext()      # gloo has no launch grouping; the calls simply run one after the other
+            return contextlib.nullcontext()      # no launch grouping on the host; the calls simply run one after the other
 
         def broadcast(self, dev, root):
-            t = torch.from_numpy(dev.a.copy())
-            self.dist.broadcast(t, src=root)
-            dev.a[...] = t.numpy()
+            dev.a[...] = self.group_.broadcast(np.ascontiguousarray(dev.a).copy(), root)
 
-    comm = GlooAsRccl()
+    comm = HostAsRccl()
     try:
         st = DataParallelObject(HostOps(), comm, shape)
         assert st.inplace

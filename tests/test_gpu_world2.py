@@ -1,7 +1,7 @@
 """BASELINE config 4's exchange step with the PRODUCT at world size 2 on ONE GPU: two fresh processes, both on device 0,
 each running adorym_amd.reconstruct_ptychography with the real HIP kernels, the sharded optimiser and the two-part gather of
 adorym_amd/dp.py; only the transport of the collectives differs from the multi-GPU product (HostStagedComm: device -> host ->
-gloo -> device, because RCCL refuses two ranks on one device -- tools/rccl_two_ranks_one_gpu.py).
+TCP star -> device, because RCCL refuses two ranks on one device -- tools/rccl_two_ranks_one_gpu.py).
 
 Checked against golden F14 = the REFERENCE driver run as two processes (tests/golden/gen_f14_world2.py), i.e.
 adorym/ptychography.py:786,846,905-909 (rank split), :1113-1114 (summed gradients), forward_model.py:138-139 (one regulariser
@@ -128,7 +128,7 @@ def _serial_two_rank_update(A, params, seen, world):
 
 
 def run_world2(tmp_path, n_use, extra, env=None, emulate=False):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp
     world, port = 2, _free_port()
     mpc = mp.get_context('spawn')
     q = mpc.Queue()

@@ -1,0 +1,138 @@
+"""The framework-free control plane of the multi-GPU path (adorym_amd/rendezvous.py), three processes on localhost; replaces
+the reference's mpi4py seam (adorym/ptychography.py:39-50: rank / size / bcast / Barrier) and, for the host-staged
+validation transport, carries whole arrays."""
+import multiprocessing as mp
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, env, q, scenario):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1')
+    os.environ.update(env)
+    try:
+        from adorym_amd.rendezvous import TcpGroup
+        g = TcpGroup.from_env()
+        out = {'rank': rank, 'size': g.size}
+        if scenario == 'mismatch':
+            try:
+                if rank == 0:
+                    g.sum_over_ranks(1.0)
+                else:
+                    g.max_over_ranks(1.0)
+                out['raised'] = False
+            except RuntimeError as e:
+                out['raised'] = 'mismatch' in str(e)
+            except Exception:
+                out['raised'] = True          # the peer closed first: also not a silent hang
+            g.close()
+            q.put(out)
+            return
+        g.barrier()
+        out['sum'] = g.sum_over_ranks(rank + 1.0)
+        out['max'] = g.max_over_ranks(10.0 - rank)
+        out['bc0'] = g.bcast_object({'ids': [b'\x01' * 128, b'\x02' * 128]} if rank == 0 else None, root=0)
+        out['bc2'] = g.bcast_object('from two' if rank == 2 else None, root=2)
+        a = (np.arange(12, dtype=np.float32).reshape(3, 4) + 100 * rank)
+        out['allreduce'] = g.all_reduce_sum(a.copy())
+        out['reduce1'] = g.reduce_sum(a.copy(), 1)
+        b = np.full(5, rank, np.float32)
+        out['bcast_arr'] = g.broadcast(b.copy() if rank == 1 else np.zeros(5, np.float32), 1)
+        out['gather'] = g.all_gather(np.full(4, rank, np.float32))
+        big = np.random.default_rng(rank).standard_normal(1 << 20).astype(np.float32)      # 4 MB: many TCP segments
+        out['big'] = float(np.abs(g.all_reduce_sum(big.copy())).sum())
+        g.barrier()
+        g.close()
+        q.put(out)
+    except Exception as e:
+        import traceback
+        q.put({'rank': rank, 'error': '%r\n%s' % (e, traceback.format_exc())})
+
+
+def _run(world, env, scenario='all'):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, env, q, scenario)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    for r in res:
+        assert 'error' not in r, r['error']
+    return sorted(res, key=lambda r: r['rank'])
+
+
+@pytest.mark.parametrize('mode', ['master_port', 'torchrun_like', 'exact_port'])
+def test_tcp_group_collectives_world3(mode):
+    port = _free_port()
+    env = {'MASTER_PORT': str(port)}
+    holder = None
+    if mode == 'torchrun_like':
+        # torch.distributed.run keeps MASTER_PORT for its own store: the star must come up on a port above it
+        holder = socket.socket(); holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1); holder.bind(('127.0.0.1', port)); holder.listen(8)
+        env['TORCHELASTIC_RUN_ID'] = 'none'
+    if mode == 'exact_port':
+        env = {'ADM_RDV_PORT': str(port), 'ADM_RDV_JOB': 'job-7', 'MASTER_PORT': '1'}
+    try:
+        res = _run(3, env)
+    finally:
+        if holder is not None:
+            holder.close()
+    ref = sum(np.arange(12, dtype=np.float32).reshape(3, 4) + 100 * r for r in range(3))
+    bigs = [np.random.default_rng(r).standard_normal(1 << 20).astype(np.float32) for r in range(3)]
+    big_ref = float(np.abs((bigs[0] + bigs[1]) + bigs[2]).sum())         # rank order, like the star
+    for r in res:
+        k = r['rank']
+        assert r['size'] == 3 and r['sum'] == 6.0 and r['max'] == 10.0
+        assert r['bc0'] == {'ids': [b'\x01' * 128, b'\x02' * 128]} and r['bc2'] == 'from two'
+        assert np.array_equal(r['allreduce'], ref)
+        mine = np.arange(12, dtype=np.float32).reshape(3, 4) + 100 * k
+        assert np.array_equal(r['reduce1'], ref if k == 1 else mine)       # only the root's array changes
+        assert np.array_equal(r['bcast_arr'], np.full(5, 1, np.float32))
+        assert np.array_equal(r['gather'], np.repeat(np.arange(3, dtype=np.float32), 4))
+        assert r['big'] == big_ref                                         # bit-identical on every rank
+
+
+def test_tcp_group_detects_mismatched_collectives():
+    res = _run(2, {'MASTER_PORT': str(_free_port()), 'ADM_RDV_TIMEOUT': '20'}, scenario='mismatch')
+    assert res[0]['raised']         # rank 0 reads the peer's frame and sees the wrong operation name
+
+
+def test_single_rank_group_needs_no_socket():
+    sys.path.insert(0, ROOT)
+    from adorym_amd.rendezvous import TcpGroup
+    g = TcpGroup(0, 1)
+    g.barrier()
+    assert g.sum_over_ranks(3.5) == 3.5 and g.max_over_ranks(2) == 2.0 and g.bcast_object('x') == 'x'
+    a = np.arange(4, dtype=np.float32)
+    assert np.array_equal(g.all_reduce_sum(a.copy()), a) and np.array_equal(g.all_gather(a), a)
+    g.close()
+
+
+def test_product_comm_module_imports_no_torch():
+    """`import torch` appears nowhere under adorym_amd/ outside TorchComm (north_star: no PyTorch backend)."""
+    import re
+    pkg = os.path.join(ROOT, 'adorym_amd')
+    hits = []
+    for name in sorted(os.listdir(pkg)):
+        if not name.endswith('.py'):
+            continue
+        src = open(os.path.join(pkg, name)).read()
+        for m in re.finditer(r'^\s*(import torch|from torch)', src, re.M):
+            line = src.count('\n', 0, m.start()) + 1
+            hits.append((name, line))
+    cls = open(os.path.join(pkg, 'comm.py')).read()
+    a = cls.index('class TorchComm')
+    b = cls.index('class RcclComm')
+    lo, hi = cls.count('\n', 0, a) + 1, cls.count('\n', 0, b) + 1
+    assert hits and all(n == 'comm.py' and lo <= l < hi for n, l in hits), hits
