@@ -18,6 +18,7 @@ class Context(object):
         check(self.lib.adm_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self.handle = h
         self.device = int(device)
+        _lib.CREATED_CONTEXT = True
 
     def sync(self):
         check(self.lib.adm_ctx_sync(self.handle))

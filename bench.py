@@ -115,57 +115,23 @@ def cpu_baseline(cfg, seconds_budget=12.0):
                'sample': '%d positions on one core (the all-core pool failed: %r)' % (done, e)}
     out['one_core'] = one
     try:
-        out['reference_structured'] = cpu_baseline_torch(cfg, phys, probe)
+        out['reference_structured'] = cpu_baseline_torch()
     except Exception as e:      # a reported extra, never fatal for the bench line
         out['reference_structured'] = {'error': repr(e)}
     return out
 
 
-def cpu_baseline_torch(cfg, phys, probe, budget_s=75.0):
-    """Second flavour (SURVEY.md 8d ii): the reference's own op structure -- PyTorch-CPU tensors, separate re/im, strided slice
-    selects, torch.autograd.grad -- restated in oracle/torch_structured.py (timed within 15 % of the imported reference in the
-    build container: oracle/time_vs_reference.py).  A minibatch of B = 4 positions of config 3 (full 256^3 object: tile gather +
-    forward + autograd backward; the size SURVEY / BASELINE.md quote the reference at) is timed for torch thread counts
-    8 ... host cores, the best is reported with its thread count, then -- time permitting -- a larger minibatch at that count."""
-    import torch
-    from oracle import torch_structured as T
-    Y, X, Z = cfg['obj_size']
-    r = np.random.default_rng(1)
-    obj = np.stack([r.normal(8.7e-7, 1e-7, (Y, X, Z)), r.normal(5.1e-8, 1e-8, (Y, X, Z))], -1).astype(np.float32)
-    n_cpu = os.cpu_count() or 1
-    keep = torch.get_num_threads()
-    t_start = time.perf_counter()
-
-    def run(nb, threads):
-        torch.set_num_threads(threads)
-        pos = cfg['probe_pos'][200:200 + nb].astype(int)
-        meas = np.abs(np.random.default_rng(2).standard_normal((nb,) + tuple(cfg['probe_size']))).astype(np.float32)
-        t0 = time.perf_counter()
-        T.loss_and_grad(obj, pos, probe, phys.h, phys.k1, meas)
-        return time.perf_counter() - t0
-
-    T.loss_and_grad(obj[:, :, :4], cfg['probe_pos'][200:202].astype(int), probe, phys.h, phys.k1,
-                    np.ones((2,) + tuple(cfg['probe_size']), np.float32))          # warm-up (thread pool, FFT plans)
-    sweep = []
-    for th in [t for t in (8, 16, 32, 64, 128) if t <= max(8, n_cpu)]:
-        if sweep and time.perf_counter() - t_start > 0.55 * budget_s:
-            break
-        dt = run(4, min(th, n_cpu))
-        sweep.append({'threads': min(th, n_cpu), 'positions': 4, 'seconds': dt, 'positions_per_s': 4 / dt})
-    best = max(sweep, key=lambda q: q['positions_per_s'])
-    out = {'value': best['positions_per_s'], 'unit': 'probe-positions/s', 'cores': best['threads'], 'kind': 'port', 'thread_sweep': sweep,
-           'sample': '4 positions of config 3 (256^3 object, P=72, 256 slices): tile gather + fwd + torch.autograd backward, fp32, '
-                     'reference op structure (oracle/torch_structured.py), %.1f s at the best of the thread counts tried, torch %s'
-                     % (best['seconds'], torch.__version__)}
-    left = budget_s - (time.perf_counter() - t_start)
-    nb = int(min(32, 0.8 * left * best['positions_per_s']))
-    if nb >= 8:
-        dt = run(nb, best['threads'])
-        out['larger_minibatch'] = {'threads': best['threads'], 'positions': nb, 'seconds': dt, 'positions_per_s': nb / dt}
-        if nb / dt > out['value']:
-            out['value'] = nb / dt
-    torch.set_num_threads(keep)
-    return out
+def cpu_baseline_torch(budget_s=75.0):
+    """Second flavour (SURVEY.md 8d ii): the reference's own op structure on PyTorch-CPU autograd, timed by
+    oracle/torch_structured_bench.py in a CHILD process -- this process, which holds the GPU context, never imports torch (a
+    PyTorch-ROCm wheel loads its own copy of the HIP runtime beside the one libadm is linked to; the two do not shut down
+    cleanly together, and the benchmark must exit 0)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'torch_structured_bench.py'), str(budget_s)],
+                       capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError('torch_structured_bench.py exited %d: %s' % (r.returncode, r.stderr[-400:]))
+    return json.loads(r.stdout.strip().split('\n')[-1])
 
 
 def cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize):

@@ -66,3 +66,13 @@ def loss_and_grad(obj_rot, pos, probe, h, k1, meas, far_field=True, sign=1, dtyp
     loss = torch.mean((pred - t(meas)) ** 2)
     g, = torch.autograd.grad(loss, [obj])
     return float(loss.detach()), g.numpy()
+
+
+# run as a script: python oracle/torch_structured.py in.npz out.npz  (oracle/torch_child.py drives it from a torch-free process)
+if __name__ == '__main__':
+    import sys
+    f_ = np.load(sys.argv[1])
+    if int(f_['threads']) > 0:
+        torch.set_num_threads(int(f_['threads']))
+    loss_, grad_ = loss_and_grad(f_['obj_rot'], f_['pos'], f_['probe'], f_['h'], float(f_['k1']), f_['meas'])
+    np.savez(sys.argv[2], loss=np.float64(loss_), grad=grad_)

@@ -13,6 +13,16 @@ def pytest_configure(config):
 
 import pytest
 
+def pytest_sessionfinish(session, exitstatus):
+    """The product never imports torch, and the GPU tests must not either: a PyTorch-ROCm wheel carries its own copy of the HIP
+    runtime and asks for it by an unversioned name, so when libadm.so (linked to /opt/rocm's libamdhip64.so.7) is loaded
+    first and torch later, the process holds two HIP runtimes and aborts at exit ("double free or corruption") after every
+    test has passed.  Torch-based checkers run in child processes (oracle/torch_child.py).  Say so if it happens anyway."""
+    lib = sys.modules.get('adorym_amd._lib')
+    if lib is not None and getattr(lib, '_lib', None) is not None and 'torch' in sys.modules and getattr(lib, 'CREATED_CONTEXT', False):
+        sys.stderr.write('\nWARNING (tests/conftest.py): torch was imported into a process that holds a libadm GPU context; '
+                         'the interpreter may abort at exit.  Move the torch-based check into a child process.\n')
+
 
 @pytest.fixture(scope='session')
 def rccl_world1():

@@ -463,7 +463,7 @@ def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
     the reference-structured fp32 arithmetic and 1.4e-3 for the oracle's fp32 run, which is the yardstick here); at the 45-degree-class angle 6 positions of
     the same rows (the batch size only enters through the 2/(B*Py*Px) factor).  Three consecutive minibatches and a 'per angle'
     update through the driver, object against object: tests/test_gpu_fullsize.py."""
-    from oracle import torch_structured as T
+    from oracle import torch_child as T          # the torch-based checker runs in a child process (see oracle/torch_child.py)
     from adorym_amd.util import rotation_lookup
     N, P = 256, 72
     theta = np.float32(theta)
@@ -512,13 +512,8 @@ def test_c3_full_size_minibatch_vs_oracle(A, ctx, theta, full):
         g32 = (g32 + reg_grad(g32in).astype(np.float32))[1:-1]
     else:
         rot32 = O.rotate_fwd(g32in, coords, np.float32)
-        import torch
-        keep = torch.get_num_threads()
-        torch.set_num_threads(min(16, keep))      # (PyTorch-CPU is fastest at ~16 threads on this path: bench.py's thread sweep)
-        try:
-            loss32, grot32 = T.loss_and_grad(rot32, pos_s, probe, phys.h, phys.k1, meas.astype(np.float32))
-        finally:
-            torch.set_num_threads(keep)
+        # (PyTorch-CPU is fastest at ~16 threads on this path: bench.py's thread sweep)
+        loss32, grot32 = T.loss_and_grad_subprocess(rot32, pos_s, probe, phys.h, phys.k1, meas.astype(np.float32), threads=min(16, os.cpu_count() or 1))
         g32 = (O.rotate_adj(np.asarray(grot32), coords, np.float32) + reg_grad(g32in).astype(np.float32))[1:-1]
         del rot32, grot32
     # ---- GPU: the full 256^3 object (zero outside the slab; the TV term sees that edge only on the two slab-edge planes,
