@@ -8,7 +8,7 @@ There is no CPU fallback: importing the device layer without the built library r
 from .constants import PI  # noqa: F401
 from . import global_settings  # noqa: F401
 from .device import Context, DeviceArray, Plan, Event, PinnedArray, UploadRing  # noqa: F401
-from .propagate import MultisliceEngine, RotationTable, get_kernel, gen_freq_mesh  # noqa: F401
+from .propagate import MultisliceEngine, RotationTable, AngleBatch, get_kernel, gen_freq_mesh  # noqa: F401
 from .holography import HolographyEngine  # noqa: F401
 
 __version__ = '0.1.0'

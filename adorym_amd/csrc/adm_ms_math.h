@@ -46,6 +46,11 @@ template <int N, int R1, int R2> struct Layout {
 template <> struct Layout<72, 8, 9> {
     static constexpr int PA = 1, PB = 65, Q = 73;
 };
+// P = 64 (BASELINE configs 1 and 2): the smallest of the best layouts of the same search under the instruction-time model
+// (`lds_layout_search 64 8 8 100 1`): 4736 LDS cycles per pass set against 6912 for the plain padded image (8, 1, 65).
+template <> struct Layout<64, 8, 8> {
+    static constexpr int PA = 4, PB = 34, Q = 67;
+};
 
 template <int N, int R1, int R2> struct Geo {
     static constexpr int G = (R1 > R2) ? R1 : R2;      // threads per line

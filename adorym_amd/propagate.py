@@ -480,3 +480,48 @@ class MultisliceEngine(object):
         # outside the batch's y-footprint the gradient is identically zero (and grad_rot rows there are stale)
         self.rotate_adjoint(grad_obj, coords, yr)
         return self.loss()
+
+
+class AngleBatch(object):
+    """R rotation angles of an UNDIVIDED full-field dataset evaluated in one multislice launch (BASELINE config 2's "minibatch
+    16": the reference forces minibatch_size = 1 for such data, adorym/ptychography.py:342-346, so 16 in flight are 16 ranks
+    with one angle each whose gradients are summed, :1113-1114).  One angle is one workgroup, a chain of S dependent
+    propagations that leaves 255 CUs idle; R angles are independent until the sum.
+
+    No new kernel: the engine is built for a STACK of R objects along y -- plan geometry (R*Y, X, Z), probe position r at
+    (r*Y + y0, x0).  Rotations act on every y plane separately with absolute plane numbers, so block r is rotated with angle
+    r's table from the ONE real object by handing the kernel the object's address minus r blocks (plane r*Y + y of the stack
+    then IS plane y of the object; nothing outside the block's planes is touched), and block r of the stacked gradient image
+    is back-rotated -- the deterministic CSR gather, '+=' -- into the one real gradient buffer the same way, block after block
+    on one stream.  Same sums as R separate evaluations accumulated into one buffer, in the same order per voxel."""
+
+    def __init__(self, ctx, obj_size, probe_size, n_angles, energy_ev, psize_cm, probe_pos=(0, 0), **engine_kwargs):
+        self.ctx = ctx
+        self.obj_size = tuple(int(v) for v in obj_size)
+        self.R = int(n_angles)
+        Y, X, Z = self.obj_size
+        y0, x0 = int(probe_pos[0]), int(probe_pos[1])
+        self.pos = np.array([(r * Y + y0, x0) for r in range(self.R)], dtype=np.int64)
+        engine_kwargs.setdefault('max_batch', self.R)
+        self.engine = MultisliceEngine(ctx, (self.R * Y, X, Z), probe_size, self.pos, energy_ev, psize_cm, **engine_kwargs)
+        self.block_bytes = Y * X * Z * 2 * 4
+
+    def _shifted(self, arr, r):
+        Y, X, Z = self.obj_size
+        return DeviceArray(self.ctx, (self.R * Y, X, Z, 2), np.float32, ptr=arr.ptr - r * self.block_bytes)
+
+    def loss_and_grad(self, obj, grad_obj, tables, probe, targets):
+        """obj, grad_obj: DeviceArray [Y,X,Z,2]; tables: R RotationTables (built for obj_size); targets [R,Py,Px] magnitudes
+        (host or device).  grad_obj += sum over angles of d(mean loss of angle r)/d obj.  Returns the R losses (blocking)."""
+        eng = self.engine
+        Y = self.obj_size[0]
+        eng.set_batch(self.pos, targets)
+        for r, t in enumerate(tables):
+            eng.rotate(self._shifted(obj, r), t, (r * Y, (r + 1) * Y))
+        n_det = eng.n_det
+        eng.multislice(probe, grad_scale=2.0 / n_det)          # every angle is its own minibatch of one: mean over ITS pixels
+        for r, t in enumerate(tables):
+            eng.rotate_adjoint(self._shifted(grad_obj, r), t, (r * Y, (r + 1) * Y))
+        eng._check_overflow()
+        sums = eng._loss.view(0, (self.R,)).get().astype(np.float64)
+        return sums / n_det

@@ -145,6 +145,27 @@ def cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize):
     return time.perf_counter() - t1
 
 
+def cpu_baseline_c2(guess, thetas, probe_h, data, energy, psize, budget_s=20.0):
+    """CPU leg of tools/bench_rows.py (config-2 shape): the oracle's fp32 forward + hand adjoint of whole angles (rotation,
+    multislice chain, back-rotation, L1 term) on one core, as many of the 16 angles as fit the budget."""
+    from oracle import adorym_oracle as O
+    N = guess.shape[0]
+    phys = O.Physics((N, N), energy, psize, free_prop_cm=0)
+    pos = np.array([(0, 0)])
+    g32 = guess.astype(np.float32)
+    done, t_used = 0, 0.0
+    for th, meas in zip(thetas, data):
+        t1 = time.perf_counter()
+        c = O.rotation_coords((N, N, N), th)
+        O.forward_adjoint_object(g32, c, probe_h, pos, meas, phys, 'float32')
+        O.l1_value_grad(g32, 1e-9 * N ** 3, 1e-10 * N ** 3)
+        t_used += time.perf_counter() - t1
+        done += 1
+        if t_used > budget_s:
+            break
+    return done, t_used
+
+
 def cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize):
     """CPU leg of tools/bench_rows.py (config-5 shape): seconds for the oracle's fwd + adjoint of the 4-distance chain."""
     from oracle import adorym_oracle as O

@@ -1,5 +1,5 @@
 """CPU side of tests/test_gpu_fullsize.py: the fp64 / fp32 oracle runs of the full-size config-3 case, each in its own process so
-that they run side by side with each other and with the GPU (`python tests/fullsize_oracle.py OUT.npz immediate float64`).
+that they run side by side with each other and with the GPU (`python tests/fullsize_oracle.py OUT.npy immediate float64 [PRJ.npy [case [n_ranks]]]`).
 Test infrastructure only: the oracle is the checker, never the product.
 
 The oracle works on the slab [s0, s1) of y planes (cases.fullsize_inputs): planes are independent under the rotation, the data
@@ -16,11 +16,11 @@ import cases
 from oracle import adorym_oracle as O
 
 
-def setup():
+def setup(case=1):
     from adorym_amd.workloads import c3_config
     from adorym_amd.util import initialize_probe
     cfg = c3_config()
-    inp = cases.fullsize_inputs()
+    inp = cases.fullsize_inputs(case)
     P = cases.FULLSIZE['P']
     pr, pi = initialize_probe((P, P), **cfg['probe'])
     probe = np.squeeze(pr) + 1j * np.squeeze(pi)
@@ -29,20 +29,23 @@ def setup():
 
 
 def measured(inp, probe, phys):
-    """|far field| of the truth slab at every position, fp64 -> [1, n_pos, P, P]"""
+    """|far field| of the truth slab at every position and angle, fp64 -> [n_theta, n_pos, P, P]"""
     N = cases.FULLSIZE['N']
-    coords = O.rotation_coords((inp['s1'] - inp['s0'], N, N), inp['theta'], np.float64)
     pos_s = np.round(inp['pos']).astype(int) - np.array([inp['s0'], 0])
-    rot = O.rotate_fwd(inp['truth_slab'], coords, np.float64)
-    out = []
-    for i in range(0, len(pos_s), 23):
-        tt, _ = O.extract_tiles(rot, pos_s[i:i + 23], probe.shape)
-        out.append(O.predict(tt, probe, phys, 'float64')[0])
-    return np.concatenate(out)[None]
+    per_theta = []
+    for theta in inp['thetas']:
+        coords = O.rotation_coords((inp['s1'] - inp['s0'], N, N), theta, np.float64)
+        rot = O.rotate_fwd(inp['truth_slab'], coords, np.float64)
+        out = []
+        for i in range(0, len(pos_s), 23):
+            tt, _ = O.extract_tiles(rot, pos_s[i:i + 23], probe.shape)
+            out.append(O.predict(tt, probe, phys, 'float64')[0])
+        per_theta.append(np.concatenate(out))
+    return np.stack(per_theta)
 
 
-def run(scheme, dtype, prj=None):
-    cfg, inp, probe, phys = setup()
+def run(scheme, dtype, prj=None, case=1, n_ranks=1):
+    cfg, inp, probe, phys = setup(case)
     if prj is None:
         prj = measured(inp, probe, phys)
     N = cases.FULLSIZE['N']
@@ -50,13 +53,16 @@ def run(scheme, dtype, prj=None):
     sc = (s1 - s0) / float(N)
     pos_s = inp['pos'] - np.array([s0, 0.])
     g = inp['guess'][s0:s1]
-    x = O.reconstruct(prj, (g[..., 0], g[..., 1]), probe, pos_s, np.array([inp['theta']], dtype='float32'), phys, n_epochs=1,
+    x = O.reconstruct(prj, (g[..., 0], g[..., 1]), probe, pos_s, inp['thetas'], phys, n_epochs=1,
                       minibatch_size=cfg['minibatch_size'], optimizer='adam', learning_rate=cfg['learning_rate'],
-                      alpha_d=cfg['alpha_d'] * sc, alpha_b=cfg['alpha_b'] * sc, gamma=cfg['gamma'] * sc, update_scheme=scheme, dtype=dtype)
+                      alpha_d=cfg['alpha_d'] * sc, alpha_b=cfg['alpha_b'] * sc, gamma=cfg['gamma'] * sc, update_scheme=scheme, dtype=dtype,
+                      n_ranks=n_ranks)
     return x
 
 
 if __name__ == '__main__':
     out, scheme, dtype = sys.argv[1:4]
     prj = np.load(sys.argv[4]) if len(sys.argv) > 4 else None
-    np.save(out, run(scheme, dtype, prj))
+    case = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    n_ranks = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    np.save(out, run(scheme, dtype, prj, case, n_ranks))

@@ -222,18 +222,29 @@ def smooth_field_fast(shape, seed, cutoff=0.12):
     return a / a.max()
 
 
-def fullsize_inputs():
+# TWO angles (0.4 rad and a 45-degree-class one), 64 positions = two full minibatches per angle with DIFFERENT y-footprints (rows
+# 10-11, then the rest of row 11 with 18 positions of row 13): four 'immediate' minibatches, the transmission cache refilled and
+# the adjoint CSR rebuilt for the new angle, the optimiser's step counter advancing at the angle boundary
+# (adorym/ptychography.py:1266-1271); four updates -> the TV stencil reaches four planes into the margin.  (Six updates at
+# this learning rate put even the oracle's own fp32 run beyond BASELINE's absolute RMSE bound of 1e-5: Adam's early steps are
+# lr * sign(g), and the count of rounding-level sign flips grows with every update.)
+FULLSIZE2 = dict(N=256, P=72, rows=(10, 12), extra=(13, 18), thetas=(0.4, 0.78), margin=5)
+
+
+def fullsize_inputs(case=1):
     """BASELINE config 3 at its own size -- 256^3 object, 72 x 72 probe, the 23 x 23 scan with 12-pixel steps, minibatch 32,
     L1 + TV, Adam with the configuration's learning rate -- on three rows of the scan (69 positions = three minibatches of 32
     after the reference's random top-up) at one angle.  The object is smooth and non-zero EVERYWHERE (the deferred part of the
     split Adam pass works on all planes).  A rotation about axis 0 never mixes y planes, so the CPU checker works on the slab of
     planes the positions touch plus `margin` planes either side (the TV stencil reaches one plane further with every update);
     the measured data are the fp64 forward model of a second smooth object on that slab."""
-    F = FULLSIZE
+    F = FULLSIZE if case == 1 else FULLSIZE2
     N, P = F['N'], F['P']
     ys = np.arange(23) * 12 - 36
     allpos = np.array([(y, x) for y in ys for x in ys], dtype=float)
     pos = allpos[F['rows'][0] * 23:F['rows'][1] * 23]
+    if 'extra' in F:
+        pos = np.concatenate([pos, allpos[F['extra'][0] * 23:F['extra'][0] * 23 + F['extra'][1]]])
     y_lo, y_hi = int(pos[:, 0].min()), int(pos[:, 0].max()) + P
     s0, s1 = y_lo - F['margin'], y_hi + F['margin']
     guess = np.stack([3e-4 * smooth_field_fast((N, N, N), 271), 1.5e-5 * smooth_field_fast((N, N, N), 272)], -1)
@@ -241,4 +252,5 @@ def fullsize_inputs():
     # (the truth is related to the guess, as in a reconstruction under way: the data term then pulls on every footprint voxel)
     truth_slab = np.stack([3e-4 * smooth_field_fast(shp, 275), 1.5e-5 * smooth_field_fast(shp, 276)], -1)
     truth_slab = 0.6 * guess[s0:s1] + 0.4 * truth_slab
-    return dict(pos=pos, y_lo=y_lo, y_hi=y_hi, s0=s0, s1=s1, guess=guess, truth_slab=truth_slab, theta=np.float32(F['theta']))
+    thetas = np.linspace(F['thetas'][0], F['thetas'][1], 2, dtype='float32') if case != 1 else np.array([F['theta']], dtype='float32')
+    return dict(pos=pos, y_lo=y_lo, y_hi=y_hi, s0=s0, s1=s1, guess=guess, truth_slab=truth_slab, theta=thetas[0], thetas=thetas)

@@ -357,6 +357,19 @@ def test_c2_sixteen_virtual_ranks_sum_vs_oracle(A, ctx):
     assert e <= 3 * e32 + 1e-5, (e, e32)
     d = np.abs(x - x64)
     assert np.sqrt(np.mean(d ** 2)) < 1e-8 and (d > 3e-8).mean() < 2e-3       # Adam's first step is lr * sign-like: lr = 1e-7
+    # ---- the same 16 angles in ONE launch (adorym_amd.AngleBatch: 16 workgroups, the object rotated block by block into a
+    # stacked frame): the same losses and the same summed gradient ----
+    ab = A.AngleBatch(ctx, (N, N, N), (N, N), R, 800., 0.67e-7, free_prop_cm=0)
+    obj2 = ctx.array(guess.astype(np.float32))
+    grad2 = ctx.zeros((N, N, N, 2))
+    tabs = [A.RotationTable(ctx, (N, N, N), th) for th in thetas]
+    losses2 = ab.loss_and_grad(obj2, grad2, tabs, d_probe, np.concatenate(data).reshape(R, N, N))
+    for _ in range(R):
+        check(ctx.lib.adm_reg_grad(eng.plan.handle, obj2.ptr, a_d, a_b, 0.0, grad2.ptr, None))
+    g2 = grad2.get()
+    assert np.allclose(losses2, losses64, rtol=2e-5)
+    assert rel(g2, g64) <= 3 * e32 + 1e-5
+    assert rel(g2, g) < 2e-6, rel(g2, g)          # (order of the fp32 additions per voxel differs: data terms first, L1 terms last)
 
 
 def c2(z):

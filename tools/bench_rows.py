@@ -4,6 +4,9 @@ Measurement of the "next" rows at the shapes BASEL
 pinned NumPy oracle on the host.  Not the headline metric (bench.py is); prints one JSON object per row.
 
     python tools/bench_rows.py            # on a GPU box
+C2 shape: full-field multislice tomography, 64^3 object, plane probe 64 x 64, 64 slices, near field (free_prop_cm = 0), L1,
+          Adam; BASELINE's "minibatch 16" = 16 virtual ranks x minibatch 1: 16 angles, gradients summed, one update
+          (tests/test_multislice_tomography_64.py:20-65 of the reference)
 C1 shape: 2-D ptychography, 618 x 606 x 1 real_imag object, 5 incoherent probe modes (P = 64), minibatch 35, intensity
           data, Adam on object + probe + sub-pixel probe positions, TV regulariser  (demos/2d_ptychography_experimental_data.py)
 C5 shape: multi-distance holography, 512 x 512 x 1 real_imag object, plane probe, 4 distances, Adam on object +
@@ -22,6 +25,120 @@ import adorym_amd as A                      # noqa: E402
 from adorym_amd._lib import check           # noqa: E402
 from adorym_amd.optimizers import AdamOptimizer, apply_small_params      # noqa: E402
 import bench                                # noqa: E402  (its cpu_baseline legs own the oracle timing)
+
+
+def bench_c2(ctx, steps=30):
+    from adorym_amd import workloads as W
+    from adorym_amd.dp import DataParallelObject, HipOps
+    from adorym_amd.comm import LocalComm
+    cfg = W.c2_config()
+    N, R = cfg['obj_size'][0], 16
+    r = np.random.default_rng(2)
+    thetas = np.linspace(cfg['theta_st'], cfg['theta_end'], cfg['n_theta'], dtype='float32')[3:3 + R]
+    guess = W.random_guess((N, N, N), seed=0)
+    probe_h = np.ones((N, N), complex)
+    probe = ctx.array(np.stack([probe_h.real, probe_h.imag], -1)[None].astype(np.float32))
+    data_h = (1 + 0.05 * np.abs(r.standard_normal((R, N, N)))).astype(np.float32)       # throughput is data independent
+    data = ctx.array(data_h)
+    tables = [A.RotationTable(ctx, (N, N, N), th) for th in thetas]
+    a_d, a_b = cfg['alpha_d'], cfg['alpha_b']
+    lr = cfg['learning_rate']
+    alg = R * 4 * (3 * N * N * N * 2 + N * N + 2 * 2 * N ** 3)         # 10.5 MB per angle
+    out = {}
+    # ---- (a) the 16 ranks' evaluations one after the other (what one GPU does with the reference's control flow) ----
+    eng = A.MultisliceEngine(ctx, (N, N, N), (N, N), cfg['probe_pos'], cfg['energy_ev'], cfg['psize_cm'], free_prop_cm=0, max_batch=1,
+                             transmissions_only=True)
+    st = DataParallelObject(HipOps(ctx), LocalComm(), (N, N, N, 2))
+    obj, grad = st.obj.view(0, (N, N, N, 2)), st.grad.view(0, (N, N, N, 2))
+    obj.set(guess)
+    for t in tables:
+        t.csr(eng.plan)
+    ev = [ctx.event() for _ in range(2)]
+
+    def step_seq(k, timed):
+        ms = 0.0
+        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, a_d * R, a_b * R, 0.0, grad.ptr, None))      # every rank adds the L1 term
+        for i, t in enumerate(tables):
+            eng.set_batch(cfg['probe_pos'], data.view(i * N * N, (1, N, N)))
+            eng.rotate(obj, t, None)
+            if timed:
+                ev[0].record()
+            eng.multislice(probe, accumulate=False)
+            if timed:
+                ev[1].record()
+            eng.accumulate_tiles()
+            eng.rotate_adjoint(grad, t, None)
+            if timed:
+                ms += ev[0].elapsed_ms(ev[1])           # (blocks: the sequential leg is timed per launch, separately from the loop below)
+        st.exchange_and_update('adam', k, {'step_size': lr})
+        return ms
+
+    for k in range(2):
+        step_seq(k, False)
+    kern_seq = np.mean([step_seq(k, True) for k in range(3)]) / R
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step_seq(k, False)
+    ctx.sync()
+    dt_seq = (time.perf_counter() - t0) / steps
+    g_seq = None
+    obj.set(guess)
+    check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, a_d * R, a_b * R, 0.0, grad.ptr, None))
+    for i, t in enumerate(tables):
+        eng.set_batch(cfg['probe_pos'], data.view(i * N * N, (1, N, N)))
+        eng.rotate(obj, t, None)
+        eng.multislice(probe)
+        eng.rotate_adjoint(grad, t, None)
+    g_seq = grad.get()
+    # ---- (b) the 16 angles in ONE launch (adorym_amd.AngleBatch): 16 workgroups instead of 16 launches of one ----
+    ab = A.AngleBatch(ctx, (N, N, N), (N, N), R, cfg['energy_ev'], cfg['psize_cm'], free_prop_cm=0, transmissions_only=True)
+    e2 = ab.engine
+    for t in tables:
+        t.csr(e2.plan)
+    Yb = N
+
+    def step_stack(k, timed):
+        check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, a_d * R, a_b * R, 0.0, grad.ptr, None))
+        e2.set_batch(ab.pos, data)
+        for i, t in enumerate(tables):
+            e2.rotate(ab._shifted(obj, i), t, (i * Yb, (i + 1) * Yb))
+        if timed:
+            ev[0].record()
+        e2.multislice(probe, grad_scale=2.0 / e2.n_det, accumulate=False)
+        if timed:
+            ev[1].record()
+        e2.accumulate_tiles()
+        for i, t in enumerate(tables):
+            e2.rotate_adjoint(ab._shifted(grad, i), t, (i * Yb, (i + 1) * Yb))
+        st.exchange_and_update('adam', k, {'step_size': lr})
+        return ev[0].elapsed_ms(ev[1]) if timed else 0.0
+
+    obj.set(guess)
+    check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, a_d * R, a_b * R, 0.0, grad.ptr, None))
+    g_loss = ab.loss_and_grad(obj, grad, tables, probe, data)
+    g_stack = grad.get()
+    same = float(np.linalg.norm(g_stack - g_seq) / np.linalg.norm(g_seq))
+    for k in range(2):
+        step_stack(k, False)
+    kern_stack = float(np.mean([step_stack(k, True) for k in range(5)]))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step_stack(k, False)
+    ctx.sync()
+    dt_stack = (time.perf_counter() - t0) / steps
+    done, t_cpu = bench.cpu_baseline_c2(guess, thetas, probe_h, data_h, cfg['energy_ev'], cfg['psize_cm'])
+    roof = lambda ms, n_ang: {'bound': 'hbm', 'kernel': 'ms_fwd_adj_kernel<64,8,8>', 'achieved': n_ang * alg / R / (ms * 1e-3) / 1e9,
+                              'peak': bench.PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': n_ang * alg / R / (ms * 1e-3) / 1e9 / bench.PEAK_HBM_GBS,
+                              'kernel_ms': ms, 'algorithmic_bytes_per_launch': n_ang * alg // R, 'traffic': None}
+    return {'row': 'config-2 shape', 'workload': cfg['name'] + ', 16 virtual ranks x minibatch 1 (16 angles per update, gradients summed), L1, Adam',
+            'value': R / dt_stack, 'unit': 'angles/s (= probe-positions/s: one 64x64 full-field position per angle)', 'ms_per_step': 1e3 * dt_stack,
+            'dtype': 'f32', 'roofline': dict(roof(kern_stack, R), whole_step_frac=alg / dt_stack / 1e9 / bench.PEAK_HBM_GBS),
+            'one_launch_per_angle': {'value': R / dt_seq, 'ms_per_step': 1e3 * dt_seq, 'roofline': dict(roof(kern_seq, 1), whole_step_frac=alg / dt_seq / 1e9 / bench.PEAK_HBM_GBS)},
+            'stacked_vs_sequential_gradient_rel_l2': same, 'loss_first_angle': float(g_loss[0]),
+            'cpu_baseline': {'value': done / t_cpu, 'unit': 'angles/s', 'cores': 1, 'kind': 'port',
+                             'sample': '%d whole angles (rotation + 64-slice chain fwd + hand adjoint + back-rotation + L1) in %.1f s, oracle fp32, one core' % (done, t_cpu)}}
 
 
 def bench_c1(ctx, steps=50):
@@ -133,5 +250,5 @@ def bench_c5(ctx, steps=50):
 
 if __name__ == '__main__':
     ctx = A.Context(0)
-    for fn in (bench_c1, bench_c5):
+    for fn in (bench_c2, bench_c1, bench_c5):
         print(json.dumps(fn(ctx)))
