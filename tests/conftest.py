@@ -9,6 +9,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'regression: self-comparison of two paths of THIS build (bit-equality guards) -- not parity evidence; '
+                                       'the parity tests proper are `-m "gpu and not regression"`')
 
 
 import pytest

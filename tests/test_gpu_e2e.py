@@ -214,6 +214,7 @@ def test_summary_intermediate_outputs_and_plugin_loss_methods(tmp_path):
 @pytest.mark.parametrize('extra', [dict(), dict(update_scheme='per angle'), dict(optimize_probe=True, probe_learning_rate=1e-3,
                                                                                   save_intermediate=True, store_checkpoint=True,
                                                                                   n_batch_per_checkpoint=3)])
+@pytest.mark.regression
 def test_driver_through_rccl_world1_equals_local_run_bitwise(tmp_path, extra, rccl_world1):
     """The whole driver on the multi-GPU code path (RCCL behind the C ABI, in-place reduce-scatter, sharded Adam, the planes
     the next minibatches read broadcast first and the full all-gather deferred to the side stream) at world size 1 gives

@@ -76,6 +76,7 @@ def test_tiles_hanging_over_every_edge_and_duplicates(A, ctx):
     assert rel(d_grad.get(), g_o) < 1e-4
 
 
+@pytest.mark.regression
 def test_gradient_path_is_bitwise_reproducible(A, ctx):
     """No atomics on the object-gradient path (tile overlap-add and CSR rotation adjoint are gathers)."""
     r = cases.rng(62)
@@ -403,6 +404,7 @@ def test_config5_shape_driver_vs_reference(A, ctx, tmp_path):
 
 
 @pytest.mark.parametrize('B', [300, 600])
+@pytest.mark.regression
 def test_overlapped_split_launch_matches_single_launch(A, ctx, B):
     """A batch larger than the chip (B > 256 workgroups) launched as equal rounds (150 + 150, 200 + 200 + 200) with every
     round's overlap-add beside the next round (multislice_overlapped) gives the same tile-gradient sums and losses as one

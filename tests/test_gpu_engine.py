@@ -1,5 +1,5 @@
 """
-Round-2 additions, all through the C ABI on a real MI355X (pytest -m gpu):
+Engine features, all through the C ABI on a real MI355X (pytest -m gpu):
   * the device-built rotation-adjoint tables (adm_rotation_csr_build) equal the host builder's, entry for entry;
   * the pinned upload ring (adm_h2d_async) delivers what the blocking path delivers;
   * the overlap-add refuses, BEFORE launching, a batch that covers a pixel with more than 64 tiles -- also on the
@@ -35,6 +35,7 @@ def ctx(A):
 
 @pytest.mark.parametrize('size,theta,pos', [((12, 12, 12), 0.3, [(-3, -2), (5, 4)]), ((9, 40, 24), 3.44159, [(0, 0)]),
                                             ((6, 256, 256), 0.7853982, [(-2, -36), (1, 228)]), ((5, 64, 64), 0.0, [(0, -5)])])
+@pytest.mark.regression
 def test_device_built_rotation_tables_equal_host_builder(A, ctx, size, theta, pos):
     """ptr / src / lsrc / boxes identical, weights identical bit for bit (same fp32 pipeline on both sides); the object and
     the padded frame are non-square and the positions hang over the edges so that pad_x0 > 0."""
@@ -58,6 +59,7 @@ def test_device_built_rotation_tables_equal_host_builder(A, ctx, size, theta, po
     assert np.abs(g1.get() - g2.get()).max() <= 5e-6 * np.abs(g2.get()).max()
 
 
+@pytest.mark.regression
 def test_upload_ring_matches_blocking_upload(A, ctx):
     r = cases.rng(11)
     dev = A.DeviceArray(ctx, (7, 33), np.float32)
@@ -109,6 +111,7 @@ def test_driver_refuses_overcovered_fused_angle(A, ctx, tmp_path):
                                    random_theta=False, store_checkpoint=False, use_checkpoint=False, cpu_only=False)
 
 
+@pytest.mark.regression
 def test_rccl_restricted_exchange_world1_equals_local_bitwise(A, ctx, rccl_world1):
     """The footprint-restricted exchange through RCCL itself (grouped ncclReduce onto the owner, adm_reduce) at world size 1:
     the gradient buffer holds the data term on the touched range only and NaN elsewhere, the owner's `reg_shard` callback writes
@@ -155,6 +158,7 @@ def test_rccl_restricted_exchange_world1_equals_local_bitwise(A, ctx, rccl_world
         rc.ctx = None
 
 
+@pytest.mark.regression
 def test_rccl_comm_world1_equals_local_bitwise(A, ctx, rccl_world1):
     """The multi-GPU code path (adm_comm_init, in-place adm_reduce_scatter / adm_all_gather through RCCL, sharded update) at
     world size 1 gives bit for bit what the single-GPU path gives after 3 Adam steps and a GD step; the small-gradient
@@ -204,6 +208,7 @@ def test_rccl_comm_world1_equals_local_bitwise(A, ctx, rccl_world1):
         rc.ctx = None
 
 
+@pytest.mark.regression
 def test_probe_gradient_is_bitwise_reproducible(A, ctx):
     """the probe gradient was accumulated with float atomics.  Every position now stores its own slot and the
     slots are summed in a fixed order: two launches on the same inputs agree bit for bit, and the sum over a batch equals
@@ -276,6 +281,7 @@ def test_generic_kernel_variants_vs_oracle(A, ctx, kw):
     _generic_case(A, ctx, 20, 28, **kw)
 
 
+@pytest.mark.regression
 def test_generic_kernel_equals_tuned_kernel_at_72(A, ctx):
     """The same minibatch through the tuned kernel and through the generic one (forced): both within the oracle bar, and
     within 1e-4 of each other on the gradient."""
@@ -378,6 +384,7 @@ def c2(z):
 
 @pytest.mark.parametrize('P,n_modes,theta,sign,generic', [(72, 1, 0.6, 1, False), (64, 2, None, 1, False), (36, 1, 2.1, -1, False),
                                                           (72, 1, None, 1, False), (72, 1, 0.6, 1, True), (20, 2, 1.3, 1, True)])
+@pytest.mark.regression
 def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign, generic):
     """adm_plan_set_transmission_cache: exp(-k1 beta)(cos, sin)(-sigma k1 delta) stored per rotated-frame voxel by
     adm_rotate_fwd and loaded by the slice loop gives the SAME bits as evaluating it per position inside the loop (the
@@ -416,6 +423,7 @@ def test_transmission_cache_is_bit_identical(A, ctx, P, n_modes, theta, sign, ge
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+@pytest.mark.regression
 def test_transmission_cache_tracks_its_source_buffer(A, ctx):
     """The cache is used only for the obj_rot buffer adm_rotate_fwd last filled it from: a launch on ANOTHER rotated-frame
     buffer silently takes the in-loop path (right answer), and adm_transmission_refresh adopts a buffer written by other

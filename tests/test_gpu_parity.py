@@ -85,6 +85,7 @@ def test_tiles_forward_adjoint_vs_reference(A, ctx, name):
     assert rel(gp, gp64) < 1e-4
 
 
+@pytest.mark.regression
 def test_forward_only_matches_full(A, ctx):
     """grad_rot == NULL (predict-only) gives the same pred / loss as the full call."""
     name = 'p16_s32_far_bin4'
@@ -104,7 +105,7 @@ def test_forward_only_matches_full(A, ctx):
 
 
 def test_unsupported_configs_raise(A, ctx):
-    """Unlisted and non-square probe sizes now run the generic kernel (tests/test_gpu_round2.py); what still raises is a
+    """Unlisted and non-square probe sizes now run the generic kernel (tests/test_gpu_engine.py); what still raises is a
     probe whose field does not fit one workgroup, and per-position probes on a size without a tuned kernel."""
     pos = np.array([(0, 0)])
     A.MultisliceEngine(ctx, (20, 20, 4), (20, 20), pos, 5000., 1e-7)                # unlisted size: accepted

@@ -1,8 +1,9 @@
 """
-Round-3 additions, all through the C ABI on a real MI355X (pytest -m gpu):
+Driver / kernel variants, all through the C ABI on a real MI355X (pytest -m gpu):
   * the side-stream communicator (adm_comm_init_aux): the deferred all-gather in flight on the side stream while the next
     reduce-scatter is queued on the main stream, 1000 iterations, bit for bit the plain path;
-  * the fused step tail and the other round-3 kernels against their unfused forms (see each test).
+  * rotate_out_of_loop, reweighted L1 on real_imag unknowns, config 3's depth, batches larger than the chip, and the fused
+    kernels against their unfused forms (see each test).
 """
 import os
 import numpy as np
@@ -32,6 +33,7 @@ def ctx(A):
     c.close()
 
 
+@pytest.mark.regression
 def test_side_stream_gather_beside_next_reduce_scatter_1000_iterations(A, ctx, rccl_world1):
     """VERDICT r2 item 2.  RCCL orders the operations of ONE communicator in issue order whatever stream they are given, so
     the deferred all-gather (side stream) and the next reduce-scatter (main stream) each get their own communicator
@@ -241,6 +243,7 @@ def test_more_positions_than_compute_units_vs_oracle(A, ctx, B):
     assert e_p <= 3 * e_p32 + 1e-6 and e_p < 1e-4
 
 
+@pytest.mark.regression
 def test_transmissions_only_rotation_is_bitwise_the_default(A, ctx):
     """adm_plan_set_transmission_cache(plan, 2): the rotation stores the slice transmissions only (the driver's and bench.py's
     mode: nobody reads the rotated (delta, beta) once the slice loop multiplies with cached numbers).  Loss, prediction and
@@ -266,6 +269,7 @@ def test_transmissions_only_rotation_is_bitwise_the_default(A, ctx):
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.regression
 def test_small_parameter_update_in_one_launch_is_bitwise_the_separate_launches(A, ctx):
     """adm_adam_step_small (probe modes, position corrections + drift guard, distances, affine matrices + identity pin, zero fill of
     the gradient accumulators: adorym/optimizers.py:1022-1083) against adm_adam_step / adm_center_rows / adm_d2d / zero fill one

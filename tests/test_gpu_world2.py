@@ -224,6 +224,7 @@ def test_world2_straddling_batches_use_one_counter(tmp_path):
 
 
 @pytest.mark.parametrize('run', ['immediate6', 'perangle', 'probe6'])
+@pytest.mark.regression
 def test_world2_two_part_gather_is_bitwise_the_plain_gather(tmp_path, run):
     """ADM_OVERLAP_GATHER=1: the planes the next minibatches read are broadcast from their owners, the rest of the
     all-gather is deferred to the side stream of the next minibatch.  With ADM_DEBUG_POISON=1 everything the contract calls
@@ -255,6 +256,7 @@ def test_world2_constraints_and_mask_on_shards(tmp_path):
 
 
 @pytest.mark.parametrize('reg', [False, True])
+@pytest.mark.regression
 def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg):
     """One angle, 6 positions, one global batch: the 2-rank update against the same arithmetic on ONE context -- per-rank
     gradient buffers (each with its own regulariser term: the R-fold weight of adorym/forward_model.py:138-139), summed in
@@ -269,6 +271,7 @@ def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg
 
 
 @pytest.mark.parametrize('run', ['immediate6_reg', 'immediate', 'perangle', 'probe6'])
+@pytest.mark.regression
 def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
     """ADM_RESTRICTED_EXCHANGE=1 (adorym_amd/dp.py, exchange_and_update(touched=...)): only the y-planes the GLOBAL batch touches
     are summed over the ranks -- each part onto the rank that owns it (adm_reduce) -- and the regulariser term, which every rank of

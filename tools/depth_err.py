@@ -1,5 +1,5 @@
 """fp32 drift at config 3's depth (P = 72, 256 slices) against the reference's fp64 results and its OWN fp32 errors (golden F17):
-the body of tests/test_gpu_round3.py::test_depth_256_against_the_references_own_fp32_error as a tool, for A/B runs of kernel
+the body of tests/test_gpu_variants.py::test_depth_256_against_the_references_own_fp32_error as a tool, for A/B runs of kernel
 variants.  ADM_LIB_PATH=adorym_amd/libadm_X.so python tools/depth_err.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
