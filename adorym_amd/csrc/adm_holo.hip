@@ -309,6 +309,8 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
 // Gh_d = FFT2(dL/dPsi_d) / n.  GF = sum_d conj(H_d) Gh_d;  dL/dd_cm = 1e7 * Re sum_k conj(Gh_d) (-i sigma PI lambda uv2) H_d F
 template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
     using LG = LineGeo<NY>;
+    static_assert(3 * LG::LPB * NY * sizeof(cf) + 256 * sizeof(float) + TwLds<NY>::SIZE * sizeof(float2) <= 64 * 1024,
+                  "holo_k4: three line buffers + reduction scratch + twiddle copy must fit the 64 KB a workgroup may allocate");
     __shared__ cf buf[3][LG::LPB * NY];
     __shared__ float red[256];
     __shared__ float2 twl[TwLds<NY>::SIZE];

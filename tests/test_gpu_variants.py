@@ -182,17 +182,21 @@ def test_reweighted_l1_real_imag_through_the_driver(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ depth 256 vs the reference's own fp32
-def test_depth_256_against_the_references_own_fp32_error(A, ctx):
+@pytest.mark.parametrize('generic', [False, True])
+def test_depth_256_against_the_references_own_fp32_error(A, ctx, generic):
     """Golden F17 holds the REFERENCE's fp64 results at config 3's depth (P = 72, 256 slices, far field) and the reference's OWN
     fp32-vs-fp64 errors on the same inputs (prediction 1.3e-5, loss 9.8e-5, gradient 6.4e-4): fp32 rounding of twiddles and transfer
     function is coherent from slice to slice, so ANY fp32 chain drifts linearly with depth.  The kernel must be within 2x of the
     reference's own errors.  Measured (round 4, dithered butterfly constants, adm_fft.h: fft_k_dithered): 1.00x / 0.82x / 0.93x;
-    with the nominal constants in every slice it was 2.11x / 2.40x / 2.31x (profiles/r04/r04d_*)."""
+    with the nominal constants in every slice it was 2.11x / 2.40x / 2.31x (profiles/r04/r04d_*).
+    generic=True: the any-size kernel (adm_ms_generic.hip) on the same inputs.  Its transforms are R-term sums over a twiddle TABLE
+    (every entry rounded to nearest on its own), not butterflies with the two irrational constants, so the dithering does not
+    apply to it; its drift at this depth is measured here under the same 2x bar: 0.98x / 0.89x / 0.94x (round 5)."""
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F17_depth256.npz'))
     d = cases.depth256_inputs()
     P = d['P']
     Y, X, S = d['obj'].shape[:3]
-    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), d['pos'], cases.ENERGY_EV, cases.PSIZE_CM)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), d['pos'], cases.ENERGY_EV, cases.PSIZE_CM, generic=generic)
     d_obj = ctx.array(d['obj'], np.float32)
     d_grad = ctx.zeros(d['obj'].shape)
     d_probe = ctx.array(np.stack([d['probe'].real, d['probe'].imag], -1)[None], np.float32)
@@ -203,11 +207,12 @@ def test_depth_256_against_the_references_own_fp32_error(A, ctx):
     e_pred = rel(eng.pred(), g['pred_64'])
     e_loss = abs(eng.loss() - float(g['loss_64'])) / float(g['loss_64'])
     e_grad = rel(d_grad.get()[::4, ::4, ::4], g['grad_64_sample'])
-    print('depth 256 vs reference fp64: pred %.2e (reference fp32 %.2e), loss %.2e (%.2e), grad %.2e (%.2e)'
+    bar = 2            # measured (round 5): tuned 1.00x / 0.82x / 0.93x, generic 0.98x / 0.89x / 0.94x of the reference's own fp32 errors
+    print('depth 256 (' + ('generic' if generic else 'tuned') + ' kernel) vs reference fp64: pred %.2e (reference fp32 %.2e), loss %.2e (%.2e), grad %.2e (%.2e)'
           % (e_pred, float(g['ref32_pred_err']), e_loss, float(g['ref32_loss_err']), e_grad, float(g['ref32_grad_sample_err'])))
-    assert e_pred <= 2 * float(g['ref32_pred_err'])
-    assert e_loss <= 2 * float(g['ref32_loss_err'])
-    assert e_grad <= 2 * float(g['ref32_grad_sample_err'])
+    assert e_pred <= bar * float(g['ref32_pred_err'])
+    assert e_loss <= bar * float(g['ref32_loss_err'])
+    assert e_grad <= bar * float(g['ref32_grad_sample_err'])
 
 
 @pytest.mark.parametrize('B', [300])
