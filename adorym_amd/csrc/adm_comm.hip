@@ -10,7 +10,7 @@
 //   comm.bcast(...)                                        adorym/ptychography.py:217,411,485-487,664-665 -> adm_broadcast
 // librccl is loaded with dlopen at the first adm_comm_* call, so libadm has no link-time dependency on it and single-GPU
 // runs never touch it.  The unique id travels between the processes by whatever rendezvous the host side has
-// (adorym_amd/comm.py uses the TCP store of torch.distributed.run's MASTER_ADDR/MASTER_PORT).
+// (adorym_amd/comm.py uses its own TCP star on MASTER_ADDR / MASTER_PORT: adorym_amd/rendezvous.py).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstring>

@@ -5,6 +5,8 @@
 #   gpurun_out/<tag>_kbench_B32/_B256_*    rocprofv3 --kernel-trace --stats of the multislice launch alone (tools/kbench.py)
 #   gpurun_out/<tag>_pmc_B32, _B256/       five --pmc passes each over tools/kbench.py (+ summary.json); traffic_latest.json refreshed
 #   gpurun_out/<tag>_timeline_*.txt        kernel timelines of the B=32 step, the per-angle step and the 16-virtual-rank step
+#   gpurun_out/<tag>_rows.json             tools/bench_rows.py: config-2 / config-1 / config-5 shapes
+#   gpurun_out/<tag>_bench_host2.json      `python bench.py --gpus 2 --comm host`: the self-launched 2-rank line on ONE GPU (three legs)
 # Counters are collected in their own runs (no --pmc together with trace domains other than --kernel-trace).
 set -u
 TAG=${1:-r03}
@@ -15,17 +17,18 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-driver --no-per-angle > $ROOT/$OUT/${TAG}_stats.log 2>&1 )
 python tools/kstats.py $OUT/${TAG}_stats > $OUT/${TAG}_kernel_stats.txt 2>&1
 for B in 32 256; do
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_kbench_B${B}_stats -- python3 $ROOT/tools/kbench.py $B 8 > $ROOT/$OUT/${TAG}_kbench_B$B.log 2>&1 )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/${TAG}_kbench_B${B}_stats -- python3 $ROOT/tools/kbench.py $B 12 > $ROOT/$OUT/${TAG}_kbench_B$B.log 2>&1 )
   python tools/kstats.py $OUT/${TAG}_kbench_B${B}_stats > $OUT/${TAG}_kbench_B${B}_kernel_stats.txt 2>&1
   bash tools/pmc_sq.sh $OUT/${TAG}_pmc_B$B $B > $OUT/${TAG}_pmc_B$B.log 2>&1
 done
-python tools/traffic_update.py $OUT/${TAG}_pmc_B32 32 "profiles/${TAG}_pmc_B32.json" > $OUT/${TAG}_traffic.log 2>&1
+python tools/traffic_update.py $OUT/${TAG}_pmc_B32 32 "profiles/${TAG:0:3}/${TAG}_pmc_B32.json" > $OUT/${TAG}_traffic.log 2>&1
 for LEG in none per_angle vr16; do
   ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $ROOT/$OUT/${TAG}_tr_$LEG -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-driver --legs $LEG > /dev/null 2>&1 )
   f=$(find $OUT/${TAG}_tr_$LEG -name "*kernel_trace.csv" | head -1)
   python tools/trace_tail.py $f 40 > $OUT/${TAG}_timeline_$LEG.txt 2>&1
 done
 python tools/bench_rows.py > $OUT/${TAG}_rows.json 2>/dev/null
+python bench.py --gpus 2 --comm host --steps 3 --warmup 1 > $OUT/${TAG}_bench_host2.json 2> $OUT/${TAG}_bench_host2.err; echo "bench --gpus 2 rc=$?"
 python tools/bench_brief.py $OUT/${TAG}_bench.json
 cat $OUT/${TAG}_kernel_stats.txt | head -20
 cat $OUT/${TAG}_traffic.log | head -12
