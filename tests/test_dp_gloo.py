@@ -372,3 +372,42 @@ def test_restricted_exchange_equals_full_exchange_world2():
         # same sums up to the order of two fp32 additions per element: Adam (lr 1e-4) turns that into <= a few 1e-10
         assert np.abs(restricted - full).max() <= 2e-3 * 1e-4, np.abs(restricted - full).max()
     assert np.array_equal(res[0][2], res[1][2])                  # replicas identical
+
+
+def test_restricted_exchange_on_one_local_rank_completes_the_buffer():
+    """exchange_and_update(touched=..., reg_shard=...) with ONE local rank (no communicator at all) used to take the
+    ordinary path and let Adam consume the undefined part of the gradient buffer.  The contract is the same at every rank count:
+    the buffer holds the data term on the touched planes only, the owner -- here the only rank -- completes it with the
+    regulariser term before the update."""
+    sys.path.insert(0, ROOT)
+    from adorym_amd.comm import LocalComm
+    from adorym_amd.dp import DataParallelObject
+    from oracle import adorym_oracle as O
+    shape = (6, 3, 4, 2)
+    n = int(np.prod(shape))
+    plane = n // shape[0]
+    x0 = (np.random.default_rng(5).standard_normal(n) * 1e-3).astype(np.float32)
+    reg = (np.random.default_rng(6).standard_normal(n) * 1e-3).astype(np.float32)
+    data = np.zeros(n, np.float32)
+    t0, t1 = 2 * plane, 5 * plane
+    data[t0:t1] = (np.random.default_rng(7).standard_normal(t1 - t0) * 1e-3).astype(np.float32)
+    st = DataParallelObject(NumpyOps(), LocalComm(), shape)
+    assert not st.dist
+    st.obj[:n] = x0
+    st.grad[:] = np.float32(np.nan)                  # whatever is outside [t0, t1) must not matter
+    st.grad[t0:t1] = data[t0:t1]
+    calls = []
+
+    def reg_shard(s_lo, s_hi, a_lo, a_hi):
+        calls.append((s_lo, s_hi, a_lo, a_hi))
+        idx = np.arange(s_lo, min(s_hi, n))
+        add = (idx >= a_lo) & (idx < a_hi)
+        st.grad[idx[add]] += reg[idx[add]]
+        st.grad[idx[~add]] = reg[idx[~add]]
+
+    st.exchange_and_update('adam', 0, {'step_size': 1e-4}, touched=(t0, t1), reg_shard=reg_shard)
+    assert calls == [(0, n, t0, t1)]
+    ref, _, _ = O.adam_step(x0, data + reg, np.zeros(n, np.float32), np.zeros(n, np.float32), 0, 1e-4)
+    assert np.all(np.isfinite(st.obj[:n])) and np.allclose(st.obj[:n], ref, rtol=1e-6, atol=1e-10)
+    with pytest.raises(ValueError):
+        st.exchange_and_update('adam', 1, {'step_size': 1e-4}, touched=(t0, t1))
