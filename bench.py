@@ -357,6 +357,8 @@ def main():
                          'communicator -- nothing that has never run on real multi-GPU hardware sits in front of the measurement; '
                          'auto = check the two-part gather bitwise against the plain one on the running job, time both, keep the '
                          'faster (an experiment: ask for it explicitly)')
+    ap.add_argument('--leg-timeout', type=int, default=int(os.environ.get('ADM_BENCH_LEG_TIMEOUT', '240')),
+                    help='N > 1: seconds a secondary leg may take before it is abandoned and the line is printed without it (0 = no watchdog)')
     ap.add_argument('--restricted-exchange', action='store_true',
                     help='N > 1 experiment: sum only the y-planes the global batch touches, each part onto its owner; the owners add '
                          'the regulariser term N-fold (DESIGN.md section 6; tests/test_gpu_world2.py).  Off by default.')
@@ -610,26 +612,10 @@ def main():
     dt, kern_ms, phases = timed_loop()
     loss_headline = loss_box[0]
 
-    # second leg with several ranks: the same loop with the footprint-restricted exchange (or, if that was asked for as the
-    # headline, with the full exchange), from the same initial state
-    other_leg = None
-    if use_dist and world > 1 and args.scaling == 'weak':
-        leg['restricted'] = not leg['restricted']
-        reset_state()
-        dt2, kern2, ph2 = timed_loop()
-        other_leg = {'restricted_exchange': leg['restricted'], 'value': B_global * args.steps / dt2, 'unit': 'probe-positions/s',
-                     'ms_per_step': 1e3 * dt2 / args.steps, 'phases_ms': phases_dict(kern2, ph2), 'loss_last': loss_box[0]}
-        leg['restricted'] = not leg['restricted']
     restricted = leg['restricted']
 
-    # secondary leg on EVERY rank count: update_scheme='per angle' -- all minibatches of an angle fused, ONE exchange per step.
-    # (N > 1: the same two collectives on the same communicator as the headline loop that has just run.)
-    per_angle = None
-    if not args.no_per_angle and 'per_angle' in args.legs.split(',') and args.scaling == 'weak':
-        k_angle = -(-n_pos // (B * world))
-        per_angle = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle, {'update_scheme': 'per angle'},
-                                        comm=comm if use_dist else None, rank=rank, world=world)
-
+    # ---- the headline is complete: assemble its line NOW, so that nothing a secondary leg does can lose it ----
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = B_global * args.steps / dt
@@ -657,12 +643,78 @@ def main():
                      'side_stream_communicator': getattr(comm, 'backend', '') == 'rccl' and os.environ.get('ADM_COMM_AUX', '1') == '1',
                      'gather': gather, 'restricted_exchange': restricted, 'note': comm_note},
         }
+
+    def emit(line):
+        # RCCL prints a banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
+
+    # Secondary legs of a multi-rank run use collectives (grouped reductions onto the owners) or shapes (one exchange per fused
+    # angle) that the headline loop did not: each runs under a watchdog on EVERY rank -- all ranks arm it at the same barrier --
+    # so that a leg which does not come back within --leg-timeout seconds costs that leg, not the line: rank 0 prints what it has
+    # and every rank leaves without tearing the communicator down.
+    import threading
+
+    class Watchdog(object):
+        def __init__(self, what):
+            self.what = what
+            self.t = None
+
+        def __enter__(self):
+            if use_dist and world > 1 and args.leg_timeout > 0:
+                comm.barrier()
+
+                def fire():
+                    if out is not None:
+                        out['comm']['note'] = ((out['comm']['note'] + '; ') if out['comm']['note'] else '') + \
+                            "leg '%s' did not finish within %d s and was abandoned" % (self.what, args.leg_timeout)
+                        emit(out)
+                    sys.stderr.write('bench.py: rank %d: leg %s timed out\n' % (rank, self.what))
+                    os._exit(0)
+                self.t = threading.Timer(args.leg_timeout, fire)
+                self.t.daemon = True
+                self.t.start()
+            return self
+
+        def __exit__(self, *exc):
+            if self.t is not None:
+                self.t.cancel()
+            return False
+
+    # secondary leg on EVERY rank count: update_scheme='per angle' -- all minibatches of an angle fused, ONE exchange per step.
+    # (N > 1: the same two collectives on the same communicator as the headline loop that has just run.)
+    per_angle = None
+    if not args.no_per_angle and 'per_angle' in args.legs.split(',') and args.scaling == 'weak':
+        k_angle = -(-n_pos // (B * world))
+        with Watchdog('per_angle'):
+            per_angle = fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, k_angle, {'update_scheme': 'per angle'},
+                                            comm=comm if use_dist else None, rank=rank, world=world)
+        if out is not None:
+            out['per_angle'] = per_angle
+
+    # last leg with several ranks: the headline loop again with the footprint-restricted exchange (or, if that was asked for as
+    # the headline, with the full exchange), from the same initial state
+    if use_dist and world > 1 and args.scaling == 'weak':
+        with Watchdog('immediate_restricted' if not leg['restricted'] else 'immediate_full_exchange'):
+            if os.environ.get('ADM_BENCH_TEST_HANG') == '1':        # test hook: this leg never comes back
+                time.sleep(10 ** 6)
+            leg['restricted'] = not leg['restricted']
+            reset_state()
+            dt2, kern2, ph2 = timed_loop()
+            other_leg = {'restricted_exchange': leg['restricted'], 'value': B_global * args.steps / dt2, 'unit': 'probe-positions/s',
+                         'ms_per_step': 1e3 * dt2 / args.steps, 'phases_ms': phases_dict(kern2, ph2), 'loss_last': loss_box[0]}
+            leg['restricted'] = not leg['restricted']
+        if out is not None:
+            out['immediate_restricted' if other_leg['restricted_exchange'] else 'immediate_full_exchange'] = other_leg
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
-        if other_leg is not None:
-            out['immediate_restricted' if other_leg['restricted_exchange'] else 'immediate_full_exchange'] = other_leg
-        if per_angle is not None:
-            out['per_angle'] = per_angle
         if world == 1 and not args.no_per_angle:
             legs = args.legs.split(',')
             for R in (8, 16):
@@ -677,19 +729,10 @@ def main():
             out['driver']['engine_loop_ms_per_step'] = ms_per_step
             out['driver']['ratio_to_engine_loop'] = out['driver']['ms_per_step_mean'] / ms_per_step
             out['driver_per_angle'] = driver_measure(cfg, 16, 'per angle')
-    else:
-        out = None
     if use_dist:
         comm.close()            # RCCL may print its banner here; the JSON line goes last
     if out is not None:
-        # RCCL prints a banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == '__main__':
