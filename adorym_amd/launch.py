@@ -67,19 +67,24 @@ def run(n, argv, grace_s=20.0, out=None, err=None):
     threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
     [t.start() for t in threads]
     rc, t_fail = 0, None
-    while True:
-        codes = [p.poll() for p in procs]
-        bad = [c for c in codes if c not in (None, 0)]
-        if bad and rc == 0:
-            rc, t_fail = bad[0], time.time()
-        if all(c is not None for c in codes):
-            break
-        if t_fail is not None and time.time() - t_fail > grace_s:
-            for p in procs:             # exactly the processes started above
-                if p.poll() is None:
-                    p.terminate()
-            t_fail = time.time() + 1e9
-        time.sleep(0.05)
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and rc == 0:
+                rc, t_fail = bad[0], time.time()
+            if all(c is not None for c in codes):
+                break
+            if t_fail is not None and time.time() - t_fail > grace_s:
+                for p in procs:             # exactly the processes started above
+                    if p.poll() is None:
+                        p.terminate()
+                t_fail = time.time() + 1e9
+            time.sleep(0.05)
+    finally:
+        for p in procs:                     # the launcher is interrupted or dies: its ranks must not outlive it
+            if p.poll() is None:
+                p.terminate()
     [t.join(5) for t in threads]
     return rc, lines0
 
