@@ -17,6 +17,7 @@
 #include <cstring>
 #include "adm_common.h"
 #include "adm_fft.h"
+#include "adm_ms_math.h"
 
 struct adm_holo {
     adm_ctx* ctx;
@@ -60,12 +61,25 @@ __device__ __forceinline__ void stockham_pass(const cf* __restrict__ src, cf* __
     }
 }
 
+// The TPR threads of a line are one wave or part of one when TPR <= 64 (lines of up to 512 points): LDS operations of a wave
+// execute in order, so ordering the compiler is all a line-local exchange needs -- no workgroup barrier between the passes of a
+// transform, the four lines of a block run at their own pace.  Longer lines span two or four waves and keep the barrier.
+template <int TPR> __device__ __forceinline__ void line_sync() {
+    if (TPR <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int N, int NS, bool INV, int TPR> struct Passes {
     static __device__ __forceinline__ int run(cf* a, cf* b, const float2* tw, int t) {
         constexpr int REM = N / NS;
         constexpr int R = REM >= 8 ? 8 : REM;
         stockham_pass<N, NS, R, INV, TPR>(a, b, tw, t);
-        __syncthreads();
+        line_sync<TPR>();
         return 1 + Passes<N, NS * R, INV, TPR>::run(b, a, tw, t);
     }
 };
@@ -119,7 +133,7 @@ __device__ __forceinline__ cf holo_h(float uv2, float dist_cm, float c1) {
     // -sigma*PI*lambda (c1, rounded once on the host) * dist_nm * (u^2+v^2), every product in fp32 like the reference
     const float arg = (c1 * (dist_cm * 1e7f)) * uv2;
     float sn, cs;
-    sincosf(arg, &sn, &cs);
+    sincos_fast(arg, sn, cs);       // branch-free, ~1 ulp (adm_ms_math.h); ocml's sincosf was a third of the y-stage kernels' instructions
     return make_float2(cs, sn);
 }
 // torch's affine_grid base coordinate (see oracle/adorym_oracle.py::affine_sample for the derivation)
@@ -216,7 +230,7 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k2(HoloArgs A) {
         for (int k = t; k < NY; k += LG::TPR) A.Ft[(size_t)kx * NY + k] = F[k];
     const float dist = A.dists[d];
     for (int k = t; k < NY; k += LG::TPR) p[k] = ok ? cmul(F[k], holo_h(A.uv2t[(size_t)kx * NY + k], dist, A.c1)) : make_float2(0.f, 0.f);
-    __syncthreads();
+    line_sync<LG::TPR>();
     const cf* res = line_fft<NY, true>(p, F, tw, t);      // (F's buffer is free once p is filled)
     if (ok)
         for (int y = t; y < NY; y += LG::TPR) A.Wq[((size_t)d * NY + y) * A.nx + kx] = res[y];
@@ -300,7 +314,7 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
         if (ok && t == 0) A.part3[(size_t)job * 8] = ls;
     }
     if (!GRAD) return;
-    __syncthreads();
+    line_sync<LG::TPR>();
     const cf* G = line_fft<NX, false>(oth, res, tw, t);
     if (ok)
         for (int k = t; k < NX; k += LG::TPR) A.T3[((size_t)d * NX + k) * ny + y] = G[k];
@@ -325,7 +339,8 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
         const int d = d0 + ll;
         const bool ok = d < A.nd;
         for (int j = t; j < NY; j += LG::TPR) a[j] = ok ? A.T3[((size_t)d * A.nx + kx) * NY + j] : make_float2(0.f, 0.f);
-        __syncthreads();
+        if (d0 == 0) __syncthreads();                 // (also orders the twiddle copy of stage_twiddles before the first pass)
+        else line_sync<LG::TPR>();
         const cf* res = line_fft<NY, false>(a, b, tw, t);
         const float dist = ok ? A.dists[d] : 0.f;
         float acc = 0.f;
@@ -344,10 +359,11 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
             const float sd = line_sum<LG::TPR>(acc, red);
             if (ok && t == 0) A.part4[(size_t)d * A.nx + kx] = sd;
         }
-        __syncthreads();                              // a / b are refilled by the next round of distances
+        line_sync<LG::TPR>();                         // a / b are refilled by the next round of distances
     }
     // the slots' sums over their distances, added in slot order into slot 0, which transforms back
     if (LG::LPB > 1) {
+        __syncthreads();                              // every slot's GF is complete
         for (int k = threadIdx.x; k < NY; k += 256) {
             cf sum = buf[2][k];
 #pragma unroll
@@ -356,7 +372,7 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
         }
         __syncthreads();
     }
-    const cf* gy = line_fft<NY, true>(GF, a, tw, t);      // (every slot runs it -- the barriers inside are the block's -- slot 0's counts)
+    const cf* gy = line_fft<NY, true>(GF, a, tw, t);      // (every slot runs it on its own buffers; slot 0's counts)
     if (ll == 0)
         for (int y = t; y < NY; y += LG::TPR) A.T4[(size_t)y * A.nx + kx] = gy[y];
 }
