@@ -92,3 +92,17 @@ def test_bench_under_a_launcher_does_not_relaunch(monkeypatch):
     with pytest.raises(SystemExit) as ex:
         bench.main()
     assert 'WORLD_SIZE=4' in str(ex.value.code)
+
+
+def test_a_failing_rank_does_not_leave_the_others_waiting_for_ever(tmp_path):
+    """Rank 1 dies before the rendezvous; rank 0 would wait in it for minutes.  The launcher gives the survivors a grace period,
+    terminates exactly the processes it started and returns the failing rank's code."""
+    import time
+    from adorym_amd import launch
+    script = tmp_path / 'rank.py'
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(9)\n"
+                      "time.sleep(600)\n")
+    t0 = time.time()
+    rc, _ = launch.run(2, [sys.executable, str(script)], grace_s=1.0, out=io.StringIO(), err=io.StringIO())
+    assert rc == 9 and time.time() - t0 < 30

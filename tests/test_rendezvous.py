@@ -136,3 +136,13 @@ def test_product_comm_module_imports_no_torch():
     b = cls.index('class RcclComm')
     lo, hi = cls.count('\n', 0, a) + 1, cls.count('\n', 0, b) + 1
     assert hits and all(n == 'comm.py' and lo <= l < hi for n, l in hits), hits
+
+
+def test_missing_rank_is_a_clean_error_not_a_hang():
+    """Rank 0 of a two-rank job whose peer never shows up: a RuntimeError after ADM_RDV_TIMEOUT, naming what is missing."""
+    sys.path.insert(0, ROOT)
+    from adorym_amd.rendezvous import TcpGroup
+    with pytest.raises(RuntimeError, match='only 1 of 2 ranks connected'):
+        TcpGroup(0, 2, '127.0.0.1', _free_port(), job='lonely', exact_port=True, timeout=1.5)
+    with pytest.raises(RuntimeError, match='could not reach rank 0'):
+        TcpGroup(1, 2, '127.0.0.1', _free_port(), job='lonely', exact_port=True, timeout=1.5)
