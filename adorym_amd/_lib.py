@@ -10,6 +10,8 @@ ADM_OK, ADM_ERR_INVALID, ADM_ERR_HIP, ADM_ERR_UNSUPPORTED, ADM_ERR_NOMEM = 0, -1
 DET_NONE, DET_FARFIELD, DET_FRESNEL = 0, 1, 2
 LOSS_LSQ, LOSS_POISSON = 0, 1
 FLAG_NONNEG, FLAG_ZERO_CH0, FLAG_ZERO_CH1 = 1, 2, 4
+OPT_ADAM, OPT_GD, OPT_MOMENTUM = 0, 1, 2
+P2P_HANDLE_BYTES, P2P_MAX_RANKS = 64, 16
 
 
 class PlanDesc(C.Structure):
@@ -79,6 +81,20 @@ SIGNATURES = {
     'adm_reduce': (_I, [_VP, _VP, _SZ, _I]),
     'adm_comm_group_start': (_I, [_VP]),
     'adm_comm_group_end': (_I, [_VP]),
+    'adm_p2p_create': (_I, [_VP, _I, _I, _SZ]),
+    'adm_p2p_local': (_I, [_VP, _I, C.POINTER(_VP)]),
+    'adm_p2p_export': (_I, [_VP, _VP, _VP]),
+    'adm_p2p_open': (_I, [_VP, _VP, C.POINTER(_VP)]),
+    'adm_p2p_close': (_I, [_VP, _VP]),
+    'adm_p2p_connect': (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    'adm_p2p_bind_object': (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), _SZ]),
+    'adm_p2p_rank': (_I, [_VP]),
+    'adm_p2p_size': (_I, [_VP]),
+    'adm_p2p_update': (_I, [_VP, _I, _VP, _VP, _SZ, _SZ, _SZ, _SZ, _I, _D, _D, _D, _D, _I, _VP]),
+    'adm_p2p_all_reduce': (_I, [_VP, _VP, _SZ]),
+    'adm_p2p_barrier': (_I, [_VP]),
+    'adm_p2p_status': (_I, [_VP]),
+    'adm_p2p_destroy': (_I, [_VP]),
     'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
     'adm_plan_destroy': (_I, [_VP]),
     'adm_plan_set_detector_mask': (_I, [_VP, _VP]),

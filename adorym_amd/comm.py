@@ -18,10 +18,12 @@ Backends (all expose the same methods to adorym_amd/dp.py and the driver):
                        collective is staged through host memory (adm_d2h -> TCP star -> adm_h2d).  It exists so that the PRODUCT
                        -- driver, HIP kernels, sharded optimiser, two-part gather -- can run at world size > 1 with several
                        ranks on ONE GPU, where RCCL refuses duplicate devices.  Slow by construction; never the default;
-  TorchComm            NOT part of the product path -- the only class here that imports torch.  ('gloo'): host buffers, for CPU
-                       tests of the sharding logic with a NumPy stand-in for the kernels; ('nccl'): the same collectives
-                       through torch.distributed tensors, the fallback bench.py agrees on, on all ranks together, if the
-                       C-ABI communicator cannot come up (such a line says so in `comm.note`).
+  P2PComm              direct all-pairs exchange without RCCL (ADM_COMM=p2p): every rank maps the object and gradient buffers of
+                       its peers (IPC handles handed over the TCP star) and ONE kernel per update sums the ranks' gradients of
+                       the owned shard in rank order, applies the optimiser in registers and writes every replica
+                       (adm_p2p_update: reduce-scatter + optimiser + all-gather in one pass); ranks are ordered against each
+                       other by device-side flags, no host synchronisation.  Several ranks may share one GPU;
+(No class here imports torch: the torch.distributed stand-in the CPU sharding tests use lives in tests/torch_comm.py.)
 """
 import os
 import numpy as np
@@ -57,114 +59,6 @@ def shard_bounds(n, size, rank, align=2):
     lo = min(rank * per, n)
     hi = min(lo + per, n)
     return lo, hi
-
-
-class TorchComm(object):
-    """torch.distributed process group (env:// rendezvous: RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
-
-    def __init__(self, backend='nccl', device_index=None, init=True):
-        import torch
-        import torch.distributed as dist
-        self.torch = torch
-        self.dist = dist
-        self.backend = backend
-        if init and not dist.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29511')
-            os.environ.setdefault('RANK', '0')
-            os.environ.setdefault('WORLD_SIZE', '1')
-            kw = {}
-            if backend == 'nccl':
-                if device_index is None:
-                    device_index = int(os.environ.get('LOCAL_RANK', '0'))
-                torch.cuda.set_device(device_index)
-                try:
-                    kw['device_id'] = torch.device('cuda', device_index)
-                except Exception:
-                    pass
-            dist.init_process_group(backend=backend, **kw)
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
-        self.device_index = device_index
-        self.device = torch.device('cuda', device_index) if backend == 'nccl' else torch.device('cpu')
-        self.stream = None
-        if backend == 'nccl':
-            # a dedicated, explicit stream shared by libadm and torch: collectives are ordered against the
-            # CURRENT torch stream, and the legacy null stream would not order against a non-blocking one
-            self.stream = torch.cuda.Stream(device=self.device)
-            torch.cuda.set_stream(self.stream)
-
-    # ---- buffers the collectives touch -------------------------------------------------
-    def alloc(self, n, dtype=None):
-        """A flat fp32 torch tensor on the communication device (zero-filled)."""
-        return self.torch.zeros(int(n), dtype=dtype or self.torch.float32, device=self.device)
-
-    def stream_handle(self):
-        """hipStream_t of torch's current stream, for adm_ctx_create(): libadm kernels and the
-        collectives are then ordered on one stream."""
-        return int(self.stream.cuda_stream) if self.backend == 'nccl' else None
-
-    # ---- collectives ---------------------------------------------------------------------
-    def barrier(self):
-        self.dist.barrier()
-
-    def shard_range(self, n):
-        return shard_bounds(n, self.size, self.rank)
-
-    def reduce_scatter_sum(self, full, shard_out):
-        """shard_out[:] = sum over ranks of full[lo:hi] (lo, hi = this rank's shard).  Requires
-        n == size * len(shard_out)."""
-        if self.backend == 'nccl':
-            self.dist.reduce_scatter_tensor(shard_out, full, op=self.dist.ReduceOp.SUM)
-        else:   # gloo has no reduce_scatter_tensor: all_reduce then slice (CPU tests only)
-            tmp = full.clone()
-            self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM)
-            lo = self.rank * shard_out.numel()
-            shard_out.copy_(tmp[lo:lo + shard_out.numel()])
-
-    def all_gather(self, full_out, shard_in):
-        if self.backend == 'nccl':
-            self.dist.all_gather_into_tensor(full_out, shard_in)
-        else:
-            parts = [self.torch.empty_like(shard_in) for _ in range(self.size)]
-            self.dist.all_gather(parts, shard_in)
-            full_out.copy_(self.torch.cat(parts))
-
-    def all_reduce_sum(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t
-
-    def reduce_tensor(self, t, root):
-        """t (a tensor or a view of one) of rank ``root`` = sum over ranks of their ``t``, in place."""
-        self.dist.reduce(t, dst=int(root), op=self.dist.ReduceOp.SUM)
-        return t
-
-    def all_reduce_device(self, dev):
-        """In-place sum over ranks of a libadm device array, through a torch tensor (host bounce: this backend has no
-        view of libadm's memory; RcclComm reduces in place on the device)."""
-        g = self.torch.from_numpy(dev.get()).to(self.device)
-        self.dist.all_reduce(g, op=self.dist.ReduceOp.SUM)
-        dev.set(g.cpu().numpy())
-        return dev
-
-    def max_over_ranks(self, value):
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def sum_over_ranks(self, value):
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
-
-    def bcast_object(self, obj, root=0):
-        lst = [obj]
-        self.dist.broadcast_object_list(lst, src=root)
-        return lst[0]
-
-    def close(self):
-        if self.dist.is_initialized():
-            self.dist.destroy_process_group()
 
 
 class RcclComm(object):
@@ -354,6 +248,167 @@ class HostStagedComm(RcclComm):
             self.group_.close()
 
 
+class P2PComm(RcclComm):
+    """Direct all-pairs exchange through IPC-mapped peer buffers (adm_p2p.hip); ADM_COMM=p2p.  Control plane = the TCP star
+    (it carries the 64-byte IPC handles once, at attach / bind time); data plane = the ranks' own kernels reading and writing each
+    other's device buffers, ordered by device-side flags.  The exchange of adorym/ptychography.py:1113-1129 is ONE call:
+    ``fused_update`` (DataParallelObject uses it instead of reduce_scatter -> optimiser -> all_gather).  Sums are taken in
+    rank order: the result equals HostStagedComm's and a serial sum of the ranks' buffers bit for bit.  Ranks may share a GPU
+    (device index = LOCAL_RANK modulo the number of devices)."""
+    backend = 'p2p'
+
+    def __init__(self, device_index=None, group=None):
+        RcclComm.__init__(self, device_index=device_index, group=group)
+        if device_index is None:
+            self.device_index = self.device_index % max(1, device_count())
+        self._mapped = []           # peer allocations this rank has opened (closed in close())
+        self.bound = None
+
+    def _exchange_handles(self, arrays):
+        """arrays: this rank's device pointers.  Returns, per array, the list over ranks of pointers valid in THIS process
+        (own entry = own pointer).  Collective; either every rank returns or every rank raises."""
+        import ctypes as C
+        from ._lib import check, P2P_HANDLE_BYTES
+        lib, h = self.ctx.lib, self.ctx.handle
+        mine = np.zeros((len(arrays), P2P_HANDLE_BYTES), np.uint8)
+        ok, why = 1.0, ''
+        try:
+            for k, ptr in enumerate(arrays):
+                buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+                check(lib.adm_p2p_export(h, C.c_void_p(ptr), buf))
+                mine[k] = np.frombuffer(buf.raw, np.uint8)
+        except Exception as e:
+            ok, why = 0.0, repr(e)
+        if self.sum_over_ranks(ok) < self.size:
+            raise RuntimeError('peer-to-peer transport: exporting the IPC handles failed on some rank (this rank: %s)' % (why or 'ok'))
+        everyone = self.group_.all_gather(mine.reshape(1, -1)).reshape(self.size, len(arrays), P2P_HANDLE_BYTES)
+        out = [[None] * self.size for _ in arrays]
+        try:
+            for q in range(self.size):
+                for k, ptr in enumerate(arrays):
+                    if q == self.rank:
+                        out[k][q] = int(ptr)
+                        continue
+                    dp = C.c_void_p()
+                    check(lib.adm_p2p_open(h, C.create_string_buffer(everyone[q, k].tobytes(), P2P_HANDLE_BYTES), C.byref(dp)))
+                    self._mapped.append(dp.value)
+                    out[k][q] = dp.value
+        except Exception as e:
+            ok, why = 0.0, repr(e)
+        if self.sum_over_ranks(ok) < self.size:
+            raise RuntimeError('peer-to-peer transport: mapping the peers\' buffers failed on some rank (this rank: %s)' % (why or 'ok'))
+        return out
+
+    @staticmethod
+    def _ptr_array(ptrs):
+        import ctypes as C
+        return (C.c_void_p * len(ptrs))(*[C.c_void_p(p_) for p_ in ptrs])
+
+    def attach(self, ctx):
+        """Flag block + mailbox of this rank, exchanged with and mapped by every peer (collective)."""
+        import ctypes as C
+        from ._lib import check, P2P_MAX_RANKS
+        if self.ctx is ctx:
+            return self
+        if self.size > P2P_MAX_RANKS:
+            raise RuntimeError('peer-to-peer transport: at most %d ranks' % P2P_MAX_RANKS)
+        self.ctx = ctx
+        ok, why = 1.0, ''
+        local = []
+        try:
+            check(ctx.lib.adm_p2p_create(ctx.handle, self.rank, self.size, int(os.environ.get('ADM_P2P_MAILBOX_BYTES', '0'))))
+            for which in (0, 1):
+                dp = C.c_void_p()
+                check(ctx.lib.adm_p2p_local(ctx.handle, which, C.byref(dp)))
+                local.append(dp.value)
+        except Exception as e:
+            ok, why = 0.0, repr(e)
+        if self.sum_over_ranks(ok) < self.size:
+            self.ctx = None
+            ctx.lib.adm_p2p_destroy(ctx.handle)
+            raise RuntimeError('peer-to-peer transport could not be created on every rank (this rank: %s)' % (why or 'ok'))
+        if self.size > 1:
+            flags, mail = self._exchange_handles(local)
+            check(ctx.lib.adm_p2p_connect(ctx.handle, self._ptr_array(flags), self._ptr_array(mail)))
+        self.group_.barrier()       # nobody signals into a flag block before every rank has zeroed and published its own
+        return self
+
+    def bind_object(self, obj, grad, n):
+        """The object and gradient buffers of every rank, mapped here (collective; DataParallelObject calls it once)."""
+        from ._lib import check
+        if self.size > 1:
+            xs, gs = self._exchange_handles([obj.ptr, grad.ptr])
+        else:
+            xs, gs = [obj.ptr], [grad.ptr]
+        check(self.ctx.lib.adm_p2p_bind_object(self.ctx.handle, self._ptr_array(xs), self._ptr_array(gs), int(n)))
+        self.bound = (obj, grad)
+
+    # ---- device collectives (asynchronous on the context's stream) ----
+    def fused_update(self, kind, m, v, lo, hi, sum_lo, sum_hi, i_batch, step_size, b1, b2, eps, flags, mask):
+        """adm_p2p_update on the bound buffers: rank-order sum of the ranks' gradients on [lo, hi) n [sum_lo, sum_hi) (own
+        gradient elsewhere), optimiser + constraints, result written to every replica."""
+        from ._lib import check
+        check(self.ctx.lib.adm_p2p_update(self.ctx.handle, int(kind), m.ptr if m is not None else None, v.ptr if v is not None else None,
+                                          int(lo), int(hi), int(sum_lo), int(sum_hi), int(i_batch), float(step_size), float(b1), float(b2),
+                                          float(eps), int(flags), mask.ptr if mask is not None else None))
+
+    def all_reduce_device(self, dev):
+        from ._lib import check
+        check(self.ctx.lib.adm_p2p_all_reduce(self.ctx.handle, dev.ptr, dev.size))
+        return dev
+
+    def device_barrier(self):
+        from ._lib import check
+        check(self.ctx.lib.adm_p2p_barrier(self.ctx.handle))
+
+    def check_status(self):
+        """Raises if a wait on a peer timed out (the update kernels after it were skipped)."""
+        from ._lib import check
+        if self.ctx is not None:
+            check(self.ctx.lib.adm_p2p_status(self.ctx.handle))
+
+    def reduce_scatter_sum(self, full, shard_out):
+        raise NotImplementedError('P2PComm: the exchange is fused with the update (fused_update)')
+
+    all_gather = broadcast = reduce = reduce_scatter_sum
+
+    def group(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def barrier(self):
+        if self.ctx is not None:
+            self.ctx.sync()
+            self.check_status()
+        self.group_.barrier()
+
+    def close(self, keep_group=False):
+        if self.ctx is not None:
+            ctx = self.ctx
+            ctx.sync()
+            err = None
+            try:
+                self.check_status()
+            except Exception as e:      # still tear down in step with the peers
+                err = e
+            try:
+                self.group_.barrier()       # every rank has finished using its peers' buffers
+                for ptr in self._mapped:
+                    ctx.lib.adm_p2p_close(ctx.handle, ptr)
+                self._mapped = []
+                self.group_.barrier()       # every mapping of this rank's buffers is gone: they may be freed
+            except Exception:
+                pass
+            ctx.lib.adm_p2p_destroy(ctx.handle)
+            self.ctx = None
+            self.bound = None
+            if err is not None and not keep_group:
+                self.group_.close()
+                raise err
+        if not keep_group:
+            self.group_.close()
+
+
 def device_count():
     """Number of GPUs libadm sees (adm_device_count: hipGetDeviceCount, no context is created)."""
     from . import _lib
@@ -362,12 +417,14 @@ def device_count():
 
 def from_env():
     """LocalComm unless launched with WORLD_SIZE > 1 (torch.distributed.run, an mpirun wrapper, bench.py); then ADM_COMM selects the data plane:
-    'rccl' (default: RCCL through the C ABI), 'torch' (torch.distributed's nccl backend), 'host' (validation: staged
-    through host memory, several ranks may share a GPU)."""
+    'rccl' (default: RCCL through the C ABI), 'p2p' (direct all-pairs exchange through IPC-mapped peer buffers, fused with
+    the update; several ranks may share a GPU), 'host' (validation: staged through host memory, several ranks may share a GPU)."""
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         kind = os.environ.get('ADM_COMM', 'rccl')
-        if kind == 'torch':
-            return TorchComm('nccl')
+        if kind == 'p2p':
+            return P2PComm()
+        if kind not in ('rccl', 'host'):
+            raise ValueError("ADM_COMM must be 'rccl', 'p2p' or 'host' (got '%s')" % kind)
         if kind == 'host':
             return HostStagedComm(device_index=int(os.environ.get('LOCAL_RANK', '0')) % max(1, device_count()))
         return RcclComm()

@@ -48,6 +48,7 @@ extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
     c->comm_aux = nullptr;
     c->comm_rank = 0;
     c->comm_size = 1;
+    c->p2p = nullptr;
     hipError_t e2 = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -90,6 +91,7 @@ extern "C" int adm_ctx_destroy(adm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->main_stream);
     (void)adm_comm_destroy(ctx);
+    (void)adm_p2p_destroy(ctx);
     (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_join);

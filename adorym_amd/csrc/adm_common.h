@@ -20,6 +20,7 @@ struct adm_ctx {
     void* comm;              // ncclComm_t of adm_comm_init (adm_comm.hip) or nullptr
     void* comm_aux;          // ncclComm_t of adm_comm_init_aux: collectives queued on the side stream, or nullptr
     int comm_rank, comm_size;
+    void* p2p;               // peer-to-peer group of adm_p2p_create (adm_p2p.hip) or nullptr
 };
 
 struct adm_plan {

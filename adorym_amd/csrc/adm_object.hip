@@ -5,6 +5,7 @@
 #include <cstring>
 #include <hip/hip_fp16.h>
 #include "adm_common.h"
+#include "adm_optim.h"
 #include "adm_ms_math.h"
 
 namespace adm {
@@ -754,37 +755,6 @@ __global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x,
 // followed by the constraints of adorym/ptychography.py:1135-1158 and the support mask
 // (adorym/array_ops.py:239-251).  Same operation order as the reference, fp32.
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ float constrain(float xv, size_t i, int flags, const float* mask) {
-    if ((flags & ADM_FLAG_NONNEG) && xv < 0.f) xv = 0.f;
-    if ((flags & ADM_FLAG_ZERO_CH0) && !(i & 1)) xv *= 0.f;
-    if ((flags & ADM_FLAG_ZERO_CH1) && (i & 1)) xv *= 0.f;
-    if (mask) xv *= mask[i >> 1];
-    return xv;
-}
-
-struct AdamScalars {
-    float step, b1, b2, omb1, omb2, q1, q2, eps;
-    int flags;
-    const float* mask;
-};
-
-// one element of AdamOptimizer.apply_gradient + constraints; shared by adam_kernel and small_adam_kernel, with contraction off
-// so that both produce the same bits
-__device__ __forceinline__ float adam_value(float xv, float gv, float m_in, float v_in, const AdamScalars& a, size_t i, float& m_out,
-                                            float& v_out) {
-#pragma clang fp contract(off)
-    float mv = a.b1 * m_in;
-    mv = mv + a.omb1 * gv;
-    float vv = a.b2 * v_in;
-    vv = vv + a.omb2 * (gv * gv);
-    const float mhat = mv / a.q1;
-    const float vhat = vv / a.q2;
-    const float d = a.step * mhat / (sqrtf(vhat) + a.eps);
-    m_out = mv;
-    v_out = vv;
-    return constrain(xv - d, i, a.flags, a.mask);
-}
-
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, size_t lo, size_t hi, AdamScalars a) {
     for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
@@ -836,19 +806,17 @@ __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamSca
 
 __global__ __launch_bounds__(256) void gd_kernel(float* __restrict__ x, const float* __restrict__ g, size_t lo, size_t hi,
                                                  float step, int flags, const float* __restrict__ mask) {
-#pragma clang fp contract(off)
     for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x)
-        x[i] = constrain(x[i] - step * g[i], i, flags, mask);
+        x[i] = gd_value(x[i], g[i], step, i, flags, mask);
 }
 
 __global__ __launch_bounds__(256) void momentum_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ v,
                                                        size_t lo, size_t hi, float step, float gamma, int flags,
                                                        const float* __restrict__ mask) {
-#pragma clang fp contract(off)
     for (size_t i = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (size_t)gridDim.x * blockDim.x) {
-        const float vv = gamma * v[i] + step * g[i];
+        float vv;
+        x[i] = momentum_value(x[i], g[i], v[i], step, gamma, i, flags, mask, vv);
         v[i] = vv;
-        x[i] = constrain(x[i] - vv, i, flags, mask);
     }
 }
 
@@ -1253,18 +1221,6 @@ extern "C" int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols
     hipLaunchKernelGGL(center_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, x, n_rows, n_cols);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
-}
-
-static AdamScalars adam_scalars(int i_batch, double step_size, double b1, double b2, double eps, int flags, const float* mask) {
-    // the reference evaluates the scalars in Python doubles and torch casts them to fp32 at the op
-    AdamScalars a;
-    double p1 = 1.0, p2 = 1.0;
-    for (int k = 0; k < i_batch + 1; ++k) { p1 *= b1; p2 *= b2; }
-    a.step = (float)step_size; a.b1 = (float)b1; a.b2 = (float)b2;
-    a.omb1 = (float)(1.0 - b1); a.omb2 = (float)(1.0 - b2);
-    a.q1 = (float)(1.0 - p1); a.q2 = (float)(1.0 - p2);
-    a.eps = (float)eps; a.flags = flags; a.mask = mask;
-    return a;
 }
 
 extern "C" int adm_adam_step(adm_ctx* ctx, float* x, const float* g, float* m, float* v, size_t lo, size_t hi, int i_batch,

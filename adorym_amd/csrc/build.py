@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, 'libadm.so')
-SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip', 'adm_ms_generic.hip', 'adm_rotcsr.hip', 'adm_comm.hip', 'adm_holo.hip']
-HDRS = ['adm_common.h', 'adm_fft.h', 'adm_ms_math.h', os.path.join('..', '..', 'include', 'adm.h')]
+SRCS = ['adm_api.hip', 'adm_object.hip', 'adm_multislice.hip', 'adm_ms_generic.hip', 'adm_rotcsr.hip', 'adm_comm.hip', 'adm_p2p.hip', 'adm_holo.hip']
+HDRS = ['adm_common.h', 'adm_fft.h', 'adm_ms_math.h', 'adm_optim.h', os.path.join('..', '..', 'include', 'adm.h')]
 
 
 def _hipcc():

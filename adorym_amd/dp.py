@@ -84,10 +84,15 @@ class DataParallelObject(object):
         # RcclComm (and its host-staged validation twin) work on libadm's own buffers, in place: the reduced shard lands in
         # its slot of the gradient buffer and the updated shard is gathered from its slot of the object (no staging copies,
         # no torch tensors)
-        self.inplace = self.dist and getattr(comm, 'backend', '') in ('rccl', 'host')
+        self.inplace = self.dist and getattr(comm, 'backend', '') in ('rccl', 'host', 'p2p')
+        # P2PComm: the ranks read each other's gradient buffers and write each other's objects directly; reduce-scatter,
+        # optimiser and all-gather are ONE kernel per update (adm_p2p_update)
+        self.p2p = self.dist and getattr(comm, 'backend', '') == 'p2p'
         if self.inplace:
             self.obj = ops.alloc(self.n_pad)
             self.grad = ops.alloc(self.n_pad)
+            if self.p2p:
+                comm.bind_object(self.obj, self.grad, self.n_pad)
         elif self.dist:
             t_obj, t_grad = comm.alloc(self.n_pad), comm.alloc(self.n_pad)
             self.t_obj, self.t_grad = t_obj, t_grad
@@ -157,6 +162,8 @@ class DataParallelObject(object):
         reference, hence R-fold -- inside [lo, hi) and WRITES it elsewhere on the shard.  Same sums as the full exchange up to
         the order of two fp32 additions per element."""
         self.finish_update()
+        if self.p2p:
+            return self._exchange_and_update_p2p(optimizer, i_batch, options, flags, mask, touched, reg_shard)
         self._tic('reduce_scatter')
         if touched is not None:
             if reg_shard is None:
@@ -211,6 +218,37 @@ class DataParallelObject(object):
             self.ops.copy(self.xshard, 0, self.obj, self.lo, self.per)
             self.comm.all_gather(self.t_obj, self.t_xshard)
         self._toc('first_gather')
+
+    def _exchange_and_update_p2p(self, optimizer, i_batch, options, flags, mask, touched, reg_shard):
+        """The whole exchange as one kernel per rank (P2PComm.fused_update): for the owned shard, the ranks' gradient buffers are
+        summed in rank order straight from the peers' memory, the optimiser runs in registers and the new values are written
+        into every replica; the ranks' streams are barriered on entry and exit, so nothing is deferred (``first`` is moot).
+        ``touched``: the buffers hold every rank's data term on [t_lo, t_hi) only, so only that range is summed over the ranks;
+        the owner has completed ITS buffer on its shard beforehand (reg_shard: R-fold regulariser term added inside the range,
+        written outside), and that is all the kernel reads outside the range."""
+        kinds = {'adam': _lib.OPT_ADAM, 'gd': _lib.OPT_GD, 'momentum': _lib.OPT_MOMENTUM}
+        if optimizer not in kinds:
+            raise NotImplementedError("object optimizer '%s' is outside the accelerated path" % optimizer)
+        s_lo, s_hi = 0, self.n_pad
+        lo, hi = self.lo, max(self.lo, self.hi)
+        if touched is not None:
+            if reg_shard is None:
+                raise ValueError('exchange_and_update: touched= needs reg_shard=')
+            s_lo, s_hi = max(0, int(touched[0])), min(self.n, int(touched[1]))
+            self._tic('reduce_scatter')
+            reg_shard(self.lo, self.hi, s_lo, s_hi)
+            self._toc('reduce_scatter')
+        self._tic('fused_exchange')
+        if optimizer == 'adam':
+            self.comm.fused_update(kinds[optimizer], self.moments[0], self.moments[1], lo, hi, s_lo, s_hi, i_batch,
+                                   options.get('step_size', 0.001), options.get('b1', 0.9), options.get('b2', 0.999),
+                                   options.get('eps', 1e-7), flags, mask)
+        elif optimizer == 'gd':
+            self.comm.fused_update(kinds[optimizer], None, None, lo, hi, s_lo, s_hi, 0, options['step_size'], 0., 0., 0., flags, mask)
+        else:
+            self.comm.fused_update(kinds[optimizer], self.moments[0], None, lo, hi, s_lo, s_hi, 0, options.get('step_size', 0.001),
+                                   options.get('gamma', 0.9), 0., 0., flags, mask)
+        self._toc('fused_exchange')
 
     def _poison_stale(self, f_lo, f_hi):
         """Debug aid: NaN-fill what the contract of exchange_and_update(first=...) calls stale (other ranks' shards outside

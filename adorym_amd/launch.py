@@ -10,9 +10,11 @@ without a launcher around it.
 
 Rank 0's stdout is relayed to this process's stdout line by line (a benchmark's one JSON line arrives unchanged); the other
 ranks' stdout goes to stderr.  The exit code is the first non-zero child code, else 0; when one rank fails the others are
-given a grace period and then terminated (they would otherwise wait in a collective for ever).
+given a grace period, then terminated, then -- if SIGTERM does not end them -- killed (they would otherwise wait in a
+collective for ever); SIGTERM to the launcher itself takes the same path, and every child is reaped before run() returns.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -44,7 +46,7 @@ def rank_envs(n, base=None, port=None, job=None):
     return envs
 
 
-def run(n, argv, grace_s=20.0, out=None, err=None):
+def run(n, argv, grace_s=20.0, out=None, err=None, kill_after_s=5.0):
     """Start ``argv`` n times (one rank each), wait for all, return (exit code, rank 0's stdout lines)."""
     out = out or sys.stdout
     err = err or sys.stderr
@@ -66,7 +68,14 @@ def run(n, argv, grace_s=20.0, out=None, err=None):
 
     threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
     [t.start() for t in threads]
-    rc, t_fail = 0, None
+    rc, t_fail, t_term = 0, None, None
+
+    def on_term(signum, frame):             # SIGTERM to the launcher: unwind through the finally block below
+        raise KeyboardInterrupt('launcher received signal %d' % signum)
+
+    old_handler = None
+    if threading.current_thread() is threading.main_thread():
+        old_handler = signal.signal(signal.SIGTERM, on_term)
     try:
         while True:
             codes = [p.poll() for p in procs]
@@ -75,16 +84,35 @@ def run(n, argv, grace_s=20.0, out=None, err=None):
                 rc, t_fail = bad[0], time.time()
             if all(c is not None for c in codes):
                 break
-            if t_fail is not None and time.time() - t_fail > grace_s:
+            if t_fail is not None and t_term is None and time.time() - t_fail > grace_s:
                 for p in procs:             # exactly the processes started above
                     if p.poll() is None:
                         p.terminate()
-                t_fail = time.time() + 1e9
+                t_term = time.time()
+            if t_term is not None and time.time() - t_term > kill_after_s:
+                for p in procs:             # a rank stuck in a driver call does not die of SIGTERM
+                    if p.poll() is None:
+                        p.kill()
+                t_term = time.time() + 1e9
             time.sleep(0.05)
     finally:
-        for p in procs:                     # the launcher is interrupted or dies: its ranks must not outlive it
-            if p.poll() is None:
-                p.terminate()
+        # the launcher is interrupted, terminated or failing: its ranks must not outlive it.  terminate -> wait -> kill -> reap
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        deadline = time.time() + kill_after_s
+        for p in alive:
+            try:
+                p.wait(max(0.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(5)
+            except Exception:
+                pass
+        if old_handler is not None:
+            signal.signal(signal.SIGTERM, old_handler)
     [t.join(5) for t in threads]
     return rc, lines0
 

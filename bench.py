@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+EXIT_LEG_ABANDONED = 5      # a secondary leg of an N > 1 run hung: the headline line was printed, with `legs_abandoned`
 
 
 def algorithmic_bytes_fwd_grad(B, Py, Px, S, V):
@@ -345,9 +346,10 @@ def main():
     ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
     ap.add_argument('--legs', default='per_angle,vr8,vr16,sweep', help='which secondary full-chip legs to run (profiling aid)')
     ap.add_argument('--force-dist', action='store_true', help='use the multi-GPU (RCCL) code path even with one rank')
-    ap.add_argument('--comm', choices=('rccl', 'torch', 'host'), default=os.environ.get('ADM_COMM', 'rccl'),
-                    help="collectives through libadm's C ABI (default), through torch.distributed's nccl backend, or staged through "
-                         "host memory (validation: the ranks may then share one GPU)")
+    ap.add_argument('--comm', choices=('rccl', 'p2p', 'host'), default=os.environ.get('ADM_COMM', 'rccl'),
+                    help="rccl (default): RCCL reduce-scatter / all-gather behind libadm's C ABI; p2p: direct all-pairs exchange through "
+                         "IPC-mapped peer buffers, fused with the optimiser (one kernel per update; the ranks may share one GPU); host: "
+                         "staged through host memory (validation only; the ranks may share one GPU)")
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help="weak: every rank runs --minibatch positions per step (global batch N x 32, the reference's `mpirun -n N`); "
                          "strong: ONE minibatch of --minibatch positions split over the ranks (N x 32/N)")
@@ -359,6 +361,7 @@ def main():
                          'faster (an experiment: ask for it explicitly)')
     ap.add_argument('--leg-timeout', type=int, default=int(os.environ.get('ADM_BENCH_LEG_TIMEOUT', '240')),
                     help='N > 1: seconds a secondary leg may take before it is abandoned and the line is printed without it (0 = no watchdog)')
+    ap.add_argument('--test-hang-leg', action='store_true', help=argparse.SUPPRESS)     # tests/: the last secondary leg never returns
     ap.add_argument('--restricted-exchange', action='store_true',
                     help='N > 1 experiment: sum only the y-planes the global batch touches, each part onto its owner; the owners add '
                          'the regulariser term N-fold (DESIGN.md section 6; tests/test_gpu_world2.py).  Off by default.')
@@ -381,42 +384,44 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.comm == 'host':
-        local_rank %= max(1, C.device_count())     # validation transport: several ranks may share a GPU
+    if args.comm in ('host', 'p2p'):
+        local_rank %= max(1, C.device_count())     # these transports let several ranks share a GPU
     use_dist = world > 1 or args.force_dist
     if not use_dist:
         comm = C.LocalComm()
-    elif args.comm == 'torch':
-        comm = C.TorchComm('nccl', device_index=local_rank)
     elif args.comm == 'host':
         comm = C.HostStagedComm(device_index=local_rank)
+    elif args.comm == 'p2p':
+        comm = C.P2PComm(device_index=local_rank)
     else:
         comm = C.RcclComm(device_index=local_rank)
     rank = comm.rank
     if use_dist and args.overlap_gather == '0':
         os.environ['ADM_COMM_AUX'] = '0'        # no side-stream communicator unless the two-part gather is asked for
-    # libadm kernels and the RCCL collectives share one stream: the context's own (RcclComm) or torch's (TorchComm)
-    ctx = A.Context(local_rank, stream=comm.stream_handle() if use_dist else None)
+    # libadm kernels and the collectives share the context's own stream
+    ctx = A.Context(local_rank)
     comm_note = None
     if hasattr(comm, 'attach'):
-        # RcclComm.attach either succeeds on every rank or raises on every rank (two-phase agreement inside); if it raises,
-        # every rank falls back TOGETHER to torch.distributed's nccl backend (same collectives, torch tensors as buffers)
+        # attach() either succeeds on every rank or raises on every rank (agreement over the control plane inside).  There is
+        # NO fall-back to another transport: a line measured on a different system would not be this system's number.  Every
+        # rank leaves with the same non-zero code; the launcher (or the caller) decides what to start instead.
         try:
             comm.attach(ctx)
         except Exception as e:
-            comm_note = 'RCCL through the C ABI failed (%r): fell back to torch.distributed nccl' % (e,)
-            sys.stderr.write('bench.py: rank %d: %s\n' % (rank, comm_note))
-            comm.ctx = None
-            comm.close()                        # leaves the TCP star; TorchComm opens an nccl group on MASTER_ADDR / MASTER_PORT
-            ctx.close()
-            comm = C.TorchComm('nccl', device_index=local_rank)
-            ctx = A.Context(local_rank, stream=comm.stream_handle())
+            sys.stderr.write("bench.py: rank %d: the '%s' transport could not be brought up on every rank (%r); no line is printed. "
+                             "Other transports: --comm rccl | p2p | host\n" % (rank, args.comm, e))
+            try:
+                comm.ctx = None
+                comm.close()
+            except Exception:
+                pass
+            raise SystemExit(4)
     # the communicator really spans N ranks (a silent 1-rank communicator would make every collective the identity)
-    abi_size = int(ctx.lib.adm_comm_size(ctx.handle))
+    abi_size = int(ctx.lib.adm_p2p_size(ctx.handle) if getattr(comm, 'backend', '') == 'p2p' else ctx.lib.adm_comm_size(ctx.handle))
     if use_dist and comm.size != world:
         raise SystemExit('bench.py: communicator has %d ranks, expected %d' % (comm.size, world))
-    if getattr(comm, 'backend', '') == 'rccl' and abi_size != world:
-        raise SystemExit('bench.py: adm_comm_size() = %d, expected %d' % (abi_size, world))
+    if getattr(comm, 'backend', '') in ('rccl', 'p2p') and abi_size != world:
+        raise SystemExit('bench.py: adm_comm_size() / adm_p2p_size() = %d, expected %d' % (abi_size, world))
 
     cfg = W.c3_config()
     B_global = args.minibatch * world if args.scaling == 'weak' else args.minibatch
@@ -606,8 +611,11 @@ def main():
         return dt_, ms_kernel_total[0] / args.steps, ph
 
     def phases_dict(kern_ms_, ph):
-        return {'kernel_ms': kern_ms_, 'reduce_scatter_ms': ph.get('reduce_scatter', 0.0), 'update_ms': ph.get('update', 0.0),
-                'first_gather_ms': ph.get('first_gather', 0.0), 'deferred_gather_ms': ph.get('deferred_gather', 0.0)}
+        d_ = {'kernel_ms': kern_ms_, 'reduce_scatter_ms': ph.get('reduce_scatter', 0.0), 'update_ms': ph.get('update', 0.0),
+              'first_gather_ms': ph.get('first_gather', 0.0), 'deferred_gather_ms': ph.get('deferred_gather', 0.0)}
+        if 'fused_exchange' in ph:      # --comm p2p: reduce-scatter + optimiser + all-gather are one kernel between two stream barriers
+            d_['fused_exchange_ms'] = ph['fused_exchange']
+        return d_
 
     dt, kern_ms, phases = timed_loop()
     loss_headline = loss_box[0]
@@ -671,11 +679,12 @@ def main():
 
                 def fire():
                     if out is not None:
+                        out['legs_abandoned'] = out.get('legs_abandoned', []) + [self.what]
                         out['comm']['note'] = ((out['comm']['note'] + '; ') if out['comm']['note'] else '') + \
                             "leg '%s' did not finish within %d s and was abandoned" % (self.what, args.leg_timeout)
                         emit(out)
                     sys.stderr.write('bench.py: rank %d: leg %s timed out\n' % (rank, self.what))
-                    os._exit(0)
+                    os._exit(EXIT_LEG_ABANDONED)      # the headline line is out, but the run is NOT clean: automation can tell
                 self.t = threading.Timer(args.leg_timeout, fire)
                 self.t.daemon = True
                 self.t.start()
@@ -701,7 +710,7 @@ def main():
     # the headline, with the full exchange), from the same initial state
     if use_dist and world > 1 and args.scaling == 'weak':
         with Watchdog('immediate_restricted' if not leg['restricted'] else 'immediate_full_exchange'):
-            if os.environ.get('ADM_BENCH_TEST_HANG') == '1':        # test hook: this leg never comes back
+            if args.test_hang_leg:
                 time.sleep(10 ** 6)
             leg['restricted'] = not leg['restricted']
             reset_state()

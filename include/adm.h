@@ -125,6 +125,53 @@ int adm_reduce(adm_ctx* ctx, float* buf, size_t count, int root);
 int adm_comm_group_start(adm_ctx* ctx);
 int adm_comm_group_end(adm_ctx* ctx);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Peer-to-peer transport (adm_p2p.hip): the same exchange as above -- `gradient.arr = comm.allreduce(gradient.arr)`
+ * (adorym/ptychography.py:1113-1114) followed by the identical optimiser step on every rank (:1120-1129, optimizers.py:309-318)
+ * and the constraints / mask (:1135-1158, array_ops.py:239-251) -- as a DIRECT all-pairs exchange without RCCL: every rank maps
+ * the object and gradient buffers of its peers (IPC handles; on one node every peer is one xGMI hop away) and ONE kernel per
+ * update sums the ranks' gradients of the owned shard in rank order, applies the optimiser in registers and writes the new
+ * values into every replica: reduce-scatter + optimiser + all-gather in one pass.  Ordering between the ranks uses device-side
+ * flags in uncached memory (signal / wait kernels on the context's stream: no host synchronisation).  Several ranks may share
+ * one GPU (the mapped pointers then name local memory), which is how the path is exercised on a single-GPU machine.
+ *   adm_p2p_create       per rank: flag block + mailbox (for small all-reduces; bytes, 0 = 8 MB).  nranks <= ADM_P2P_MAX_RANKS.
+ *   adm_p2p_local        which = 0: the rank's flag block, 1: its mailbox -- to be exported to the peers.
+ *   adm_p2p_export/open/close   ADM_P2P_HANDLE_BYTES-byte IPC handle of a device allocation (its base address) / mapping of a
+ *                        peer's allocation in this process / unmapping.  A handle cannot be opened by the process that made it.
+ *   adm_p2p_connect      the flag blocks and mailboxes of all ranks (array of nranks device pointers; own entries ignored).
+ *   adm_p2p_bind_object  the object and gradient buffers of all ranks, n floats each (own entries = own buffers).
+ *   adm_p2p_update       kind = ADM_OPT_*.  For the flat elements [lo, hi) -- this rank's shard: g = sum over ranks q of g_q[i]
+ *                        (rank order) where i is in [sum_lo, sum_hi), g = own g[i] elsewhere (footprint-restricted exchange: the
+ *                        owner's buffer is complete there); then adm_adam_step / adm_gd_step / adm_momentum_step's arithmetic
+ *                        with the moments m, v indexed from the shard's start (m[i - lo]; momentum: m is the velocity, b1 is
+ *                        gamma); the result is written to x_q[i] of every rank.  A barrier of the ranks' streams on entry
+ *                        (every gradient buffer complete) and on exit (every replica updated, every gradient buffer free).
+ *   adm_p2p_all_reduce   in-place rank-order sum of a small device array through the mailboxes (comm.allreduce of the small
+ *                        parameter gradients, adorym/optimizers.py:1025,1041,1053,1064,1079).
+ *   adm_p2p_barrier      barrier of the ranks' streams (device side).
+ *   adm_p2p_status       ADM_OK, or an error if a wait timed out (ADM_P2P_TIMEOUT_S, default 30 s): which rank did not arrive.
+ *   adm_p2p_destroy      frees flag block and mailbox; the peers must have closed their mappings. */
+#define ADM_P2P_HANDLE_BYTES 64
+#define ADM_P2P_MAX_RANKS 16
+#define ADM_OPT_ADAM 0
+#define ADM_OPT_GD 1
+#define ADM_OPT_MOMENTUM 2
+int adm_p2p_create(adm_ctx* ctx, int rank, int nranks, size_t mailbox_bytes);
+int adm_p2p_local(adm_ctx* ctx, int which, void** dptr);
+int adm_p2p_export(adm_ctx* ctx, const void* dptr, void* handle64);
+int adm_p2p_open(adm_ctx* ctx, const void* handle64, void** dptr);
+int adm_p2p_close(adm_ctx* ctx, void* dptr);
+int adm_p2p_connect(adm_ctx* ctx, void* const* peer_flags, void* const* peer_mailbox);
+int adm_p2p_bind_object(adm_ctx* ctx, void* const* peer_x, void* const* peer_g, size_t n);
+int adm_p2p_rank(adm_ctx* ctx);
+int adm_p2p_size(adm_ctx* ctx);
+int adm_p2p_update(adm_ctx* ctx, int kind, float* m, float* v, size_t lo, size_t hi, size_t sum_lo, size_t sum_hi, int i_batch,
+                   double step_size, double b1, double b2, double eps, int flags, const float* mask);
+int adm_p2p_all_reduce(adm_ctx* ctx, float* buf, size_t count);
+int adm_p2p_barrier(adm_ctx* ctx);
+int adm_p2p_status(adm_ctx* ctx);
+int adm_p2p_destroy(adm_ctx* ctx);
+
 /* ---- plan: static geometry + physics of one reconstruction ------------------------- */
 typedef enum { ADM_DET_NONE = 0, ADM_DET_FARFIELD = 1, ADM_DET_FRESNEL = 2 } adm_det_mode;
 typedef enum { ADM_LOSS_LSQ = 0, ADM_LOSS_POISSON = 1 } adm_loss_type;

@@ -40,18 +40,18 @@ def _driver_kwargs(cfg, inp, prj, tmp):
                 store_checkpoint=False, use_checkpoint=False, return_state=True, **cfg['probe'])
 
 
-def _worker(rank, world, port, prj_path, tmp, q):
+def _worker(rank, world, port, prj_path, tmp, q, transport):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     sys.path.insert(0, HERE)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ADM_COMM='host')
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ADM_COMM=transport)
     try:
         import adorym_amd as A
         from adorym_amd import comm as C
         import fullsize_oracle as F
         cfg, inp, _, _ = F.setup(1)
         comm = C.from_env()
-        assert isinstance(comm, C.HostStagedComm) and comm.size == world
+        assert type(comm) is {'host': C.HostStagedComm, 'p2p': C.P2PComm}[transport] and comm.size == world
         st = A.reconstruct_ptychography(comm=comm, **_driver_kwargs(cfg, inp, np.load(prj_path).astype(np.float32), tmp))
         np.save(os.path.join(tmp, 'rank%d.npy' % rank), np.stack([st['delta'], st['beta']], -1))
         comm.close()
@@ -97,7 +97,11 @@ def _serial_one_rank(A, ctx, cfg, inp, prj, world):
     return obj.get(), len(batches)
 
 
-def test_world2_exchange_at_config4_size(tmp_path):
+@pytest.mark.parametrize('transport,world', [('host', 2), ('p2p', 2), ('p2p', 4)])
+def test_world2_exchange_at_config4_size(tmp_path, transport, world):
+    """transport 'host': every collective staged through host memory; 'p2p': the direct exchange (adm_p2p.hip) -- each rank's fused
+    kernel reads the other ranks' 134 MB gradient buffers and writes their objects through IPC mappings, at 2 and at 4 ranks
+    (4 ranks: one global batch of 128 positions, the 69 of the scan topped up from its start as the reference does)."""
     sys.path.insert(0, HERE)
     import fullsize_oracle as F
     import adorym_amd as A
@@ -105,31 +109,31 @@ def test_world2_exchange_at_config4_size(tmp_path):
     prj = F.measured(inp, probe, phys)
     prj_path = str(tmp_path / 'prj.npy')
     np.save(prj_path, prj)
-    world = 2
-    # the fp64 / fp32 oracle runs of `mpirun -n 2` beside everything else
+    # the fp64 / fp32 oracle runs of `mpirun -n world` beside everything else
     orc = {dt: subprocess.Popen([sys.executable, os.path.join(HERE, 'fullsize_oracle.py'), str(tmp_path / ('o_%s.npy' % dt)), 'immediate', dt,
                                  prj_path, '1', str(world)]) for dt in ('float64', 'float32')}
     try:
         mpc = mp.get_context('spawn')
         q = mpc.Queue()
         port = _free_port()
-        procs = [mpc.Process(target=_worker, args=(r, world, port, prj_path, str(tmp_path), q)) for r in range(world)]
+        procs = [mpc.Process(target=_worker, args=(r, world, port, prj_path, str(tmp_path), q, transport)) for r in range(world)]
         [p.start() for p in procs]
         res = [q.get(timeout=900) for _ in procs]
         [p.join(120) for p in procs]
         for r in res:
             assert 'error' not in r, r['error']
-        x0r, x1r = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
-        # (a) one sharded object: after the all-gather both replicas hold the same bits
-        assert np.array_equal(x0r, x1r)
+        x0r = np.load(tmp_path / 'rank0.npy')
+        # (a) one sharded object: after the all-gather every replica holds the same bits
+        for r_ in range(1, world):
+            assert np.array_equal(x0r, np.load(tmp_path / ('rank%d.npy' % r_)))
         assert np.all(np.isfinite(x0r))
         # (b) the one-rank run on the same global batches, same kernels, rank-order sum: bit for bit
         ctx = A.Context(0)
         serial, n_updates = _serial_one_rank(A, ctx, cfg, inp, prj, world)
         ctx.close()
-        assert n_updates == 2                              # 69 positions -> two global batches of 64
+        assert n_updates == (2 if world == 2 else 1)       # 69 positions -> two global batches of 64, or one of 128
         nd = int((serial != x0r).sum())
-        print('world 2 at 256^3: %d of %d voxels differ from the serial one-rank sum' % (nd, serial.size))
+        print('world %d (%s) at 256^3: %d of %d voxels differ from the serial one-rank sum' % (world, transport, nd, serial.size))
         assert nd == 0
         # (c) the fp64 oracle's 2-rank run
         for dt, p in orc.items():
@@ -145,7 +149,7 @@ def test_world2_exchange_at_config4_size(tmp_path):
         rmse = np.sqrt(np.mean((xs[..., 0] - x64[..., 0]) ** 2))
         fl, fl32 = d > 0.5 * lr, d32 > 0.5 * lr
         e_us, e_ref = np.linalg.norm((xs - x64)[~fl]), np.linalg.norm((x32 - x64)[~fl32])
-        print('   vs fp64 oracle (n_ranks=2): delta RMSE %.2e; |x-x64|/|update| %.2e (oracle fp32 %.2e); voxels off by > lr/2: %d (oracle fp32: %d) of %d'
+        print('   vs fp64 oracle (same number of ranks): delta RMSE %.2e; |x-x64|/|update| %.2e (oracle fp32 %.2e); voxels off by > lr/2: %d (oracle fp32: %d) of %d'
               % (rmse, e_us / upd, e_ref / upd, fl.sum(), fl32.sum(), d.size))
         assert upd > 50 * lr and rmse < 1e-5
         assert fl.sum() <= 3 * fl32.sum() + 1e-4 * d.size

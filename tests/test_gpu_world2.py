@@ -38,12 +38,12 @@ def _params(n_use, extra, tmp):
     return p
 
 
-def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate):
+def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate, transport):
     """One rank: a fresh process that has not touched the GPU before."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      ADM_COMM='host')
+                      ADM_COMM=transport)
     os.environ.update(env)
     try:
         import adorym_amd as A
@@ -67,7 +67,7 @@ def _worker(rank, world, port, n_use, extra, tmp, env, q, emulate):
 
         DP.DataParallelObject.exchange_and_update = rec_x
         comm = C.from_env()
-        assert isinstance(comm, C.HostStagedComm) and comm.size == world and comm.device_index == 0
+        assert type(comm) is {'host': C.HostStagedComm, 'p2p': C.P2PComm}[transport] and comm.size == world and comm.device_index == 0
         params = _params(n_use, extra, tmp)
         theta_ls = None
         if emulate:
@@ -127,12 +127,16 @@ def _serial_two_rank_update(A, params, seen, world):
     return obj.get()
 
 
-def run_world2(tmp_path, n_use, extra, env=None, emulate=False):
+def run_world2(tmp_path, n_use, extra, env=None, emulate=False, transport='host', world=2):
+    """``transport``: 'host' (every collective staged through host memory) or 'p2p' (the direct exchange of adm_p2p.hip: the ranks
+    read and write each other's device buffers; one fused kernel per update).  ``world`` processes, all on GPU 0."""
     import multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, n_use, extra, str(tmp_path), env or {}, q, emulate)) for r in range(world)]
+    os.makedirs(str(tmp_path), exist_ok=True)
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n_use, extra, str(tmp_path), env or {}, q, emulate, transport))
+             for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=600) for _ in procs]
     [p.join(120) for p in procs]
@@ -159,10 +163,11 @@ def _grouped(theta, ind):
     return [(t, sorted(v)) for t, v in out]
 
 
+@pytest.mark.parametrize('transport', ['host', 'p2p'])
 @pytest.mark.parametrize('run', ['immediate6', 'immediate6_reg', 'perangle', 'probe6'])
-def test_world2_driver_matches_reference_two_rank_run(tmp_path, run):
+def test_world2_driver_matches_reference_two_rank_run(tmp_path, run, transport):
     n_use, extra = cases.W2_RUNS[run]
-    res = run_world2(tmp_path, n_use, extra)
+    res = run_world2(tmp_path, n_use, extra, transport=transport)
     g, x64, x32 = _golden(run)
     x0 = np.stack(cases.e2e_inputs()['guess'], -1)
     upd = np.linalg.norm(x64 - x0)
@@ -193,14 +198,15 @@ def test_world2_driver_matches_reference_two_rank_run(tmp_path, run):
         assert np.abs(pg - cases.e2e_inputs()['probe_mag'] * np.exp(1j * cases.e2e_inputs()['probe_phase'])).max() > 1e-3
 
 
-def test_world2_straddling_batches_use_one_counter(tmp_path):
+@pytest.mark.parametrize('transport', ['host', 'p2p'])
+def test_world2_straddling_batches_use_one_counter(tmp_path, transport):
     """9 positions: global batches straddle angles.  The reference's ranks then count optimiser steps differently and their
     replicas drift apart (golden F14 'immediate', restated by the oracle's rank_local_counters=True); the product keeps ONE
     counter (one sharded object), which the oracle restates with rank_local_counters=False.  Compared with that fp64 run
     under the 3x rule, with the reference's own fp32-vs-fp64 distance of this very run as the yardstick."""
     from oracle import adorym_oracle as O           # checker only
     n_use, extra = cases.W2_RUNS['immediate']
-    res = run_world2(tmp_path, n_use, extra)
+    res = run_world2(tmp_path, n_use, extra, transport=transport)
     g, x64_ref, x32_ref = _golden('immediate')
     inp = cases.e2e_inputs()
     E = cases.E2E
@@ -240,7 +246,8 @@ def test_world2_two_part_gather_is_bitwise_the_plain_gather(tmp_path, run):
         assert np.array_equal(a['probe'], b['probe'])
 
 
-def test_world2_constraints_and_mask_on_shards(tmp_path):
+@pytest.mark.parametrize('transport,world', [('host', 2), ('p2p', 2), ('p2p', 4)])
+def test_world2_constraints_and_mask_on_shards(tmp_path, transport, world):
     """Non-negativity clip and finite-support mask are applied by the optimiser kernel on each rank's SHARD (absolute voxel
     indices, adorym/ptychography.py:1135-1158, adorym/array_ops.py:239-251): the 2-rank result equals the one-context
     restatement bit for bit, the clip and the mask are visible in it."""
@@ -248,31 +255,33 @@ def test_world2_constraints_and_mask_on_shards(tmp_path):
     N = cases.E2E['N']
     support = (r.uniform(size=(N, N, N)) > 0.3).astype(np.float32)
     extra = dict(n_epochs=1, optimizer='adam', learning_rate=1e-4, non_negativity=True, finite_support_mask_path=support)
-    res = run_world2(tmp_path, 6, extra, emulate=True)
+    res = run_world2(tmp_path, 6, extra, emulate=True, transport=transport, world=world)
     emu = res[0]['emulated']
     for r_ in res:
         assert np.array_equal(r_['delta'], emu[..., 0]) and np.array_equal(r_['beta'], emu[..., 1])
     assert np.all(res[0]['delta'] >= 0) and np.all(res[0]['delta'][support == 0] == 0) and np.any(res[0]['delta'][support == 1] > 0)
 
 
+@pytest.mark.parametrize('transport,world', [('host', 2), ('p2p', 2), ('p2p', 4)])
 @pytest.mark.parametrize('reg', [False, True])
 @pytest.mark.regression
-def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg):
+def test_world2_update_is_bitwise_the_serial_sum_of_rank_gradients(tmp_path, reg, transport, world):
     """One angle, 6 positions, one global batch: the 2-rank update against the same arithmetic on ONE context -- per-rank
     gradient buffers (each with its own regulariser term: the R-fold weight of adorym/forward_model.py:138-139), summed in
     rank order, one full-range Adam step.  Bit for bit: the exchange adds nothing but the sum."""
     extra = dict(n_epochs=1, optimizer='adam', learning_rate=1e-6)
     if reg:
         extra.update(gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)
-    res = run_world2(tmp_path, 6, extra, emulate=True)
+    res = run_world2(tmp_path, 6, extra, emulate=True, transport=transport, world=world)
     emu = res[0]['emulated']
     for r in res:
         assert np.array_equal(r['delta'], emu[..., 0]) and np.array_equal(r['beta'], emu[..., 1])
 
 
+@pytest.mark.parametrize('transport', ['host', 'p2p'])
 @pytest.mark.parametrize('run', ['immediate6_reg', 'immediate', 'perangle', 'probe6'])
 @pytest.mark.regression
-def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
+def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run, transport):
     """ADM_RESTRICTED_EXCHANGE=1 (adorym_amd/dp.py, exchange_and_update(touched=...)): only the y-planes the GLOBAL batch touches
     are summed over the ranks -- each part onto the rank that owns it (adm_reduce) -- and the regulariser term, which every rank of
     the reference adds to its own gradient (adorym/forward_model.py:138-139), is added R-fold by the owners afterwards
@@ -284,8 +293,8 @@ def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
     n_use, extra = cases.W2_RUNS[run]
     if run != 'immediate6_reg':
         extra = dict(extra, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)      # (the regulariser is what the owners add back)
-    full = run_world2(tmp_path / 'a', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '0'})
-    rest = run_world2(tmp_path / 'b', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '1'})
+    full = run_world2(tmp_path / 'a', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '0'}, transport=transport)
+    rest = run_world2(tmp_path / 'b', n_use, extra, env={'ADM_RESTRICTED_EXCHANGE': '1'}, transport=transport)
     lr = extra['learning_rate']
     n_obj = 2 * cases.E2E['N'] ** 3
     assert not full[0]['restricted'] and len(rest[0]['restricted']) > 0 and rest[0]['restricted'] == rest[1]['restricted']
@@ -305,3 +314,53 @@ def test_world2_restricted_exchange_equals_full_exchange(tmp_path, run):
         assert np.allclose(a['losses'], b['losses'], rtol=1e-5)
         assert np.allclose(a['probe'], b['probe'], rtol=0, atol=1e-6 * np.abs(a['probe']).max())      # (probe6: the probe is optimised too)
     assert np.array_equal(rest[0]['delta'], rest[1]['delta']) and np.array_equal(rest[0]['beta'], rest[1]['beta'])
+
+
+@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('run', ['immediate', 'immediate6_reg', 'perangle', 'probe6'])
+@pytest.mark.regression
+def test_p2p_exchange_is_bitwise_the_host_staged_exchange(tmp_path, run, world):
+    """The direct exchange (ADM_COMM=p2p: one fused kernel per update that reads the peers' gradient buffers, adds them in rank
+    order, applies Adam and writes every replica; small parameter gradients summed through the mailboxes) against the
+    host-staged transport (device -> host -> rank-order sum on rank 0 -> device, then the one-rank optimiser kernel on the shard)
+    on the same driver run, at 2 and at 4 ranks on ONE GPU: objects, probes and losses agree bit for bit on every rank.  At 4
+    ranks the global batches (12 positions) straddle angles and wrap around the scan."""
+    n_use, extra = cases.W2_RUNS[run]
+    host = run_world2(tmp_path / 'h', n_use, extra, transport='host', world=world)
+    p2p = run_world2(tmp_path / 'p', n_use, extra, transport='p2p', world=world)
+    x0 = np.stack(cases.e2e_inputs()['guess'], -1)
+    for a, b in zip(host, p2p):
+        assert np.all(np.isfinite(b['delta'])) and np.abs(b['delta'] - x0[..., 0]).max() > 0
+        assert np.array_equal(a['theta'], b['theta']) and all(np.array_equal(u, v) for u, v in zip(a['ind'], b['ind']))
+        assert np.array_equal(a['delta'], b['delta']) and np.array_equal(a['beta'], b['beta'])
+        assert np.array_equal(a['losses'], b['losses'])
+        assert np.array_equal(a['probe'], b['probe'])
+    for b in p2p[1:]:
+        assert np.array_equal(p2p[0]['delta'], b['delta']) and np.array_equal(p2p[0]['beta'], b['beta'])
+
+
+def test_world4_p2p_against_fp64_oracle(tmp_path):
+    """Four ranks on one GPU through the direct exchange against the fp64 oracle's 4-rank run (the oracle is pinned to the
+    reference at 1 and 2 ranks: goldens F6 / F14; rank_local_counters=False restates the product's one optimiser counter)."""
+    from oracle import adorym_oracle as O           # checker only
+    n_use, extra = cases.W2_RUNS['immediate6_reg']
+    res = run_world2(tmp_path, n_use, extra, transport='p2p', world=4)
+    inp = cases.e2e_inputs()
+    E = cases.E2E
+    phys = O.Physics((E['P'], E['P']), E['energy_ev'], E['psize_cm'], free_prop_cm='inf')
+    g6 = np.load(os.path.join(G, 'F6_e2e.npz'))
+    probe = inp['probe_mag'] * np.exp(1j * inp['probe_phase'])
+    kw = dict(minibatch_size=E['minibatch_size'], n_ranks=4, n_epochs=1, learning_rate=extra['learning_rate'], gamma=extra['gamma'],
+              alpha_d=extra['alpha_d'], alpha_b=extra['alpha_b'])
+    prj = g6['prj'].astype(np.float32)[:, :n_use]
+    x64, losses, _ = O.reconstruct(prj.astype(np.float64), inp['guess'], probe, inp['probe_pos'][:n_use], inp['theta_ls'], phys, return_trace=True, **kw)
+    x32, _, _ = O.reconstruct(prj, inp['guess'], probe, inp['probe_pos'][:n_use], inp['theta_ls'], phys, return_trace=True, dtype='float32', **kw)
+    upd = np.linalg.norm(x64 - np.stack(inp['guess'], -1))
+    for r in res:
+        x = np.stack([r['delta'], r['beta']], -1).astype(np.float64)
+        d = np.abs(x - x64)
+        print('world 4, rank %d: |x-x64|/|update| = %.2e (oracle fp32: %.2e)' % (r['rank'], np.linalg.norm(x - x64) / upd, np.linalg.norm(x32 - x64) / upd))
+        assert np.sqrt(np.mean((x[..., 0] - x64[..., 0]) ** 2)) < 1e-5
+        assert (d > 1e-6).mean() < 1e-3 and d.max() < 1e-4        # (L1 / TV sign() gradients: a handful of voxels flip in any fp32 run)
+        assert np.array_equal(r['delta'], res[0]['delta']) and np.array_equal(r['beta'], res[0]['beta'])
+    assert np.allclose(res[0]['losses'], losses, rtol=2e-4)

@@ -119,23 +119,19 @@ def test_single_rank_group_needs_no_socket():
     g.close()
 
 
-def test_product_comm_module_imports_no_torch():
-    """`import torch` appears nowhere under adorym_amd/ outside TorchComm (north_star: no PyTorch backend)."""
+def test_product_imports_no_torch():
+    """`import torch` appears nowhere under adorym_amd/ nor in bench.py (north_star: no PyTorch backend): the
+    torch.distributed stand-in of the CPU sharding tests lives in tests/torch_comm.py."""
     import re
     pkg = os.path.join(ROOT, 'adorym_amd')
     hits = []
-    for name in sorted(os.listdir(pkg)):
-        if not name.endswith('.py'):
-            continue
-        src = open(os.path.join(pkg, name)).read()
+    files = [os.path.join(pkg, n) for n in sorted(os.listdir(pkg)) if n.endswith('.py')] + [os.path.join(ROOT, 'bench.py')]
+    for path in files:
+        src = open(path).read()
         for m in re.finditer(r'^\s*(import torch|from torch)', src, re.M):
-            line = src.count('\n', 0, m.start()) + 1
-            hits.append((name, line))
-    cls = open(os.path.join(pkg, 'comm.py')).read()
-    a = cls.index('class TorchComm')
-    b = cls.index('class RcclComm')
-    lo, hi = cls.count('\n', 0, a) + 1, cls.count('\n', 0, b) + 1
-    assert hits and all(n == 'comm.py' and lo <= l < hi for n, l in hits), hits
+            hits.append((os.path.basename(path), src.count('\n', 0, m.start()) + 1))
+    assert not hits, hits
+    assert 'TorchComm' not in open(os.path.join(pkg, 'comm.py')).read()
 
 
 def test_missing_rank_is_a_clean_error_not_a_hang():
