@@ -361,6 +361,7 @@ def main():
                          'faster (an experiment: ask for it explicitly)')
     ap.add_argument('--leg-timeout', type=int, default=int(os.environ.get('ADM_BENCH_LEG_TIMEOUT', '240')),
                     help='N > 1: seconds a secondary leg may take before it is abandoned and the line is printed without it (0 = no watchdog)')
+    ap.add_argument('--no-p2p-leg', action='store_true', help='N > 1: skip the extra leg that repeats the headline loop through the peer-to-peer transport')
     ap.add_argument('--test-hang-leg', action='store_true', help=argparse.SUPPRESS)     # tests/: the last secondary leg never returns
     ap.add_argument('--restricted-exchange', action='store_true',
                     help='N > 1 experiment: sum only the y-planes the global batch touches, each part onto its owner; the owners add '
@@ -720,6 +721,42 @@ def main():
             leg['restricted'] = not leg['restricted']
         if out is not None:
             out['immediate_restricted' if other_leg['restricted_exchange'] else 'immediate_full_exchange'] = other_leg
+
+    # ... and the headline loop once more through the OTHER device transport, from the same initial state: a line measured with
+    # RCCL also carries the direct exchange (`immediate_p2p`: IPC-mapped peer buffers, one fused kernel per update), so that one
+    # run on a multi-GPU node decides between them.  The peer-to-peer group shares the control plane; its buffers are its own.
+    # A transport that cannot come up (no peer access between two GPUs, ...) raises on every rank together: the leg is
+    # recorded as unavailable, the line is unaffected.
+    if use_dist and world > 1 and args.scaling == 'weak' and args.comm != 'p2p' and not args.no_p2p_leg:
+        with Watchdog('immediate_p2p'):
+            p2p_leg = {'transport': 'p2p'}
+            p2p = C.P2PComm(device_index=local_rank, group=comm.group_)
+            try:
+                p2p.attach(ctx)
+            except Exception as e:
+                p2p_leg['error'] = 'could not be brought up on every rank: %r' % (e,)
+                p2p = None
+            if p2p is not None:
+                state_main, restricted_main = state, leg['restricted']
+                try:
+                    state = DataParallelObject(ops, p2p, (Y, X, Z, 2))
+                    leg['restricted'] = False
+                    reset_state()
+                    dt3, kern3, ph3 = timed_loop()
+                    ctx.sync()
+                    p2p.check_status()
+                    p2p_leg.update({'value': B_global * args.steps / dt3, 'unit': 'probe-positions/s', 'ms_per_step': 1e3 * dt3 / args.steps,
+                                    'phases_ms': phases_dict(kern3, ph3), 'loss_last': loss_box[0], 'loss_headline': loss_headline})
+                except Exception as e:
+                    p2p_leg['error'] = repr(e)
+                finally:
+                    state, leg['restricted'] = state_main, restricted_main
+                    try:
+                        p2p.close(keep_group=True)
+                    except Exception as e:
+                        p2p_leg.setdefault('error', repr(e))
+        if out is not None:
+            out['immediate_p2p'] = p2p_leg
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
