@@ -44,6 +44,7 @@ SIGNATURES = {
     'adm_version': (_I, []),
     'adm_last_error': (C.c_char_p, []),
     'adm_device_count': (_I, []),
+    'adm_mem_info': (_I, [_VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
     'adm_ctx_create': (_I, [_I, _VP, C.POINTER(_VP)]),
     'adm_ctx_destroy': (_I, [_VP]),
     'adm_ctx_sync': (_I, [_VP]),

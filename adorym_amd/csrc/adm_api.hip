@@ -112,6 +112,13 @@ extern "C" int adm_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
+extern "C" int adm_mem_info(adm_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return fail(ADM_ERR_INVALID, "adm_mem_info: null argument");
+    ADM_HIP(hipSetDevice(ctx->device));
+    ADM_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return ADM_OK;
+}
+
 extern "C" int adm_malloc(adm_ctx* ctx, size_t bytes, void** dptr) {
     if (!ctx || !dptr) return fail(ADM_ERR_INVALID, "adm_malloc: null argument");
     ADM_HIP(hipSetDevice(ctx->device));

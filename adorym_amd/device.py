@@ -23,6 +23,12 @@ class Context(object):
     def sync(self):
         check(self.lib.adm_ctx_sync(self.handle))
 
+    def mem_info(self):
+        """(free bytes, total bytes) of this context's GPU."""
+        f, t = C.c_size_t(), C.c_size_t()
+        check(self.lib.adm_mem_info(self.handle, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
     def fork(self):
         """Following calls go to the side stream (after everything enqueued so far) until end_fork()."""
         check(self.lib.adm_ctx_fork(self.handle))

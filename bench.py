@@ -301,7 +301,7 @@ def kernel_sweep(ctx, eng, probe, cfg, targets, batches=(1, 8, 32, 64, 128, 256,
     return rows
 
 
-def driver_measure(cfg, n_theta=16, update_scheme='immediate'):
+def driver_measure(cfg, n_theta=16, update_scheme='immediate', one_block_of_data=False):
     """The PRODUCT's driver, not the engine loop: one epoch of adorym_amd.reconstruct_ptychography over `n_theta` angles of
     config 3 that it has never seen (rotation tables and their adjoint CSR are built inside the timed run), host-resident
     measured data handed over minibatch by minibatch (adorym/forward_model.py:113-119).  Step time = MEAN spacing of the
@@ -312,7 +312,12 @@ def driver_measure(cfg, n_theta=16, update_scheme='immediate'):
     r = np.random.default_rng(0)
     n_pos = len(cfg['probe_pos'])
     Py, Px = cfg['probe_size']
-    prj = (np.abs(r.standard_normal((n_theta, n_pos, Py, Px), dtype=np.float32)) * 30)
+    if one_block_of_data:
+        # a whole epoch (500 angles = 5.5 GB of magnitudes): one angle's worth of synthetic data seen through a stride-0 view, so
+        # that nothing is generated for minutes on the host; the driver still hands over every minibatch from host memory
+        prj = np.broadcast_to(np.abs(r.standard_normal((1, n_pos, Py, Px), dtype=np.float32)) * 30, (n_theta, n_pos, Py, Px))
+    else:
+        prj = (np.abs(r.standard_normal((n_theta, n_pos, Py, Px), dtype=np.float32)) * 30)
     g = W.random_guess(cfg['obj_size'], seed=1)
     import contextlib
     with tempfile.TemporaryDirectory() as td, open(os.devnull, 'w') as sink, contextlib.redirect_stdout(sink):
@@ -344,6 +349,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-per-angle', action='store_true', help="skip the secondary full-chip legs (per angle, virtual ranks, sweep)")
     ap.add_argument('--no-driver', action='store_true', help='skip timing reconstruct_ptychography itself')
+    ap.add_argument('--no-driver-epoch', action='store_true', help='skip the whole-epoch (500 angles) run of reconstruct_ptychography (~25 s)')
     ap.add_argument('--legs', default='per_angle,vr8,vr16,sweep', help='which secondary full-chip legs to run (profiling aid)')
     ap.add_argument('--force-dist', action='store_true', help='use the multi-GPU (RCCL) code path even with one rank')
     ap.add_argument('--comm', choices=('rccl', 'p2p', 'host'), default=os.environ.get('ADM_COMM', 'rccl'),
@@ -775,6 +781,12 @@ def main():
             out['driver']['engine_loop_ms_per_step'] = ms_per_step
             out['driver']['ratio_to_engine_loop'] = out['driver']['ms_per_step_mean'] / ms_per_step
             out['driver_per_angle'] = driver_measure(cfg, 16, 'per angle')
+            if not args.no_driver_epoch:
+                # config 3 AS WRITTEN: one whole epoch, all 500 angles x 17 minibatches, rotation tables / adjoint CSR of every
+                # angle built on first touch inside the timed run (tools/driver_c3_epoch.py: the same with synthesised data, a
+                # second epoch, device memory and reconstruction quality; profiles/r06/r06b_c3_epoch.json)
+                out['driver_epoch'] = driver_measure(cfg, cfg['n_theta'], 'immediate', one_block_of_data=True)
+                out['driver_epoch']['ratio_to_16_angle_driver_leg'] = out['driver_epoch']['ms_per_step_mean'] / out['driver']['ms_per_step_mean']
     if use_dist:
         comm.close()            # RCCL may print its banner here; the JSON line goes last
     if out is not None:

@@ -44,6 +44,9 @@ const char* adm_last_error(void);
 /* Number of GPUs visible to the process (0 if none / on error); creates no context.  Replaces the device enumeration
  * behind `gpu_index` (adorym/ptychography.py:203-205) for launchers that map local ranks to devices. */
 int adm_device_count(void);
+/* Free and total bytes of the context's GPU (hipMemGetInfo): what a driver logs as device memory in use; the reference has
+ * no counterpart beyond torch's allocator statistics. */
+int adm_mem_info(adm_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 
 /* One context = one GPU + one stream.  `stream` may be an existing hipStream_t (e.g.
  * torch.cuda.current_stream().cuda_stream) or NULL to let the context own a new one.
