@@ -29,6 +29,13 @@ struct adm_holo {
     float *part3, *part4;     // per-line partial sums: [n_dists][ny][8], [n_dists][nx]
 };
 
+// transposed store index (row r of pitch p, column c); -DHOLO_ABL_STORE: timing-only variant that stores along the line instead
+#ifdef HOLO_ABL_STORE
+#define HOLO_TIDX(r, p, c, n) ((size_t)(c) * (n) + (r))
+#else
+#define HOLO_TIDX(r, p, c, n) ((size_t)(r) * (p) + (c))
+#endif
+
 namespace adm {
 
 static inline int grid_for(size_t n) {
@@ -95,7 +102,7 @@ template <int N, bool INV, int TPR> struct Passes<N, N, INV, TPR> {
 //   K1  rows y      : psi = probe * c(obj)                      -> FFT_x                       -> T1[kx][y]
 //   K2  lines kx    : FFT_y -> F (kept: Ft[kx][ky])  ; per d: x H_d -> IFFT_y                  -> Wq[d][y][kx]
 //   K3  rows (d, y) : IFFT_x / n -> Psi_d, loss, affine-gradient sums, dL/dPsi -> FFT_x        -> T3[d][kx][y]
-//   K4  lines kx    : per d: FFT_y / n -> Gh_d, distance-gradient sums, GF += conj(H_d) Gh_d ; IFFT_y -> T4[y][kx]
+//   K4  lines kx    : per d: FFT_y / n -> Gh_d, distance-gradient sums, GF += conj(H_d) Gh_d ; IFFT_y -> T4t[kx][y]
 //   K5  rows y      : IFFT_x -> dL/dpsi -> dL/dobj (+=), dL/dprobe (=) ; block 0: the sums of K3 / K4 in fixed order
 // (17 launches of 4.5-13 us each before round 4, back to back: the path is bound by the NUMBER of launches.)
 // Partial sums: one slot per line (K3: per (d, y), 8 floats; K4: per (d, kx)), summed by K5's block 0 -- or by
@@ -104,7 +111,26 @@ template <int N, bool INV, int TPR> struct Passes<N, N, INV, TPR> {
 template <int N> struct LineGeo {
     static constexpr int TPR = N / 8;             // threads per line
     static constexpr int LPB = 256 / TPR;         // lines per block
+    // pitch of a line's LDS buffer: N + 32 / min(LPB, 32) elements, so that the block-wide transposed read of
+    // store_lines_transposed (a half wave = min(LPB, 32) lines x 32 / min(LPB, 32) consecutive points) touches 32 different
+    // 8-byte bank pairs
+    static constexpr int LP = N + (LPB > 1 ? 32 / (LPB < 32 ? LPB : 32) : 0);
 };
+
+// The x and y stages of a 2-D transform hand their results over transposed.  A line's own threads would store its points 8 bytes
+// at a time, pitch * 8 bytes apart: one L2 write transaction per point (1 M of them per K2 / K3 launch at 512 x 512 x 4 -- the
+// store-ablated build of round 6 is 15 us of 76 faster).  Instead the block stores its LPB adjacent lines together: thread e writes
+// point e / LPB of line e % LPB, so LPB consecutive lanes fill LPB * 8 contiguous bytes (32 B at N = 512: a quarter of the
+// transactions).  `base`: LDS address of line 0's result (all lines of a block finish in the same buffer); at(r, c): destination
+// of point r of line c.
+template <int N, typename At> __device__ __forceinline__ void store_lines_transposed(const cf* base, int n_lines, At at) {
+    using LG = LineGeo<N>;
+    __syncthreads();                               // every line of the block is complete
+    for (int e = threadIdx.x; e < N * LG::LPB; e += 256) {
+        const int c = e % LG::LPB, r = e / LG::LPB;
+        if (c < n_lines) *at(r, c) = base[c * LG::LP + r];
+    }
+}
 // The passes read 7 twiddles per butterfly: from an LDS copy of the table (N <= 1024; the caller's next barrier orders the copy
 // before the first pass), from global memory otherwise (the line buffers of N = 2048 leave no room).
 template <int N> struct TwLds {
@@ -155,9 +181,15 @@ struct HoloArgs {
     float k1, sigma, c1, inv_n, gscale;
 };
 
-// sum of v over the TPR threads of a line group (TPR a power of two <= 256); red: [256] floats of LDS; every thread of the
-// block calls it
+// sum of v over the TPR threads of a line group (TPR a power of two <= 256); every thread of the block calls it.  A line of up to
+// 64 threads is (part of) one wave: a fixed shuffle tree, no LDS, no workgroup barrier (the lines of a block stay independent);
+// longer lines go through red ([256] floats of LDS).  Either way the order of the additions is fixed: bit-reproducible.
 template <int TPR> __device__ __forceinline__ float line_sum(float v, float* red) {
+    if (TPR <= 64) {
+#pragma unroll
+        for (int s = TPR / 2; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+        return v;
+    }
     const int tid = threadIdx.x;
     red[tid] = v;
     __syncthreads();
@@ -173,6 +205,14 @@ template <int TPR> __device__ __forceinline__ float line_sum(float v, float* red
 
 // the same for Q quantities at once (one set of barriers); red: [Q][256]
 template <int TPR, int Q> __device__ __forceinline__ void line_sums(float (&v)[Q], float (*red)[256]) {
+    if (TPR <= 64) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int s = TPR / 2; s > 0; s >>= 1) v[q] += __shfl_xor(v[q], s, 64);
+        }
+        return;
+    }
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < Q; ++q) red[q][tid] = v[q];
@@ -192,36 +232,37 @@ template <int TPR, int Q> __device__ __forceinline__ void line_sums(float (&v)[Q
 
 template <int NX> __global__ __launch_bounds__(256) void holo_k1(HoloArgs A) {
     using LG = LineGeo<NX>;
-    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ cf buf[2][LG::LPB * LG::LP];
     __shared__ float2 twl[TwLds<NX>::SIZE];
     const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
     const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
-    const int y = blockIdx.x * LG::LPB + ll;
+    const int y0 = blockIdx.x * LG::LPB, y = y0 + ll;
     const bool ok = y < A.ny;
-    cf* a = buf[0] + ll * NX;
-    cf* b = buf[1] + ll * NX;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
     for (int x = t; x < NX; x += LG::TPR) {
         const size_t i = (size_t)y * NX + x;
         a[x] = ok ? cmul(A.probe[i], holo_transmission(A.obj[i], A.real_imag, A.k1, A.sigma)) : make_float2(0.f, 0.f);
     }
     __syncthreads();
     const cf* res = line_fft<NX, false>(a, b, tw, t);
-    if (ok)
-        for (int k = t; k < NX; k += LG::TPR) A.T1[(size_t)k * A.ny + y] = res[k];
+    float2* T1 = A.T1;
+    const int ny = A.ny;
+    store_lines_transposed<NX>(res - ll * LG::LP, min(LG::LPB, ny - y0), [=](int k, int c) { return T1 + HOLO_TIDX(k, ny, y0 + c, NX); });
 }
 
 // LPB adjacent lines kx per block (so that the transposed stores are LPB x 8 bytes long) and one distance per blockIdx.y: the
 // forward transform of a line is repeated for every distance (cheaper than a kernel boundary); blockIdx.y == 0 keeps F
 template <int NY> __global__ __launch_bounds__(256) void holo_k2(HoloArgs A) {
     using LG = LineGeo<NY>;
-    __shared__ cf buf[2][LG::LPB * NY];
+    __shared__ cf buf[2][LG::LPB * LG::LP];
     __shared__ float2 twl[TwLds<NY>::SIZE];
     const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
     const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
-    const int kx = blockIdx.x * LG::LPB + ll, d = blockIdx.y;
+    const int kx0 = blockIdx.x * LG::LPB, kx = kx0 + ll, d = blockIdx.y;
     const bool ok = kx < A.nx;
-    cf* a = buf[0] + ll * NY;
-    cf* b = buf[1] + ll * NY;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
     for (int j = t; j < NY; j += LG::TPR) a[j] = ok ? A.T1[(size_t)kx * NY + j] : make_float2(0.f, 0.f);
     __syncthreads();
     cf* F = line_fft<NY, false>(a, b, tw, t);
@@ -232,22 +273,23 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k2(HoloArgs A) {
     for (int k = t; k < NY; k += LG::TPR) p[k] = ok ? cmul(F[k], holo_h(A.uv2t[(size_t)kx * NY + k], dist, A.c1)) : make_float2(0.f, 0.f);
     line_sync<LG::TPR>();
     const cf* res = line_fft<NY, true>(p, F, tw, t);      // (F's buffer is free once p is filled)
-    if (ok)
-        for (int y = t; y < NY; y += LG::TPR) A.Wq[((size_t)d * NY + y) * A.nx + kx] = res[y];
+    float2* Wq = A.Wq + (size_t)d * NY * A.nx;
+    const int nx = A.nx;
+    store_lines_transposed<NY>(res - ll * LG::LP, min(LG::LPB, nx - kx0), [=](int y, int c) { return Wq + HOLO_TIDX(y, nx, kx0 + c, NY); });
 }
 
 template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(HoloArgs A) {
     using LG = LineGeo<NX>;
-    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ cf buf[2][LG::LPB * LG::LP];
     __shared__ float red[7][256];
     __shared__ float2 twl[TwLds<NX>::SIZE];
     const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
     const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
-    const int job = blockIdx.x * LG::LPB + ll;        // job = d * ny + y
+    const int job0 = blockIdx.x * LG::LPB, job = job0 + ll;        // job = d * ny + y
     const bool ok = job < A.nd * A.ny;
     const int d = ok ? job / A.ny : 0, y = ok ? job % A.ny : 0;
-    cf* a = buf[0] + ll * NX;
-    cf* b = buf[1] + ll * NX;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
     for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.Wq[((size_t)d * A.ny + y) * NX + k] : make_float2(0.f, 0.f);
     __syncthreads();
     cf* res = line_fft<NX, true>(a, b, tw, t);
@@ -316,24 +358,27 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
     if (!GRAD) return;
     line_sync<LG::TPR>();
     const cf* G = line_fft<NX, false>(oth, res, tw, t);
-    if (ok)
-        for (int k = t; k < NX; k += LG::TPR) A.T3[((size_t)d * NX + k) * ny + y] = G[k];
+    float2* T3 = A.T3;
+    store_lines_transposed<NX>(G - ll * LG::LP, min(LG::LPB, A.nd * ny - job0), [=](int k, int c) {
+        const int j = job0 + c, dd = j / ny, yy = j % ny;          // (the lines of a block may belong to different distances when ny < LPB)
+        return T3 + (size_t)dd * NX * ny + HOLO_TIDX(k, ny, yy, NX);
+    });
 }
 
 // Gh_d = FFT2(dL/dPsi_d) / n.  GF = sum_d conj(H_d) Gh_d;  dL/dd_cm = 1e7 * Re sum_k conj(Gh_d) (-i sigma PI lambda uv2) H_d F
 template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
     using LG = LineGeo<NY>;
-    static_assert(3 * LG::LPB * NY * sizeof(cf) + 256 * sizeof(float) + TwLds<NY>::SIZE * sizeof(float2) <= 64 * 1024,
+    static_assert(3 * LG::LPB * LG::LP * sizeof(cf) + 256 * sizeof(float) + TwLds<NY>::SIZE * sizeof(float2) <= 64 * 1024,
                   "holo_k4: three line buffers + reduction scratch + twiddle copy must fit the 64 KB a workgroup may allocate");
-    __shared__ cf buf[3][LG::LPB * NY];
+    __shared__ cf buf[3][LG::LPB * LG::LP];
     __shared__ float red[256];
     __shared__ float2 twl[TwLds<NY>::SIZE];
     const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
     const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
     const int kx = blockIdx.x;                        // one line per block, slot s works on distances s, s + LPB, ...
-    cf* a = buf[0] + ll * NY;
-    cf* b = buf[1] + ll * NY;
-    cf* GF = buf[2] + ll * NY;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    cf* GF = buf[2] + ll * LG::LP;
     for (int k = t; k < NY; k += LG::TPR) GF[k] = make_float2(0.f, 0.f);
     for (int d0 = 0; d0 < A.nd; d0 += LG::LPB) {
         const int d = d0 + ll;
@@ -367,14 +412,16 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
         for (int k = threadIdx.x; k < NY; k += 256) {
             cf sum = buf[2][k];
 #pragma unroll
-            for (int s_ = 1; s_ < LG::LPB; ++s_) sum = cadd(sum, buf[2][s_ * NY + k]);
+            for (int s_ = 1; s_ < LG::LPB; ++s_) sum = cadd(sum, buf[2][s_ * LG::LP + k]);
             buf[2][k] = sum;
         }
         __syncthreads();
     }
     const cf* gy = line_fft<NY, true>(GF, a, tw, t);      // (every slot runs it on its own buffers; slot 0's counts)
+    // one line kx per block: nothing to store side by side, so the line goes out as it is (T4t[kx][y], contiguous) and K5 -- whose
+    // blocks own LPB adjacent rows y -- does the transposition on its way in, LPB * 8 bytes per column
     if (ll == 0)
-        for (int y = t; y < NY; y += LG::TPR) A.T4[(size_t)y * A.nx + kx] = gy[y];
+        for (int y = t; y < NY; y += LG::TPR) A.T4[(size_t)kx * NY + y] = gy[y];
 }
 
 // the per-line sums of K3 / K4 in a fixed order: loss_sum[d] =, grad_affine[d][q] +=, grad_dists[d] += 1e7 * ...
@@ -400,15 +447,22 @@ __global__ __launch_bounds__(64) void holo_sums_kernel(HoloArgs A) { holo_sum_on
 // dL/dpsi -> dL/dobj (accumulated) and dL/dprobe (written)
 template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
     using LG = LineGeo<NX>;
-    __shared__ cf buf[2][LG::LPB * NX];
+    __shared__ cf buf[2][LG::LPB * LG::LP];
     __shared__ float2 twl[TwLds<NX>::SIZE];
     const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
     const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
     const int y = blockIdx.x * LG::LPB + ll;
     const bool ok = y < A.ny;
-    cf* a = buf[0] + ll * NX;
-    cf* b = buf[1] + ll * NX;
-    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.T4[(size_t)y * NX + k] : make_float2(0.f, 0.f);
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    // T4t[kx][y]: thread e fetches column e / LPB of row e % LPB, so LPB consecutive lanes read LPB * 8 contiguous bytes
+    {
+        const int y0 = blockIdx.x * LG::LPB, ny = A.ny;
+        for (int e = threadIdx.x; e < NX * LG::LPB; e += 256) {
+            const int c = e % LG::LPB, k = e / LG::LPB;
+            buf[0][c * LG::LP + k] = (y0 + c < ny) ? A.T4[(size_t)k * ny + y0 + c] : make_float2(0.f, 0.f);
+        }
+    }
     __syncthreads();
     const cf* res = line_fft<NX, true>(a, b, tw, t);
     if (ok)

@@ -771,11 +771,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const 
 // asked -- the drift guard of the position corrections (center_rows_kernel's sums), the pin of the first entries to fixed values,
 // and the zero fill of the gradient accumulator for the next minibatch.  These paths are launch-bound (4-5 us per launch whatever
 // its size): config-5 shape 24 -> 17 launches per minibatch, config-1 shape 17 -> 10.
-// An array without a drift guard is element-wise, so it is spread over ceil(n / SMALL_CHUNK) workgroups (five probe modes of
+// An array without a drift guard is element-wise, so it is spread over ceil(n / chunk) workgroups (five probe modes of
 // 64 x 64 took 77 us in ONE workgroup, 40 % of a config-1-shape minibatch); an array with one stays in a single workgroup
 // (its column means need every element).  first_block[i]: the first workgroup of array i; first_block[count] = grid size.
-#define SMALL_CHUNK 2048
-struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; int first_block[ADM_SMALL_PARAMS_MAX + 1]; int count; };
+// Elements per workgroup of an element-wise array: 2048 for the genuinely small ones; an array of hundreds of thousands of elements
+// (the 2-D object itself, which the driver adds to this launch on one rank) gets 256 -- one element per thread, like adam_kernel
+// (8 dependent iterations per thread made the launch 8.4 us for a 512 x 512 x 2 object against adam_kernel's 5.6 us).
+static inline int small_chunk(uint64_t n) { return n > 65536 ? 256 : 2048; }
+struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; int first_block[ADM_SMALL_PARAMS_MAX + 1]; int chunk[ADM_SMALL_PARAMS_MAX]; int count; };
 
 __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamScalars a) {
     __shared__ float red[4];
@@ -784,8 +787,9 @@ __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamSca
     while (k + 1 < sp.count && (int)blockIdx.x >= sp.first_block[k + 1]) ++k;
     const adm_small_param q = sp.p[k];
     const bool whole = q.center_cols > 0;
-    const size_t lo = whole ? 0 : (size_t)(blockIdx.x - sp.first_block[k]) * SMALL_CHUNK;
-    const size_t hi = whole ? q.n : (lo + SMALL_CHUNK < q.n ? lo + SMALL_CHUNK : q.n);
+    const size_t chunk = (size_t)sp.chunk[k];
+    const size_t lo = whole ? 0 : (size_t)(blockIdx.x - sp.first_block[k]) * chunk;
+    const size_t hi = whole ? q.n : (lo + chunk < q.n ? lo + chunk : q.n);
     a.step = (float)q.step_size;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         float mv, vv;
@@ -1247,7 +1251,8 @@ extern "C" int adm_adam_step_small(adm_ctx* ctx, const adm_small_param* params, 
         if (q.pin && q.pin_n > q.n) return fail(ADM_ERR_INVALID, "adm_adam_step_small: pin_n exceeds n");
         sp.p[k] = q;
         sp.first_block[k] = nblocks;
-        nblocks += q.center_cols > 0 ? 1 : (int)((q.n + SMALL_CHUNK - 1) / SMALL_CHUNK);
+        sp.chunk[k] = small_chunk(q.n);
+        nblocks += q.center_cols > 0 ? 1 : (int)((q.n + sp.chunk[k] - 1) / sp.chunk[k]);
     }
     sp.first_block[count] = nblocks;
     sp.count = count;

@@ -138,15 +138,26 @@ def apply_small_params(ctx, items, i_batch):
              float(it['opt'].options_dict.get('eps', 1e-7))) for it in items}
     plain = all(type(it['opt']) is AdamOptimizer and set(it['opt'].options_dict) <= {'step_size', 'b1', 'b2', 'eps'} for it in items)
     if plain and len(keys) == 1 and len(items) <= SMALL_PARAMS_MAX:
-        arr = (SmallParam * len(items))()
-        for k, it in enumerate(items):
-            o = it['opt']
-            pin = it.get('pin')
-            arr[k] = SmallParam(x=it['x'].ptr, g=it['g'].ptr, m=o.params_whole_array_dict['m'].ptr, v=o.params_whole_array_dict['v'].ptr,
-                                n=it['x'].size, step_size=float(o.options_dict.get('step_size', 0.001)),
-                                center_cols=int(it.get('center_cols', 0)), zero_grad=1 if it.get('zero_grad') else 0,
-                                pin=pin.ptr if pin is not None else None, pin_n=pin.size if pin is not None else 0)
-            o.i_batch += 1
+        # the descriptor array is the same minibatch after minibatch (same buffers, same step sizes): build it once per combination
+        sig = tuple((it['x'].ptr, it['g'].ptr, it['opt'].params_whole_array_dict['m'].ptr, it['opt'].params_whole_array_dict['v'].ptr,
+                     it['x'].size, float(it['opt'].options_dict.get('step_size', 0.001)), int(it.get('center_cols', 0)),
+                     bool(it.get('zero_grad')), it['pin'].ptr if it.get('pin') is not None else 0) for it in items)
+        cache = ctx.__dict__.setdefault('_small_param_descs', {})
+        arr = cache.get(sig)
+        if arr is None:
+            if len(cache) > 64:
+                cache.clear()
+            arr = (SmallParam * len(items))()
+            for k, it in enumerate(items):
+                o = it['opt']
+                pin = it.get('pin')
+                arr[k] = SmallParam(x=it['x'].ptr, g=it['g'].ptr, m=o.params_whole_array_dict['m'].ptr, v=o.params_whole_array_dict['v'].ptr,
+                                    n=it['x'].size, step_size=float(o.options_dict.get('step_size', 0.001)),
+                                    center_cols=int(it.get('center_cols', 0)), zero_grad=1 if it.get('zero_grad') else 0,
+                                    pin=pin.ptr if pin is not None else None, pin_n=pin.size if pin is not None else 0)
+            cache[sig] = arr
+        for it in items:
+            it['opt'].i_batch += 1
         b1, b2, eps = next(iter(keys))
         check(ctx.lib.adm_adam_step_small(ctx.handle, arr, len(items), int(i_batch), b1, b2, eps))
         return

@@ -164,8 +164,12 @@ def bench_c1(ctx, steps=50):
     # the driver's optimiser objects and its ONE launch for the small parameters (adorym_amd/ptychography.py)
     o_probe = AdamOptimizer('probe', options_dict={'step_size': 1e-3}); o_probe.create_param_arrays(list(probe.shape), device=ctx)
     o_pos = AdamOptimizer('probe_pos_correction', options_dict={'step_size': 1e-2}); o_pos.create_param_arrays(list(corr.shape), device=ctx)
+    o_obj = AdamOptimizer('obj', options_dict={'step_size': 1e-3}); o_obj.params_whole_array_dict = {'m': m, 'v': v}
+    obj_flat, g_flat = obj.view(0, (obj.size,)), g.view(0, (g.size,))
     ring = ctx.uploader()
     pending = [None]
+    ev = [ctx.event(), ctx.event()]
+    timed = [False]
 
     def step(k):
         s = (k * B) % (len(pos_int) - B)
@@ -174,11 +178,15 @@ def bench_c1(ctx, steps=50):
         ring.upload(idx, np.arange(s, s + B, dtype=np.int32))          # asynchronous, like the driver's per-minibatch uploads
         eng.rotate(obj, None, None)
         g.zero_()
+        if timed[0]:
+            ev[0].record()
         eng.multislice(probe, grad_probe=gp, shifts=corr, shift_index=idx, grad_shifts=gc)
+        if timed[0]:
+            ev[1].record()
         eng.rotate_adjoint(g, None, None)
         check(lib.adm_reg_grad(eng.plan.handle, obj.ptr, 0., 0., 1e-6, g.ptr, None))
-        check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-3, 0.9, 0.999, 1e-7, 0, None))
-        apply_small_params(ctx, [dict(opt=o_probe, x=probe, g=gp, zero_grad=True),
+        # (as the driver does for a small unconstrained object on one rank: the object is one more array of the one launch)
+        apply_small_params(ctx, [dict(opt=o_obj, x=obj_flat, g=g_flat), dict(opt=o_probe, x=probe, g=gp, zero_grad=True),
                                  dict(opt=o_pos, x=corr, g=gc, center_cols=2, zero_grad=True)], 0)
         tok = eng.loss_async()
         out = eng.loss_result(pending[0]) if pending[0] is not None else None     # the PREVIOUS minibatch's loss: no pipeline drain
@@ -191,11 +199,27 @@ def bench_c1(ctx, steps=50):
     t0 = time.perf_counter()
     for k in range(steps):
         step(3 + k)
+    t_issue = (time.perf_counter() - t0) / steps
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
+    timed[0] = True
+    ks = []
+    for k in range(10):
+        step(3 + steps + k)
+        ks.append(ev[0].elapsed_ms(ev[1]))
+    timed[0] = False
+    kern = float(np.median(ks))
+    # SURVEY 8(d)'s byte count at this shape: tile data read fwd + read bwd + gradient written (S = 1), measured intensities, the
+    # object read once and its gradient written once; plus the M probe modes read and their gradient written
+    V = Y * X
+    alg = 4 * (3 * B * P * P * 1 * 2 + B * P * P + 2 * (2 * V)) + 2 * 4 * (M * P * P * 2)
     tc = bench.cpu_baseline_c1(obj_h, pos, pos_int, probe_h, B, P, energy, psize)
-    return {'row': 'f2 / config-1 shape', 'workload': '2-D ptychography 618x606x1 real_imag, P=64, 5 modes, minibatch 35, object+probe+position Adam, TV',
-            'value': B / dt, 'unit': 'probe-positions/s', 'ms_per_step': 1e3 * dt,
+    return {'row': 'f2 / config-1 shape', 'dtype': 'f32',
+            'roofline': {'bound': 'latency (a chain of 10 launches of 4-60 us; 35 workgroups on 256 CUs in the dominant one) -- priced against hbm',
+                         'kernel': 'probe_shift + ms_fwd_adj_kernel<64,8,8,...,MULTI> + probe_shift_adj (the forward+adjoint launch group, HIP events)',
+                         'achieved': alg / (kern * 1e-3) / 1e9, 'peak': bench.PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': alg / (kern * 1e-3) / 1e9 / bench.PEAK_HBM_GBS,
+                         'kernel_ms': kern, 'algorithmic_bytes_per_launch': alg, 'whole_step_frac': alg / dt / 1e9 / bench.PEAK_HBM_GBS, 'traffic': None}, 'workload': '2-D ptychography 618x606x1 real_imag, P=64, 5 modes, minibatch 35, object+probe+position Adam, TV',
+            'value': B / dt, 'unit': 'probe-positions/s', 'ms_per_step': 1e3 * dt, 'host_issue_ms_per_step': 1e3 * t_issue,
             'cpu_baseline': {'value': B / tc, 'unit': 'probe-positions/s', 'cores': 1, 'kind': 'port',
                              'sample': 'one minibatch fwd+adjoint incl. probe shifts, oracle fp32 (optimiser and regulariser excluded)'}}
 
@@ -221,12 +245,19 @@ def bench_c5(ctx, steps=50):
     lib = ctx.lib
     o_d = AdamOptimizer('free_prop_cm', options_dict={'step_size': 1e-1}); o_d.create_param_arrays([nd], device=ctx)
     o_a = AdamOptimizer('prj_affine_ls', options_dict={'step_size': 1e-3}); o_a.create_param_arrays(list(aff.shape), device=ctx)
+    o_obj = AdamOptimizer('obj', options_dict={'step_size': 1e-2}); o_obj.params_whole_array_dict = {'m': m, 'v': v}
+    obj_flat, g_flat = obj.view(0, (obj.size,)), g.view(0, (g.size,))
     pending = [None]
+    ev = [ctx.event(), ctx.event()]
+    timed = [False]
 
     def step():
+        if timed[0]:
+            ev[0].record()
         eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd, grad_affine=ga, overwrite=True)
-        check(lib.adm_adam_step(ctx.handle, obj.ptr, g.ptr, m.ptr, v.ptr, 0, obj.size, 0, 1e-2, 0.9, 0.999, 1e-7, 0, None))
-        apply_small_params(ctx, [dict(opt=o_d, x=dists, g=gd), dict(opt=o_a, x=aff, g=ga, pin=ident)], 0)
+        if timed[0]:
+            ev[1].record()
+        apply_small_params(ctx, [dict(opt=o_obj, x=obj_flat, g=g_flat), dict(opt=o_d, x=dists, g=gd), dict(opt=o_a, x=aff, g=ga, pin=ident)], 0)
         tok = eng.loss_async()
         out = pending[0]() if pending[0] is not None else None           # the PREVIOUS minibatch's loss
         pending[0] = tok
@@ -238,17 +269,37 @@ def bench_c5(ctx, steps=50):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    t_issue = (time.perf_counter() - t0) / steps          # host time to queue a minibatch (if ~ dt, the host is the bound)
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
+    timed[0] = True
+    ks = []
+    for _ in range(10):
+        step()
+        ks.append(ev[0].elapsed_ms(ev[1]))
+    timed[0] = False
+    kern = float(np.median(ks))
     tc = bench.cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize)
-    # algorithmic bytes of one step: read obj+probe, read 4 holograms, write grad (fields stay on chip in principle)
-    return {'row': 'f1 / config-5 shape', 'workload': 'multi-distance holography 512x512x1 real_imag, 4 distances, object+distance+affine Adam',
-            'value': 1.0 / dt, 'unit': 'minibatches/s (4 holograms each)', 'ms_per_step': 1e3 * dt,
+    # algorithmic bytes of one minibatch (SURVEY 8d's rule: compulsory traffic only, intermediates are the design's): object and
+    # probe read, the nd holograms read, object gradient written
+    alg = 4 * (2 * N * N + 2 * N * N + nd * N * N + 2 * N * N)
+    # the transforms of one minibatch: FFT2(psi), nd inverse, nd forward, one inverse = 2 nd + 2 transforms of 5 N^2 log2(N^2) flop
+    flop = (2 * nd + 2) * 5.0 * N * N * np.log2(N * N)
+    return {'row': 'f1 / config-5 shape', 'dtype': 'f32',
+            'roofline': {'bound': 'latency (five dependent line-transform kernels of 128-512 workgroups; all intermediates stay in L2 / Infinity Cache) -- priced against hbm',
+                         'kernel': 'holo_k1..k5<512> (the forward+adjoint launch group, HIP events)', 'achieved': alg / (kern * 1e-3) / 1e9,
+                         'peak': bench.PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': alg / (kern * 1e-3) / 1e9 / bench.PEAK_HBM_GBS, 'kernel_ms': kern,
+                         'algorithmic_bytes_per_launch': alg, 'whole_step_frac': alg / dt / 1e9 / bench.PEAK_HBM_GBS, 'traffic': None,
+                         'transform_tflops': flop / (kern * 1e-3) / 1e12}, 'workload': 'multi-distance holography 512x512x1 real_imag, 4 distances, object+distance+affine Adam',
+            'value': 1.0 / dt, 'unit': 'minibatches/s (4 holograms each)', 'ms_per_step': 1e3 * dt, 'host_issue_ms_per_step': 1e3 * t_issue,
             'cpu_baseline': {'value': 1.0 / tc, 'unit': 'minibatches/s', 'cores': 1, 'kind': 'port',
                              'sample': 'one fwd+adjoint of the 4-distance chain, oracle fp32 (optimiser excluded)'}}
 
 
 if __name__ == '__main__':
+    # python tools/bench_rows.py [c2] [c1] [c5]   (default: all three; one name = one row, e.g. under rocprofv3 --stats)
+    rows = {'c2': bench_c2, 'c1': bench_c1, 'c5': bench_c5}
+    want = [a for a in sys.argv[1:] if a in rows] or ['c2', 'c1', 'c5']
     ctx = A.Context(0)
-    for fn in (bench_c2, bench_c1, bench_c5):
-        print(json.dumps(fn(ctx)))
+    for name in want:
+        print(json.dumps(rows[name](ctx)))
