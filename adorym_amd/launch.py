@@ -14,6 +14,7 @@ given a grace period, then terminated, then -- if SIGTERM does not end them -- k
 collective for ever); SIGTERM to the launcher itself takes the same path, and every child is reaped before run() returns.
 """
 import os
+import secrets
 import signal
 import socket
 import subprocess
@@ -35,11 +36,12 @@ def rank_envs(n, base=None, port=None, job=None):
     base = dict(os.environ if base is None else base)
     port = int(port) if port is not None else free_port()
     job = job or 'adm-%d-%d' % (os.getpid(), port)
+    token = base.get('ADM_RDV_TOKEN') or secrets.token_hex(16)      # the job's shared secret for the control plane's handshake
     envs = []
     for r in range(int(n)):
         e = dict(base)
         e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
-                 MASTER_PORT=str(port), ADM_RDV_PORT=str(port), ADM_RDV_JOB=job)
+                 MASTER_PORT=str(port), ADM_RDV_PORT=str(port), ADM_RDV_JOB=job, ADM_RDV_TOKEN=token)
         e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's intra-node transport needs it on this driver
         e.pop('TORCHELASTIC_RUN_ID', None)
         envs.append(e)

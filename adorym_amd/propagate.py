@@ -501,9 +501,17 @@ class AngleBatch(object):
         self.R = int(n_angles)
         Y, X, Z = self.obj_size
         y0, x0 = int(probe_pos[0]), int(probe_pos[1])
+        Py = int(probe_size[0])
+        # a probe that leaves its block along y would read the NEIGHBOURING angle's planes instead of vacuum and scatter its
+        # gradient into the wrong block: the stack only stands in for R separate objects while every tile stays inside its own
+        if self.R < 1 or y0 < 0 or y0 + Py > Y:
+            raise ValueError('AngleBatch: the probe must lie inside the object along y (0 <= y0 and y0 + probe_y <= Y); got y0 = %d, '
+                             'probe_y = %d, Y = %d' % (y0, Py, Y))
         self.pos = np.array([(r * Y + y0, x0) for r in range(self.R)], dtype=np.int64)
         engine_kwargs.setdefault('max_batch', self.R)
         self.engine = MultisliceEngine(ctx, (self.R * Y, X, Z), probe_size, self.pos, energy_ev, psize_cm, **engine_kwargs)
+        if tuple(self.engine.plan.pads[0]) != (0, 0):
+            raise ValueError('AngleBatch: unexpected y padding %s of the stacked geometry' % (self.engine.plan.pads[0],))
         self.block_bytes = Y * X * Z * 2 * 4
 
     def _shifted(self, arr, r):
@@ -515,6 +523,12 @@ class AngleBatch(object):
         (host or device).  grad_obj += sum over angles of d(mean loss of angle r)/d obj.  Returns the R losses (blocking)."""
         eng = self.engine
         Y = self.obj_size[0]
+        if len(tables) != self.R:
+            raise ValueError('AngleBatch.loss_and_grad: %d rotation tables for %d angles' % (len(tables), self.R))
+        n_t = targets.size if hasattr(targets, 'size') else np.asarray(targets).size
+        if n_t != self.R * eng.n_det:
+            raise ValueError('AngleBatch.loss_and_grad: targets must hold R x Py x Px = %d values, got %d' % (self.R * eng.n_det, n_t))
+        # (the shifted base pointers below rely on the rotation kernels touching only the planes [r*Y, (r+1)*Y) they are given)
         eng.set_batch(self.pos, targets)
         for r, t in enumerate(tables):
             eng.rotate(self._shifted(obj, r), t, (r * Y, (r + 1) * Y))

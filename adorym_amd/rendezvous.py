@@ -9,20 +9,87 @@ socket; every operation is a collective issued in the same order on every rank, 
 the operation, so a mismatched sequence raises instead of deadlocking silently.
 
 Environment (the variables torch.distributed.run, mpirun wrappers and bench.py's own launcher set): RANK, WORLD_SIZE,
-MASTER_ADDR, MASTER_PORT; optional ADM_RDV_PORT (exact port of the star), ADM_RDV_TIMEOUT (seconds, default 300).
+MASTER_ADDR, MASTER_PORT; optional ADM_RDV_PORT (exact port of the star), ADM_RDV_TIMEOUT (seconds for the ranks to find each
+other, default 300), ADM_RDV_OP_TIMEOUT (seconds a collective may wait for a late rank, default 3600, 0 = for ever),
+ADM_RDV_TOKEN (the job's shared secret, set by adorym_amd/launch.py: only peers that know it pass the handshake).  Rank 0
+listens on MASTER_ADDR's interface only; control-plane objects travel as a JSON tree plus raw blobs, never as pickles.
 Under torch.distributed.run MASTER_PORT itself belongs to the launcher's own store, so the star takes the first free
 port ABOVE it; peers find it by a handshake that carries the job id (TORCHELASTIC_RUN_ID or the port number).
 """
+import hashlib
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import time
 
 import numpy as np
 
-_MAGIC = b'ADMRDV1\0'
+_MAGIC = b'ADMRDV2\0'
 _SCAN = 32            # ports tried above the base port
+
+
+# ---- control-plane objects on the wire: a JSON tree + raw blobs (no pickle: a peer's frame is data, never code) --------------------
+def _pack_obj(obj):
+    """None / bool / int / float / str / bytes / NumPy arrays and scalars / lists, tuples and str-keyed dicts of those."""
+    blobs = []
+
+    def enc(o):
+        if o is None or isinstance(o, (bool, int, float, str)):
+            return o
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (np.floating,)):
+            return float(o)
+        if isinstance(o, (bytes, bytearray, memoryview)):
+            blobs.append(bytes(o))
+            return {'__b__': len(blobs) - 1}
+        if isinstance(o, np.ndarray):
+            a = np.ascontiguousarray(o)
+            if a.dtype.hasobject:
+                raise TypeError('rendezvous: object arrays cannot travel over the control plane')
+            blobs.append(a.tobytes())
+            return {'__nd__': len(blobs) - 1, 'dtype': a.dtype.str, 'shape': list(a.shape)}
+        if isinstance(o, tuple):
+            return {'__t__': [enc(v) for v in o]}
+        if isinstance(o, list):
+            return [enc(v) for v in o]
+        if isinstance(o, dict) and all(isinstance(k, str) for k in o):
+            return {'__d__': {k: enc(v) for k, v in o.items()}}
+        raise TypeError('rendezvous: cannot send an object of type %s over the control plane' % type(o).__name__)
+
+    head = json.dumps({'tree': enc(obj), 'sizes': [len(b) for b in blobs]}).encode('utf-8')
+    return struct.pack('!I', len(head)) + head + b''.join(blobs)
+
+
+def _unpack_obj(buf):
+    nh = struct.unpack('!I', buf[:4])[0]
+    head = json.loads(bytes(buf[4:4 + nh]).decode('utf-8'))
+    offs, pos = [], 4 + nh
+    for n in head['sizes']:
+        offs.append((pos, n))
+        pos += n
+    if pos != len(buf):
+        raise RuntimeError('rendezvous: malformed control-plane frame')
+
+    def dec(o):
+        if isinstance(o, list):
+            return [dec(v) for v in o]
+        if isinstance(o, dict):
+            if '__b__' in o:
+                a, n = offs[o['__b__']]
+                return bytes(buf[a:a + n])
+            if '__nd__' in o:
+                a, n = offs[o['__nd__']]
+                return np.frombuffer(bytes(buf[a:a + n]), dtype=np.dtype(o['dtype'])).reshape(o['shape']).copy()
+            if '__t__' in o:
+                return tuple(dec(v) for v in o['__t__'])
+            if '__d__' in o:
+                return {k: dec(v) for k, v in o['__d__'].items()}
+        return o
+
+    return dec(head['tree'])
 
 
 def _send_frame(sock, tag, payload):
@@ -59,15 +126,23 @@ def _recv_frame(sock, tag, into=None):
 class TcpGroup(object):
     """rank / size + the collectives of the control plane.  ``TcpGroup.from_env()`` reads the launcher's variables."""
 
-    def __init__(self, rank, size, addr='127.0.0.1', port=29511, job='', exact_port=False, timeout=None):
+    def __init__(self, rank, size, addr='127.0.0.1', port=29511, job='', exact_port=False, timeout=None, token=None):
         self.rank, self.size = int(rank), int(size)
+        # ADM_RDV_TIMEOUT bounds the connection set-up only; a collective may legitimately wait much longer for a rank that is
+        # loading data or writing a checkpoint (ADM_RDV_OP_TIMEOUT, default one hour; 0 = no limit)
         self.timeout = float(timeout if timeout is not None else os.environ.get('ADM_RDV_TIMEOUT', '300'))
+        op = float(os.environ.get('ADM_RDV_OP_TIMEOUT', '3600'))
+        self.op_timeout = op if op > 0 else None
+        # the job's shared secret (launch.py puts a random one into every rank's environment): only a peer that knows it gets past
+        # the handshake.  Absent under foreign launchers: the handshake then rests on the job id alone, as before.
+        token = os.environ.get('ADM_RDV_TOKEN', '') if token is None else token
         self._peers = {}          # rank 0: {rank: socket}
         self._root = None         # other ranks: socket to rank 0
         self._closed = False
         if self.size == 1:
             return
-        hello = _MAGIC + struct.pack('!I', len(job)) + job.encode('utf-8')
+        proof = hmac.new(token.encode('utf-8'), b'adm-rendezvous:' + job.encode('utf-8'), hashlib.sha256).digest()
+        hello = _MAGIC + struct.pack('!I', len(job)) + job.encode('utf-8') + proof
         ports = [int(port)] if exact_port else [int(port) + k for k in range(_SCAN)]
         deadline = time.time() + self.timeout
         if self.rank == 0:
@@ -76,7 +151,8 @@ class TcpGroup(object):
                 try:
                     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                    srv.bind(('127.0.0.1' if addr in ('127.0.0.1', 'localhost') else '', p))
+                    # listen on MASTER_ADDR's own interface (loopback for a one-node job), never on all of them
+                    srv.bind((socket.gethostbyname(addr), p))
                     break
                 except OSError as e:
                     err = e
@@ -97,14 +173,14 @@ class TcpGroup(object):
                     c.settimeout(5.0)
                     got = bytes(_recv_exact(c, len(hello)))
                     r = struct.unpack('!I', bytes(_recv_exact(c, 4)))[0]
-                    if got != hello or not (0 < r < self.size) or r in self._peers:
+                    if not hmac.compare_digest(got, hello) or not (0 < r < self.size) or r in self._peers:
                         raise ConnectionError('foreign connection')
                     c.sendall(_MAGIC)
                 except Exception:
                     c.close()           # not one of this job's ranks (a port scanner, another job): ignore it
                     continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(self.timeout)
+                c.settimeout(self.op_timeout)
                 self._peers[r] = c
             srv.close()
         else:
@@ -130,7 +206,7 @@ class TcpGroup(object):
                                            % (self.rank, addr, ports, self.timeout))
                     time.sleep(0.05)
             sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            sock.settimeout(self.timeout)
+            sock.settimeout(self.op_timeout)
             self._root = sock
 
     @classmethod
@@ -171,10 +247,10 @@ class TcpGroup(object):
             return obj
         if root != 0:           # the owner hands it to rank 0 first
             if self.rank == root:
-                _send_frame(self._root, 'bcast>', pickle.dumps(obj))
+                _send_frame(self._root, 'bcast>', _pack_obj(obj))
             elif self.rank == 0:
-                obj = pickle.loads(_recv_frame(self._peers[root], 'bcast>'))
-        return pickle.loads(self._scatter_same('bcast', pickle.dumps(obj) if self.rank == 0 else b''))
+                obj = _unpack_obj(_recv_frame(self._peers[root], 'bcast>'))
+        return _unpack_obj(self._scatter_same('bcast', _pack_obj(obj) if self.rank == 0 else b''))
 
     def _reduce_scalar(self, value, fn, tag):
         if self.size == 1:

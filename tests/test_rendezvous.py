@@ -142,3 +142,43 @@ def test_missing_rank_is_a_clean_error_not_a_hang():
         TcpGroup(0, 2, '127.0.0.1', _free_port(), job='lonely', exact_port=True, timeout=1.5)
     with pytest.raises(RuntimeError, match='could not reach rank 0'):
         TcpGroup(1, 2, '127.0.0.1', _free_port(), job='lonely', exact_port=True, timeout=1.5)
+
+
+def test_control_plane_objects_travel_without_pickle():
+    """What the driver broadcasts (RCCL ids as bytes, time stamps, seeds, counters, initial guesses and probes as arrays) survives
+    the JSON + blob codec unchanged; anything else is refused on the sending side (no pickle on the wire)."""
+    sys.path.insert(0, ROOT)
+    from adorym_amd.rendezvous import _pack_obj, _unpack_obj
+    r = np.random.default_rng(0)
+    obj = [b'\x00\x01' * 64, ('2026_10_03', 7, 2.5, None, True), {'a': r.standard_normal((3, 4)).astype(np.float32), 'b': np.arange(5)},
+           [np.float32(1.5), np.int64(3)], r.standard_normal((2, 2)) + 1j * r.standard_normal((2, 2))]
+    back = _unpack_obj(_pack_obj(obj))
+    assert back[0] == obj[0] and back[1] == obj[1] and isinstance(back[1], tuple)
+    assert np.array_equal(back[2]['a'], obj[2]['a']) and back[2]['a'].dtype == np.float32 and np.array_equal(back[2]['b'], obj[2]['b'])
+    assert back[3] == [1.5, 3] and np.array_equal(back[4], obj[4])
+    with pytest.raises(TypeError):
+        _pack_obj({'f': open})
+    assert b'pickle' not in open(os.path.join(ROOT, 'adorym_amd', 'rendezvous.py'), 'rb').read().replace(b'as pickles', b'').replace(b'no pickle', b'')
+
+
+def test_a_peer_without_the_job_token_is_not_admitted():
+    """Rank 0 admits only peers whose hello carries the HMAC of the job's token; a connection with the right job id but another
+    token is dropped like any foreign connection, and rank 0 reports the missing rank after its time-out."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from adorym_amd.rendezvous import TcpGroup
+    port = _free_port()
+    errs = {}
+
+    def rank0():
+        try:
+            TcpGroup(0, 2, '127.0.0.1', port, job='j', exact_port=True, timeout=2.0, token='right')
+        except Exception as e:
+            errs[0] = e
+
+    t = threading.Thread(target=rank0)
+    t.start()
+    with pytest.raises(RuntimeError, match='could not reach rank 0'):
+        TcpGroup(1, 2, '127.0.0.1', port, job='j', exact_port=True, timeout=1.5, token='wrong')
+    t.join(10)
+    assert 'only 1 of 2 ranks connected' in str(errs.get(0))
