@@ -272,6 +272,7 @@ class PtychographyModel(ForwardModel):
             eng.rotate(obj, coords, yr)
         ctx.fork()
         eng.flush_loss_copy()       # the previous minibatch's loss read-back: on the side stream, beside this kernel
+        self._flush_reg_copy()      # ... and its regulariser value (before the kernel below overwrites it)
         if side_hook is not None:
             side_hook()
         # init_grad: grad_obj is uninitialised -- the regulariser kernel writes it (one pass) or it is zero-filled
@@ -336,6 +337,7 @@ class PtychographyModel(ForwardModel):
         current stream.  ``init_grad``: grad_obj holds garbage and is initialised here (regulariser kernel in 'set' mode,
         or a zero fill).  ``value_only``: no gradient at all (plain L1 / TV).  Returns True if a value is pending."""
         from .regularizers import ReweightedL1Regularizer
+        self._flush_reg_copy()      # the previous value leaves before this launch overwrites it
         ad, ab, gm = combined_weights(self.reg_list)
         rw = [r for r in self.reg_list if isinstance(r, ReweightedL1Regularizer)]
         plain = ad != 0 or ab != 0 or gm != 0
@@ -368,7 +370,11 @@ class PtychographyModel(ForwardModel):
         return True
 
     def _reg_value_async(self, pending):
-        """Queue the read-back of the regulariser value (after the join); returns a callable giving the float."""
+        """Register the read-back of the regulariser value; returns a callable giving the float.  Like the data term's sums
+        (MultisliceEngine.loss_async) the 4-byte copy itself is DEFERRED: it is queued by the next evaluation inside its
+        side-stream region, before the regulariser kernel that overwrites the value -- on the main stream it sat between the
+        back-rotation and the optimiser kernel with its dependency gap (~12 us per minibatch) -- or by the callable, whichever
+        comes first."""
         if not pending:
             return lambda: 0.0
         from .device import PinnedArray, Event
@@ -376,16 +382,26 @@ class PtychographyModel(ForwardModel):
             self._reg_pinned = [PinnedArray(self.device, (1,)) for _ in range(2)]
             self._reg_events = [Event(self.device) for _ in range(2)]
             self._reg_slot = 0
+        self._flush_reg_copy()
         self._reg_slot ^= 1
         k = self._reg_slot
-        self._reg_pinned[k].copy_from_async(self._reg_val, 4)
-        self._reg_events[k].record()
+        self._reg_deferred = k
         g = float(self.batch_group)
 
         def value():
+            if getattr(self, '_reg_deferred', None) == k:
+                self._flush_reg_copy()
             self._reg_events[k].synchronize()
             return float(self._reg_pinned[k].array[0]) / g
         return value
+
+    def _flush_reg_copy(self):
+        """Queue the deferred regulariser-value read-back, if any, on the stream the context is enqueuing on right now."""
+        k = getattr(self, '_reg_deferred', None)
+        if k is not None:
+            self._reg_deferred = None
+            self._reg_pinned[k].copy_from_async(self._reg_val, 4)
+            self._reg_events[k].record()
 
     def _regularize(self, obj, grad_obj):
         """Adds the regulariser gradient to grad_obj (if given) and returns the regulariser value (blocking)."""
