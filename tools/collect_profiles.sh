@@ -12,6 +12,9 @@ for B in 32 256; do
   cp $(find $SRC/${TAG}_kbench_B${B}_stats -name "*kernel_stats.csv" | head -1) $DST/${TAG}_kbench_B${B}_kernel_stats.csv
   cp $SRC/${TAG}_pmc_B$B/summary.json $DST/${TAG}_pmc_B$B.json
 done
+for N in 2 4; do cp $SRC/${TAG}_bench_p2p$N.json $DST/${TAG}_bench_p2p${N}_one_gpu.json; done
+cp $(find $SRC/${TAG}_p2p2_stats -name "*kernel_stats.csv" | head -1) $DST/${TAG}_bench_p2p2_rank0_kernel_stats.csv
+for R in c1 c5; do cp $(find $SRC/${TAG}_rows_${R}_stats -name "*kernel_stats.csv" | head -1) $DST/${TAG}_bench_rows_${R}_kernel_stats.csv; done
 cp $SRC/${TAG}_timeline_none.txt $DST/${TAG}_timeline_B32.txt
 cp $SRC/${TAG}_timeline_per_angle.txt $DST/${TAG}_timeline_per_angle.txt
 cp $SRC/${TAG}_timeline_vr16.txt $DST/${TAG}_timeline_vr16.txt
