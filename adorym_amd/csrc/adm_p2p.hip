@@ -278,7 +278,40 @@ extern "C" int adm_p2p_open(adm_ctx* ctx, const void* handle64, void** dptr) {
     ADM_HIP(hipSetDevice(ctx->device));
     hipIpcMemHandle_t h;
     std::memcpy(&h, handle64, sizeof h);
-    ADM_HIP(hipIpcOpenMemHandle(dptr, h, hipIpcMemLazyEnablePeerAccess));
+    void* p = nullptr;
+    ADM_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    // The mapping must be usable by this GPU's KERNELS: a pointer they cannot reach is a memory fault that takes the process
+    // down, not an error code.  So before anybody launches on it: if the allocation lives on another device, that device must
+    // be a peer this one can access (and access is switched on explicitly, whatever the lazy flag did), and a 4-byte copy
+    // through the mapping must succeed.
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.device != ctx->device) {
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, ctx->device, attr.device);
+        if (e != hipSuccess || !can) {
+            (void)hipGetLastError();
+            (void)hipIpcCloseMemHandle(p);
+            return fail(ADM_ERR_UNSUPPORTED, "adm_p2p_open: device " + std::to_string(ctx->device) + " cannot access device " +
+                                                 std::to_string(attr.device) + " as a peer");
+        }
+        e = hipDeviceEnablePeerAccess(attr.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            (void)hipIpcCloseMemHandle(p);
+            return adm::hip_fail(e, "hipDeviceEnablePeerAccess");
+        }
+        (void)hipGetLastError();
+    } else {
+        (void)hipGetLastError();
+    }
+    unsigned int probe = 0;
+    hipError_t e = hipMemcpy(&probe, p, sizeof probe, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipIpcCloseMemHandle(p);
+        return adm::hip_fail(e, "adm_p2p_open: reading through the mapping");
+    }
+    *dptr = p;
     return ADM_OK;
 }
 

@@ -97,6 +97,126 @@ def test_reduce_scatter_adam_allgather_world2(shape):
         assert mx == world - 1 and sm == world
 
 
+# ---- the p2p branch of DataParallelObject on CPU: a stand-in transport with P2PComm's interface (bind_object / fused_update) whose
+# "peer buffers" travel over gloo, with the fused kernel's arithmetic restated in NumPy: rank-order sum on [sum_lo, sum_hi), the
+# owner's own buffer elsewhere, optimiser on the shard, result written into every replica
+def _p2p_worker(rank, world, port, shape, seed, restricted, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from torch_comm import TorchComm
+    from adorym_amd.dp import DataParallelObject
+    from oracle import adorym_oracle as O
+    import torch
+
+    class Buf(np.ndarray):          # an ndarray that answers to the two DeviceArray members the p2p branch touches
+        @property
+        def ptr(self):
+            return self.ctypes.data
+
+    class NumpyOpsP2P(NumpyOps):
+        def alloc(self, n):
+            return np.zeros(n, np.float32).view(Buf)
+
+    class FakeP2P(TorchComm):
+        def __init__(self):
+            TorchComm.__init__(self, 'gloo')
+            self.backend = 'p2p'
+
+        def bind_object(self, obj, grad, n):
+            self.x, self.g, self.n_pad = obj, grad, n
+
+        def _gather_all(self, arr):
+            parts = [torch.empty(len(arr), dtype=torch.float32) for _ in range(self.size)]
+            self.dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)))
+            return [p_.numpy() for p_ in parts]
+
+        def fused_update(self, kind, m, v, lo, hi, sum_lo, sum_hi, i_batch, step_size, b1, b2, eps, flags, mask):
+            gs = self._gather_all(np.asarray(self.g))               # "reading the peers' gradient buffers"
+            i = np.arange(lo, hi)
+            ins = (i >= sum_lo) & (i < sum_hi)
+            acc = gs[0][lo:hi].copy()
+            for q in range(1, self.size):
+                acc = acc + gs[q][lo:hi]
+            gsum = np.where(ins, acc, gs[self.rank][lo:hi]).astype(np.float32)
+            x = np.asarray(self.x)
+            if kind == 0:
+                xs, ms, vs = O.adam_step(x[lo:hi], gsum, np.asarray(m)[:hi - lo], np.asarray(v)[:hi - lo], i_batch, step_size, b1, b2, eps)
+                if flags & 1:
+                    xs = np.clip(xs, 0, None)
+                m[:hi - lo] = ms; v[:hi - lo] = vs
+            else:
+                xs = x[lo:hi] - np.float32(step_size) * gsum
+            mine = np.zeros(self.n_pad // self.size, np.float32)
+            mine[:hi - lo] = xs
+            full = np.concatenate(self._gather_all(mine))           # "writing every replica"
+            self.x[:] = full
+
+    comm = FakeP2P()
+    try:
+        st = DataParallelObject(NumpyOpsP2P(), comm, shape)
+        assert st.p2p and st.inplace
+        n = st.n
+        x0 = (np.random.default_rng(seed).standard_normal(n) * 1e-3).astype(np.float32)
+        st.obj[:n] = x0
+        t_lo, t_hi = (2 * (n // 8), 2 * (3 * n // 8)) if restricted else (0, n)
+        for it in range(3):
+            g_all = [np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world)]
+            reg = (np.arange(n) % 5 - 2).astype(np.float32) * np.float32(0.1)
+            if restricted:
+                st.grad[:] = np.nan                                   # nothing outside the touched range may be read from a peer
+                st.grad[t_lo:t_hi] = g_all[rank][t_lo:t_hi]
+
+                def reg_shard(lo, hi, a_lo, a_hi):
+                    i = np.arange(lo, hi)
+                    ins = (i >= a_lo) & (i < a_hi)
+                    cur = np.asarray(st.grad[lo:hi]).copy()
+                    st.grad[lo:hi] = np.where(ins, cur + world * reg[lo:hi], world * reg[lo:hi])
+                st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1, touched=(t_lo, t_hi), reg_shard=reg_shard)
+            else:
+                st.grad[:n] = g_all[rank] + reg
+                st.exchange_and_update('adam', it, {'step_size': 1e-4}, flags=1, first=(0, 10))
+        st.grad[:n] = 1.0
+        st.exchange_and_update('gd', 0, {'step_size': 1e-5})
+        out_q.put((rank, np.array(st.obj[:n])))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize('restricted', [False, True])
+def test_p2p_branch_of_the_sharded_update_world2(restricted):
+    """DataParallelObject with a transport of P2PComm's shape (backend 'p2p', bind_object, fused_update): full exchange and the
+    footprint-restricted one (peers' buffers are NaN outside the touched range) against the single-process update with the summed
+    gradient (adorym/ptychography.py:1113-1129; every rank adds its regulariser term, forward_model.py:138-139)."""
+    import torch.multiprocessing as mp
+    from oracle import adorym_oracle as O
+    shape = (4, 5, 6, 2)
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, shape, 7, restricted, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    n = int(np.prod(shape))
+    x = (np.random.default_rng(7).standard_normal(n) * 1e-3).astype(np.float32)
+    m = np.zeros_like(x); v = np.zeros_like(x)
+    t_lo, t_hi = (2 * (n // 8), 2 * (3 * n // 8)) if restricted else (0, n)
+    reg = (np.arange(n) % 5 - 2).astype(np.float32) * np.float32(0.1)
+    for it in range(3):
+        g = sum(np.random.default_rng(100 * it + k).standard_normal(n).astype(np.float32) for k in range(world))
+        data = np.zeros(n, np.float32)
+        data[t_lo:t_hi] = g[t_lo:t_hi]                     # (full exchange: the whole range)
+        x, m, v = O.adam_step(x, data + world * reg, m, v, it, step_size=1e-4)
+        x = np.clip(x, 0, None)
+    x = x - np.float32(1e-5) * np.float32(world)
+    for rank, obj in res:
+        assert np.all(np.isfinite(obj))
+        assert np.allclose(obj, x, rtol=1e-5, atol=1e-8), rank
+    assert np.array_equal(res[0][1], res[1][1])
+
+
 def test_shard_bounds_cover_and_align():
     from adorym_amd.comm import shard_bounds
     for n in (2, 10, 54, 2 * 256 ** 3):
