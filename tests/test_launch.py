@@ -106,3 +106,34 @@ def test_a_failing_rank_does_not_leave_the_others_waiting_for_ever(tmp_path):
     t0 = time.time()
     rc, _ = launch.run(2, [sys.executable, str(script)], grace_s=1.0, out=io.StringIO(), err=io.StringIO())
     assert rc == 9 and time.time() - t0 < 30
+
+
+def test_sigterm_to_the_launcher_takes_its_ranks_down_even_if_they_ignore_sigterm(tmp_path):
+    """ADVICE r5: ranks must not outlive a terminated launcher, and a rank that does not die of SIGTERM (stuck in a driver call;
+    here: it ignores the signal) is killed after the escalation period; every child is reaped."""
+    import signal
+    import subprocess
+    import time
+    rank = tmp_path / 'rank.py'
+    rank.write_text("import os, signal, sys, time\n"
+                    "if os.environ['RANK'] == '1':\n    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                    "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                    "time.sleep(600)\n" % str(tmp_path))
+    drv = tmp_path / 'drv.py'
+    drv.write_text("import sys\nsys.path.insert(0, %r)\nfrom adorym_amd import launch\n"
+                   "rc, _ = launch.run(2, [sys.executable, %r], kill_after_s=1.0)\nsys.exit(rc)\n" % (ROOT, str(rank)))
+    p = subprocess.Popen([sys.executable, str(drv)])
+    deadline = time.time() + 30
+    while time.time() < deadline and not ((tmp_path / 'pid0').exists() and (tmp_path / 'pid1').exists()):
+        time.sleep(0.05)
+    pids = [int((tmp_path / ('pid%d' % r)).read_text()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    p.wait(30)
+    time.sleep(0.2)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            alive = False
+        assert not alive, 'rank process %d outlived its launcher' % pid
