@@ -430,7 +430,8 @@ int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo** out);
 int adm_holo_destroy(adm_holo* holo);
 /* obj [ny][nx][2], probe [ny][nx][2], dists_cm [n_dists] (the reference's free_prop_cm), affine [n_dists][2][3]
  * (prj_affine_ls; NULL = identity), data [n_dists][ny][nx] raw measurements: all device pointers.
- * loss_sum [n_dists] (overwritten) = per-distance sum of squared residuals; loss = sum / (n_dists*ny*nx).
+ * loss_sum [n_dists] (overwritten) = per-distance sum of squared residuals; loss = sum / (n_dists*ny*nx).  May be page-locked host
+ * memory (adm_host_alloc): the last kernel then writes the sums where the host reads them, no copy is queued.
  * want_grad = 1: grad_obj [ny][nx][2] += dL/dobj; grad_probe [ny][nx][2] = dL/dprobe (NULL ok);
  * grad_dists [n_dists] += dL/dfree_prop_cm (NULL ok); grad_affine [n_dists][2][3] += dL/dprj_affine_ls (NULL ok);
  * want_grad = 2: the same with '=' instead of '+=' (the buffers need no zero fill: three launches less per minibatch on a
