@@ -364,3 +364,27 @@ def test_world4_p2p_against_fp64_oracle(tmp_path):
         assert (d > 1e-6).mean() < 1e-3 and d.max() < 1e-4        # (L1 / TV sign() gradients: a handful of voxels flip in any fp32 run)
         assert np.array_equal(r['delta'], res[0]['delta']) and np.array_equal(r['beta'], res[0]['beta'])
     assert np.allclose(res[0]['losses'], losses, rtol=2e-4)
+
+
+@pytest.mark.parametrize('transport', ['host', 'p2p'])
+def test_world2_checkpoint_and_resume(tmp_path, transport):
+    """Checkpoints of a 2-rank run (adorym/misc.py:179-211, optimizers.py:143-188; the moments are SHARDED here, every rank
+    writes its own shard and stamp) and a resume from them: a run interrupted after its first epoch and resumed in the same
+    folder ends where the uninterrupted 2-epoch run ends (up to the reference's own restart of the Adam step counter on resume,
+    ptychography.py:848), both replicas hold the same bits, and the number of replayed minibatches is the checkpoint's."""
+    kw = dict(optimizer='adam', learning_rate=1e-6, store_checkpoint=True, n_batch_per_checkpoint=2)
+    full = run_world2(tmp_path / 'full', 6, dict(kw, n_epochs=2), transport=transport)
+    part = run_world2(tmp_path / 'part', 6, dict(kw, n_epochs=1), transport=transport)
+    ck = os.path.join(str(tmp_path / 'part'), 'out', 'checkpoint')
+    files = sorted(os.listdir(ck))
+    assert 'checkpoint.txt' in files and 'obj_checkpoint.npy' in files and 'stamp_rank_0.txt' in files and 'stamp_rank_1.txt' in files, files
+    assert 'params_0' in files and 'params_1' in files
+    e0, b0 = [int(v) for v in np.loadtxt(os.path.join(ck, 'checkpoint.txt'))]
+    n_batch = len(part[0]['losses'])                     # global batches per epoch (4 angles x 6 positions / (2 ranks x 3))
+    assert e0 == 0 and 0 < b0 < n_batch
+    res = run_world2(tmp_path / 'part', 6, dict(kw, n_epochs=2, use_checkpoint=True), transport=transport)
+    assert len(res[0]['losses']) == (n_batch - b0) + n_batch
+    for a, b in zip(res, full):
+        assert np.allclose(a['losses'][-n_batch:], b['losses'][-n_batch:], rtol=3e-2)
+        assert np.abs(a['delta'] - b['delta']).max() < 5e-5
+    assert np.array_equal(res[0]['delta'], res[1]['delta']) and np.array_equal(res[0]['beta'], res[1]['beta'])
