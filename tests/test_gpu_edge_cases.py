@@ -528,3 +528,34 @@ def test_config5_full_size_vs_oracle(A, ctx):
     assert np.linalg.norm(eng.pred() - pred) < 3e-6 * np.linalg.norm(pred)
     for mine, ref, tol in ((g.get(), g_obj, 2e-4), (gd.get(), g_d, 2e-3), (ga.get(), g_a, max(2e-3, 3 * e_a32))):
         assert np.linalg.norm(mine - ref) < tol * np.linalg.norm(ref), np.linalg.norm(mine - ref) / np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize('shape', [(16, 16), (32, 128), (256, 64), (1024, 16), (16, 2048)])
+def test_holography_gradients_at_every_line_geometry(A, ctx, shape):
+    """The gradient path of the holography kernels (K3 with gradient, K4, K5) at field sizes that exercise every lines-per-block
+    geometry of the block-cooperative transposed stores / loads of round 6 (128 lines per block at N = 16 ... one at N = 2048),
+    square and not: loss, prediction, object / distance / affine gradients against the fp64 oracle
+    (adorym/forward_model.py:809-1092 restated in oracle.holo_forward_adjoint)."""
+    from adorym_amd.holography import HolographyEngine
+    ny, nx = shape
+    nd = 3
+    r = cases.rng(9000 + ny * 7 + nx)
+    energy, psize = 17050., 1e-4
+    mag = 1 - 0.2 * cases.smooth_field((ny, nx, 1), 9100 + ny + nx); ph = 0.5 * cases.smooth_field((ny, nx, 1), 9200 + ny + nx)
+    obj = np.stack([mag * np.cos(ph), mag * np.sin(ph)], -1)
+    dists = np.array([3., 5., 9.])
+    aff = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1]) + 0.01 * r.uniform(-1, 1, (nd, 2, 3))
+    data = (1 + 0.1 * cases.smooth_field((nd, ny, nx), 9300 + ny + nx)) ** 2
+    loss, pred, _, g_obj, _, g_d, g_a = O.holo_forward_adjoint(obj, np.ones((ny, nx), complex), dists, aff, data, energy, psize)
+    g_a32 = O.holo_forward_adjoint(obj.astype(np.float32), np.ones((ny, nx), np.complex64), dists, aff, data, energy, psize, dtype='float32')[6]
+    e_a32 = np.linalg.norm(g_a32 - g_a) / np.linalg.norm(g_a)
+    eng = HolographyEngine(ctx, (ny, nx), nd, energy, psize)
+    obj_d = ctx.array(obj.astype(np.float32))
+    probe_d = ctx.array(np.stack([np.ones((ny, nx)), np.zeros((ny, nx))], -1).astype(np.float32))
+    g, gd, ga = ctx.zeros(obj_d.shape), ctx.zeros((nd,)), ctx.zeros((nd, 2, 3))
+    eng.forward_adjoint(obj_d, probe_d, ctx.array(dists.astype(np.float32)), ctx.array(data.astype(np.float32)),
+                        affine=ctx.array(aff.astype(np.float32)), grad_obj=g, grad_dists=gd, grad_affine=ga, want_pred=True)
+    assert abs(eng.loss() - loss) < 5e-5 * abs(loss)
+    assert np.linalg.norm(eng.pred() - pred) < 5e-6 * np.linalg.norm(pred)
+    for mine, ref, tol in ((g.get(), g_obj, 2e-4), (gd.get(), g_d, 2e-3), (ga.get(), g_a, max(2e-3, 3 * e_a32))):
+        assert np.linalg.norm(mine - ref) < tol * np.linalg.norm(ref), (shape, np.linalg.norm(mine - ref) / np.linalg.norm(ref))
