@@ -218,6 +218,34 @@ class PinnedArray(object):
             pass
 
 
+class MappedArray(object):
+    """Page-locked host memory that KERNELS write directly (it is device-accessible at ``ptr``): small results the host wants --
+    per-position loss sums -- land where the host reads them, and no device-to-host copy is ever queued.  ``get()`` waits for
+    the context's streams and returns a copy; ``view(offset, shape)`` is a sub-range with the same two members."""
+
+    def __init__(self, ctx, shape, dtype=np.float32, _pinned=None, _offset=0):
+        self.ctx = ctx
+        self.shape = tuple(int(v) for v in (shape if np.ndim(shape) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._pinned = _pinned if _pinned is not None else PinnedArray(ctx, (self.size,), self.dtype)
+        self._offset = int(_offset)
+        self.ptr = self._pinned.handle.value + self._offset * self.dtype.itemsize
+
+    @property
+    def host(self):
+        """The live host view (valid to read once an event recorded behind the writing kernel has happened)."""
+        return self._pinned.array.reshape(-1)[self._offset:self._offset + self.size].reshape(self.shape)
+
+    def get(self):
+        self.ctx.sync()
+        return np.array(self.host)
+
+    def view(self, offset_elems, shape):
+        return MappedArray(self.ctx, shape, self.dtype, _pinned=self._pinned, _offset=self._offset + int(offset_elems))
+
+
 class UploadRing(object):
     """Pinned staging ring owned by a context user: upload(dev, host_array) copies the array into the next pinned slot
     and queues an asynchronous host-to-device copy -- the host never waits for the stream (DeviceArray.set does).  A slot

@@ -198,6 +198,13 @@ class PtychographyModel(ForwardModel):
             return None, None
         n_pos = dev.shape[-2] if len(dev.shape) >= 2 else dev.size // 2
         idx = (int(this_i_theta) * n_pos + np.asarray(this_ind_batch, dtype=np.int64)).astype(np.int32)
+        if len(idx) > 0 and int(idx[-1]) - int(idx[0]) == len(idx) - 1 and np.all(np.diff(idx) == 1):
+            # a run of consecutive entries (the reference sorts a minibatch's indices, adorym/ptychography.py:907): a view of a
+            # resident 0, 1, 2, ... array -- no upload, no copy kernel in the minibatch
+            n_all = dev.size // 2
+            if getattr(self, '_idx_all', None) is None or self._idx_all.size < n_all:
+                self._idx_all = self.device.array(np.arange(n_all, dtype=np.int32))
+            return dev, self._idx_all.view(int(idx[0]), (len(idx),))
         if getattr(self, '_idx_dev', None) is None or self._idx_dev.size < len(idx):
             self._idx_dev = DeviceArray(self.device, (max(len(idx), 64),), np.int32)
         view = self._idx_dev.view(0, (len(idx),))

@@ -179,9 +179,15 @@ class MultisliceEngine(object):
         self._pos = DeviceArray(self.ctx, (batch, 2), np.int32)
         self._target = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
         self._pred = DeviceArray(self.ctx, (batch, Py, Px), np.float32)
-        # two buffers, written alternately by successive launches: the read-back of launch k can then be queued LATER (beside
-        # launch k+1, see loss_async) without racing with the kernel that overwrites the sums
-        self._loss_pair = [DeviceArray(self.ctx, (batch,), np.float32) for _ in range(2)]
+        # The per-position loss sums are written by the kernel straight into page-locked HOST memory (MappedArray): no
+        # device-to-host copy is ever queued (the 4.5 us blit kernel and its dependency gap sat in every minibatch of the
+        # launch-bound paths).  Two buffers, written alternately by successive launches, each with an event that is recorded
+        # LATER -- beside launch k+1, see loss_async -- and tells the host that launch k's sums have arrived.
+        from .device import MappedArray, Event
+        self._loss_pair = [MappedArray(self.ctx, (batch,), np.float32) for _ in range(2)]
+        self._loss_events = [Event(self.ctx) for _ in range(2)]
+        self._loss_tokens = [None, None]
+        self._loss_k = 0
         self._loss = self._loss_pair[0]
         self._deferred_loss = None
         # pinned staging for the per-minibatch uploads (targets, positions): asynchronous, the host never drains the stream
@@ -416,56 +422,61 @@ class MultisliceEngine(object):
         return float(sums.sum() / (len(sums) * self.n_det))
 
     def _next_loss_buffer(self):
-        """Switch to the other loss buffer for the launch about to be queued; a read-back still deferred from the launch that
-        wrote it last is queued first (on the current stream), so no sum is ever overwritten before it was copied."""
-        nxt = self._loss_pair[1] if self._loss is self._loss_pair[0] else self._loss_pair[0]
-        d = self._deferred_loss
-        if d is not None and d[3] is nxt:
-            self.flush_loss_copy()
-        self._loss = nxt
+        """Switch to the other loss buffer for the launch about to be queued.  If the launch that wrote it last still has an
+        unresolved token, its sums are taken off the buffer first (the host waits for that launch's event: it finished long
+        ago), so no sum is ever overwritten before somebody could read it."""
+        k = 1 - self._loss_k
+        tok = self._loss_tokens[k]
+        if tok is not None and tok['sums'] is None:
+            self._resolve_loss(tok)
+        self._loss_tokens[k] = None
+        self._loss_k = k
+        self._loss = self._loss_pair[k]
 
     def loss_async(self, last=None):
         """Register the read-back of the per-position loss sums of the batch just launched and return a token for
-        loss_result(); the host is not blocked, so the next minibatch can be queued first.  The copy itself is DEFERRED to
-        the next flush_loss_copy() -- the drivers call it inside the side-stream region of the next minibatch, where the copy
-        and its dependency gaps cost the main stream nothing (on the main stream it sat between the optimiser kernel and the
-        next rotation: ~11 us per minibatch) -- or to loss_result(), whichever comes first."""
-        from .device import PinnedArray, Event
-        if getattr(self, '_loss_pinned', None) is None or self._loss_pinned[0].shape[0] < self.max_batch:
-            self._loss_pinned = [PinnedArray(self.ctx, (self.max_batch,)) for _ in range(2)]
-            self._loss_events = [Event(self.ctx) for _ in range(2)]
-            self._loss_slot = 0
+        loss_result(); the host is not blocked, so the next minibatch can be queued first.  The kernel writes the sums into
+        page-locked host memory itself; what is DEFERRED to the next flush_loss_copy() is the event that says they are there
+        -- the drivers call it inside the side-stream region of the next minibatch, where the marker costs the main stream
+        nothing (on the main stream it sat between the optimiser kernel and the next rotation) -- or to loss_result(),
+        whichever comes first."""
         if self._deferred_loss is not None:
             self.flush_loss_copy()
-        self._loss_slot ^= 1
-        token = [self._loss_slot, self._B, last, self._loss]
+        token = {'k': self._loss_k, 'B': self._B, 'last': last, 'sums': None, 'recorded': False,
+                 'buf': self._loss, 'ev': self._loss_events[self._loss_k]}      # (its own buffer and event: _reserve may replace the pair)
+        self._loss_tokens[self._loss_k] = token
         self._deferred_loss = token
         return token
 
     def flush_loss_copy(self):
-        """Queue the deferred loss read-back, if any, on the stream the context is enqueuing on right now."""
+        """Record the event of the deferred loss read-back, if any, on the stream the context is enqueuing on right now (that
+        stream must be behind the launch: the main stream, or the side stream after a fork)."""
         token = self._deferred_loss
         self._deferred_loss = None
-        if token is not None and token[3] is not None:
-            k, B = token[0], token[1]
-            self._loss_pinned[k].copy_from_async(token[3], 4 * B)
-            self._loss_events[k].record()
-            token[3] = None
+        if token is not None and not token['recorded']:
+            token['ev'].record()
+            token['recorded'] = True
+
+    def _resolve_loss(self, token):
+        if not token['recorded']:
+            if self._deferred_loss is token:
+                self._deferred_loss = None
+            token['ev'].record()
+            token['recorded'] = True
+        token['ev'].synchronize()
+        token['sums'] = np.array(token['buf'].host[:token['B']], dtype=np.float64)
 
     def loss_result(self, token):
-        k, B, last = token[0], token[1], token[2]
-        if token[3] is not None:            # nobody flushed it yet: queue the copy now
-            if self._deferred_loss is token:
-                self.flush_loss_copy()
-            else:
-                self._loss_pinned[k].copy_from_async(token[3], 4 * B)
-                self._loss_events[k].record()
-                token[3] = None
-        self._loss_events[k].synchronize()
-        sums = self._loss_pinned[k].array[:B].astype(np.float64)
-        if last is not None:
-            sums = sums[B - last:]
+        if token['sums'] is None:
+            self._resolve_loss(token)
+        sums = token['sums']
+        if token['last'] is not None:
+            sums = sums[token['B'] - token['last']:]
         return float(sums.sum() / (len(sums) * self.n_det))
+
+    def loss_sums(self, n):
+        """The first n per-position sums of the last launch (blocks)."""
+        return self._loss.view(0, (n,)).get().astype(np.float64)
 
     def pred(self):
         return self._pred.view(0, (self._B,) + self.probe_size).get()
@@ -537,5 +548,5 @@ class AngleBatch(object):
         for r, t in enumerate(tables):
             eng.rotate_adjoint(self._shifted(grad_obj, r), t, (r * Y, (r + 1) * Y))
         eng._check_overflow()
-        sums = eng._loss.view(0, (self.R,)).get().astype(np.float64)
+        sums = eng.loss_sums(self.R)
         return sums / n_det

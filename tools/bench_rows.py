@@ -159,7 +159,7 @@ def bench_c1(ctx, steps=50):
     corr = ctx.array((pos - pos_int)[None].astype(np.float32))
     gc = ctx.zeros(corr.shape)
     meas = ctx.array((np.abs(r.standard_normal((B, P, P))) * 50).astype(np.float32))
-    idx = ctx.array(np.arange(B, dtype=np.int32))
+    idx_all = ctx.array(np.arange(len(pos_int), dtype=np.int32))
     lib = ctx.lib
     # the driver's optimiser objects and its ONE launch for the small parameters (adorym_amd/ptychography.py)
     o_probe = AdamOptimizer('probe', options_dict={'step_size': 1e-3}); o_probe.create_param_arrays(list(probe.shape), device=ctx)
@@ -175,16 +175,15 @@ def bench_c1(ctx, steps=50):
         s = (k * B) % (len(pos_int) - B)
         eng.flush_loss_copy()               # the previous minibatch's loss read-back goes first: its event precedes this minibatch's work
         eng.set_batch(pos_int[s:s + B], meas)
-        ring.upload(idx, np.arange(s, s + B, dtype=np.int32))          # asynchronous, like the driver's per-minibatch uploads
+        idx = idx_all.view(s, (B,))         # a run of consecutive positions: a view of the resident index array, like the driver
         eng.rotate(obj, None, None)
-        g.zero_()
+        check(lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, 0., 0., 1e-6, g.ptr, None))      # initialises the gradient buffer (no zero fill)
         if timed[0]:
             ev[0].record()
         eng.multislice(probe, grad_probe=gp, shifts=corr, shift_index=idx, grad_shifts=gc)
         if timed[0]:
             ev[1].record()
         eng.rotate_adjoint(g, None, None)
-        check(lib.adm_reg_grad(eng.plan.handle, obj.ptr, 0., 0., 1e-6, g.ptr, None))
         # (as the driver does for a small unconstrained object on one rank: the object is one more array of the one launch)
         apply_small_params(ctx, [dict(opt=o_obj, x=obj_flat, g=g_flat), dict(opt=o_probe, x=probe, g=gp, zero_grad=True),
                                  dict(opt=o_pos, x=corr, g=gc, center_cols=2, zero_grad=True)], 0)
