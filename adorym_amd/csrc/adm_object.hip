@@ -774,11 +774,71 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ x, const 
 // An array without a drift guard is element-wise, so it is spread over ceil(n / chunk) workgroups (five probe modes of
 // 64 x 64 took 77 us in ONE workgroup, 40 % of a config-1-shape minibatch); an array with one stays in a single workgroup
 // (its column means need every element).  first_block[i]: the first workgroup of array i; first_block[count] = grid size.
-// Elements per workgroup of an element-wise array: 2048 for the genuinely small ones; an array of hundreds of thousands of elements
-// (the 2-D object itself, which the driver adds to this launch on one rank) gets 256 -- one element per thread, like adam_kernel
+// Elements per workgroup of an element-wise array: 2048 for the genuinely small ones (a few KB); anything larger -- five 64 x 64
+// probe modes, the 2-D object itself, which the driver adds to this launch on one rank -- gets 256: one element per thread, like adam_kernel
 // (8 dependent iterations per thread made the launch 8.4 us for a 512 x 512 x 2 object against adam_kernel's 5.6 us).
-static inline int small_chunk(uint64_t n) { return n > 65536 ? 256 : 2048; }
+static inline int small_chunk(uint64_t n) { return n > 4096 ? 256 : 2048; }
 struct SmallParams { adm_small_param p[ADM_SMALL_PARAMS_MAX]; int first_block[ADM_SMALL_PARAMS_MAX + 1]; int chunk[ADM_SMALL_PARAMS_MAX]; int count; };
+
+// An array with a drift guard, held in registers: thread t owns the rows t, t + 256, ... (all NC columns of each), so that the
+// Adam step, the column sums (in center_rows_block's order: rows ascending per thread, the same shuffle tree, the same four partial
+// sums -- the same bits), the subtraction and the pin need ONE round of loads and ONE of stores.  The generic path below makes
+// ~35 dependent trips to memory for the 1 400 x 2 position corrections of a config-1 minibatch (17 us, the longest block of the launch).
+#define SMALL_WHOLE_RPT 8
+template <int NC>
+__device__ __forceinline__ void small_adam_whole(const adm_small_param& q, const AdamScalars& a, float* red, float* mean) {
+    const size_t n_rows = q.n / NC;
+    float xv[SMALL_WHOLE_RPT][NC];
+#pragma unroll
+    for (int j = 0; j < SMALL_WHOLE_RPT; ++j) {
+        const size_t r = threadIdx.x + (size_t)256 * j;
+        if (r < n_rows) {
+            float gv[NC], mv[NC], vv[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const size_t i = r * NC + c; xv[j][c] = q.x[i]; gv[c] = q.g[i]; mv[c] = q.m[i]; vv[c] = q.v[i]; }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const size_t i = r * NC + c;
+                float mo, vo;
+                xv[j][c] = adam_value(xv[j][c], gv[c], mv[c], vv[c], a, i, mo, vo);
+                q.m[i] = mo;
+                q.v[i] = vo;
+                if (q.zero_grad) q.g[i] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xv[j][c] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < SMALL_WHOLE_RPT; ++j)
+            if (threadIdx.x + (size_t)256 * j < n_rows) acc += xv[j][c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) *mean = (red[0] + red[1] + red[2] + red[3]) / (float)n_rows;
+        __syncthreads();
+        const float mu = *mean;
+#pragma unroll
+        for (int j = 0; j < SMALL_WHOLE_RPT; ++j) xv[j][c] -= mu;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < SMALL_WHOLE_RPT; ++j) {
+        const size_t r = threadIdx.x + (size_t)256 * j;
+        if (r < n_rows) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const size_t i = r * NC + c;
+                q.x[i] = (q.pin && i < q.pin_n) ? q.pin[i] : xv[j][c];
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamScalars a) {
     __shared__ float red[4];
@@ -787,6 +847,12 @@ __global__ __launch_bounds__(256) void small_adam_kernel(SmallParams sp, AdamSca
     while (k + 1 < sp.count && (int)blockIdx.x >= sp.first_block[k + 1]) ++k;
     const adm_small_param q = sp.p[k];
     const bool whole = q.center_cols > 0;
+    if (whole && q.center_cols <= 2 && q.n / (size_t)q.center_cols <= (size_t)256 * SMALL_WHOLE_RPT) {
+        a.step = (float)q.step_size;
+        if (q.center_cols == 1) small_adam_whole<1>(q, a, red, &mean);
+        else small_adam_whole<2>(q, a, red, &mean);
+        return;
+    }
     const size_t chunk = (size_t)sp.chunk[k];
     const size_t lo = whole ? 0 : (size_t)(blockIdx.x - sp.first_block[k]) * chunk;
     const size_t hi = whole ? q.n : (lo + chunk < q.n ? lo + chunk : q.n);

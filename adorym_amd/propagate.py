@@ -239,11 +239,20 @@ class MultisliceEngine(object):
         # scan list needs no host-to-device copy at all
         run = None
         if self._all_pos_host is not None and B <= len(self._all_pos_host):
-            cand = np.flatnonzero((self._all_pos_host[:len(self._all_pos_host) - B + 1] == pos[0]).all(axis=1))
-            for c in cand:
-                if np.array_equal(self._all_pos_host[c:c + B], pos):
-                    run = int(c)
-                    break
+            # (the same minibatches come back every epoch: the search over the scan list is done once per distinct batch)
+            cache = self.__dict__.setdefault('_run_cache', {})
+            key = pos.tobytes()
+            run = cache.get(key, -1)
+            if run == -1:
+                run = None
+                cand = np.flatnonzero((self._all_pos_host[:len(self._all_pos_host) - B + 1] == pos[0]).all(axis=1))
+                for c in cand:
+                    if np.array_equal(self._all_pos_host[c:c + B], pos):
+                        run = int(c)
+                        break
+                if len(cache) > 65536:
+                    cache.clear()
+                cache[key] = run
         if run is not None:
             self._cur_pos = self._all_pos_dev.view(2 * run, (B, 2))
         else:
