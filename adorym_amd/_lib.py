@@ -36,6 +36,14 @@ class SmallParam(C.Structure):
                 ('center_cols', C.c_int32), ('zero_grad', C.c_int32), ('pin', C.c_void_p), ('pin_n', C.c_uint64)]
 
 
+class HoloAdam(C.Structure):
+    _fields_ = [('m_obj', C.c_void_p), ('v_obj', C.c_void_p), ('step_obj', C.c_double),
+                ('m_dists', C.c_void_p), ('v_dists', C.c_void_p), ('step_dists', C.c_double),
+                ('m_affine', C.c_void_p), ('v_affine', C.c_void_p), ('step_affine', C.c_double),
+                ('affine_pin', C.c_void_p), ('affine_pin_n', C.c_uint64),
+                ('i_batch', C.c_int32), ('b1', C.c_double), ('b2', C.c_double), ('eps', C.c_double)]
+
+
 SMALL_PARAMS_MAX = 6
 _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 
@@ -132,6 +140,7 @@ SIGNATURES = {
     'adm_holo_create': (_I, [_VP, C.POINTER(HoloDesc), C.POINTER(_VP)]),
     'adm_holo_destroy': (_I, [_VP]),
     'adm_holo_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    'adm_holo_fwd_adj_adam': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(HoloAdam), _VP, _VP]),
 }
 
 _lib = None

@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include "adm_common.h"
+#include "adm_optim.h"
 #include "adm_fft.h"
 #include "adm_ms_math.h"
 
@@ -179,6 +180,15 @@ struct HoloArgs {
     float *loss_sum, *grad_affine, *grad_dists;
     int ny, nx, nd, real_imag, intensity, want_affine, want_dists, set_obj;
     float k1, sigma, c1, inv_n, gscale;
+    // adm_holo_fwd_adj_adam: the Adam steps of the object, the distances and the affine matrices run where their gradients are
+    // produced (K5), the gradients themselves are never stored.  NULL moments: that parameter is not updated.
+    float2* obj_rw;
+    float *dists_rw, *affine_rw;
+    float *m_obj, *v_obj, *m_d, *v_d, *m_a, *v_a;
+    const float* a_pin;
+    unsigned long long a_pin_n;
+    AdamScalars adam;                               // step of the object; the other two step sizes below
+    float step_d, step_a;
 };
 
 // sum of v over the TPR threads of a line group (TPR a power of two <= 256); every thread of the block calls it.  A line of up to
@@ -290,10 +300,6 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
     const int d = ok ? job / A.ny : 0, y = ok ? job % A.ny : 0;
     cf* a = buf[0] + ll * LG::LP;
     cf* b = buf[1] + ll * LG::LP;
-    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.Wq[((size_t)d * A.ny + y) * NX + k] : make_float2(0.f, 0.f);
-    __syncthreads();
-    cf* res = line_fft<NX, true>(a, b, tw, t);
-    cf* oth = (res == a) ? b : a;
     float th[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
     if (A.affine) {
 #pragma unroll
@@ -302,9 +308,32 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
     const int ny = A.ny;
     const size_t n = (size_t)ny * NX;
     const float* img = A.data + (size_t)d * n;
-    float lsum = 0.f, ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float Y = base_coord(y, ny);
-    for (int x = t; x < NX; x += LG::TPR) {
+    // The four samples of the measured hologram every pixel of the line needs depend on the affine matrix only: their loads are
+    // issued NOW, ahead of the line's fetch and inverse transform, and wait in registers (32 per thread) -- issued in the element-wise
+    // stage they were a dependent trip to memory per pixel in the longest kernel of the minibatch.
+    constexpr int PPT = NX / LG::TPR;
+    float s00[PPT], s01[PPT], s10[PPT], s11[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const float X = base_coord(t + j * LG::TPR, NX);
+        float ix = (((th[0] * X + th[1] * Y + th[2]) + 1.f) * (float)NX - 1.f) * 0.5f;
+        float iy = (((th[3] * X + th[4] * Y + th[5]) + 1.f) * (float)ny - 1.f) * 0.5f;
+        ix = fminf(fmaxf(ix, 0.f), (float)(NX - 1));
+        iy = fminf(fmaxf(iy, 0.f), (float)(ny - 1));
+        const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+        const int x1 = min(x0 + 1, NX - 1), y1 = min(y0 + 1, ny - 1);
+        s00[j] = img[(size_t)y0 * NX + x0]; s01[j] = img[(size_t)y0 * NX + x1];
+        s10[j] = img[(size_t)y1 * NX + x0]; s11[j] = img[(size_t)y1 * NX + x1];
+    }
+    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.Wq[((size_t)d * A.ny + y) * NX + k] : make_float2(0.f, 0.f);
+    __syncthreads();
+    cf* res = line_fft<NX, true>(a, b, tw, t);
+    cf* oth = (res == a) ? b : a;
+    float lsum = 0.f, ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int x = t + j * LG::TPR;
         const float X = base_coord(x, NX);
         const float gx = th[0] * X + th[1] * Y + th[2];
         const float gy = th[3] * X + th[4] * Y + th[5];
@@ -316,9 +345,7 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
         iy = fminf(fmaxf(iy, 0.f), (float)(ny - 1));
         const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
         const float wx = ix - (float)x0, wy = iy - (float)y0;
-        const int x1 = min(x0 + 1, NX - 1), y1 = min(y0 + 1, ny - 1);
-        const float v00 = img[(size_t)y0 * NX + x0], v01 = img[(size_t)y0 * NX + x1];
-        const float v10 = img[(size_t)y1 * NX + x0], v11 = img[(size_t)y1 * NX + x1];
+        const float v00 = s00[j], v01 = s01[j], v10 = s10[j], v11 = s11[j];
         const float samp = v00 * (1.f - wx) * (1.f - wy) + v01 * wx * (1.f - wy) + v10 * (1.f - wx) * wy + v11 * wx * wy;
         const float as = fabsf(samp);
         const float tgt = A.intensity ? sqrtf(as) : as;
@@ -426,6 +453,7 @@ template <int NY> __global__ __launch_bounds__(256) void holo_k4(HoloArgs A) {
 
 // the per-line sums of K3 / K4 in a fixed order: loss_sum[d] =, grad_affine[d][q] +=, grad_dists[d] += 1e7 * ...
 // One wave per output: lanes stride over the lines, then a fixed shuffle tree.
+template <bool FUSE = false>
 __device__ __forceinline__ void holo_sum_one(const HoloArgs& A, bool grad, int o) {      // called by one whole wave
     const int lane = threadIdx.x & 63;
     const int d = o >> 3, q = o & 7;
@@ -438,14 +466,32 @@ __device__ __forceinline__ void holo_sum_one(const HoloArgs& A, bool grad, int o
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) {
         if (q == 0) A.loss_sum[d] = s;
+        else if (FUSE) {
+            // the parameter's Adam step right here (adm_adam_step_small's arithmetic on the gradient an overwriting launch would store)
+            AdamScalars a = A.adam;
+            float mo, vo;
+            if (q < 7) {
+                const int i = d * 6 + q - 1;
+                a.step = A.step_a;
+                float xn = adam_value(A.affine_rw[i], 0.f + s, A.m_a[i], A.v_a[i], a, (size_t)i, mo, vo);
+                A.m_a[i] = mo; A.v_a[i] = vo;
+                if (A.a_pin && (unsigned long long)i < A.a_pin_n) xn = A.a_pin[i];
+                A.affine_rw[i] = xn;
+            } else {
+                a.step = A.step_d;
+                const float xn = adam_value(A.dists_rw[d], 0.f + 1e7f * s, A.m_d[d], A.v_d[d], a, (size_t)d, mo, vo);
+                A.m_d[d] = mo; A.v_d[d] = vo;
+                A.dists_rw[d] = xn;
+            }
+        }
         else if (q < 7) A.grad_affine[d * 6 + q - 1] = (A.set_obj ? 0.f : A.grad_affine[d * 6 + q - 1]) + s;
         else A.grad_dists[d] = (A.set_obj ? 0.f : A.grad_dists[d]) + 1e7f * s;
     }
 }
-__global__ __launch_bounds__(64) void holo_sums_kernel(HoloArgs A) { holo_sum_one(A, false, blockIdx.x); }
+__global__ __launch_bounds__(64) void holo_sums_kernel(HoloArgs A) { holo_sum_one<false>(A, false, blockIdx.x); }
 
 // dL/dpsi -> dL/dobj (accumulated) and dL/dprobe (written)
-template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
+template <int NX, bool FUSE> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
     using LG = LineGeo<NX>;
     __shared__ cf buf[2][LG::LPB * LG::LP];
     __shared__ float2 twl[TwLds<NX>::SIZE];
@@ -455,6 +501,21 @@ template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
     const bool ok = y < A.ny;
     cf* a = buf[0] + ll * LG::LP;
     cf* b = buf[1] + ll * LG::LP;
+    // what the epilogue needs of the thread's 8 pixels -- object, probe and (fused update) the moments -- is requested NOW, before
+    // the line is fetched and transformed: with 128 blocks on 256 CUs nothing else hides these loads (they cost a dependent trip to
+    // memory per pixel when issued in the epilogue: 12 -> 18 us with the moments added)
+    constexpr int PPT = NX / LG::TPR;
+    float2 ob[PPT], pb[PPT], mob[FUSE ? PPT : 1], vob[FUSE ? PPT : 1];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const size_t i = (size_t)(ok ? y : 0) * NX + t + j * LG::TPR;
+        ob[j] = A.obj[i];
+        pb[j] = A.probe[i];
+        if (FUSE) {
+            mob[j] = reinterpret_cast<const float2*>(A.m_obj)[i];
+            vob[j] = reinterpret_cast<const float2*>(A.v_obj)[i];
+        }
+    }
     // T4t[kx][y]: thread e fetches column e / LPB of row e % LPB, so LPB consecutive lanes read LPB * 8 contiguous bytes
     {
         const int y0 = blockIdx.x * LG::LPB, ny = A.ny;
@@ -466,13 +527,15 @@ template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
     __syncthreads();
     const cf* res = line_fft<NX, true>(a, b, tw, t);
     if (ok)
-        for (int x = t; x < NX; x += LG::TPR) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int x = t + j * LG::TPR;
             const size_t i = (size_t)y * NX + x;
             const cf g = res[x];
-            const cf c = holo_transmission(A.obj[i], A.real_imag, A.k1, A.sigma);
-            const cf p = A.probe[i];
+            const cf c = holo_transmission(ob[j], A.real_imag, A.k1, A.sigma);
+            const cf p = pb[j];
             if (A.grad_probe) A.grad_probe[i] = cmulc(g, c);
-            float2 go = A.set_obj ? make_float2(0.f, 0.f) : A.grad_obj[i];
+            float2 go = (FUSE || A.set_obj) ? make_float2(0.f, 0.f) : A.grad_obj[i];
             if (A.real_imag) {
                 const cf z = cmulc(g, p);                  // G conj(probe)
                 go.x += z.x;
@@ -483,22 +546,35 @@ template <int NX> __global__ __launch_bounds__(256) void holo_k5(HoloArgs A) {
                 go.y += -A.k1 * wre;                       // d/dbeta
                 go.x += A.sigma * A.k1 * wim;              // d/ddelta
             }
-            A.grad_obj[i] = go;
+            if (FUSE) {
+                // the object's Adam step on the gradient just formed (channels 2 i and 2 i + 1 of the flat object array)
+                const float2 xo = ob[j];
+                const float2 mo = mob[j], vo = vob[j];
+                float2 xn, mn, vn;
+                xn.x = adam_value(xo.x, go.x, mo.x, vo.x, A.adam, 2 * i, mn.x, vn.x);
+                xn.y = adam_value(xo.y, go.y, mo.y, vo.y, A.adam, 2 * i + 1, mn.y, vn.y);
+                reinterpret_cast<float2*>(A.m_obj)[i] = mn;
+                reinterpret_cast<float2*>(A.v_obj)[i] = vn;
+                A.obj_rw[i] = xn;
+            } else {
+                A.grad_obj[i] = go;
+            }
         }
     // the sums of K3 / K4: output o by wave 0 of block o % gridDim.x (a handful of blocks carry one or two each)
     if (threadIdx.x < 64)
-        for (int o = blockIdx.x; o < A.nd * 8; o += gridDim.x) holo_sum_one(A, true, o);
+        for (int o = blockIdx.x; o < A.nd * 8; o += gridDim.x) holo_sum_one<FUSE>(A, true, o);
 }
 
 #define ADM_HOLO_SIZES(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
 template <int N> static int blocks_for(int lines) { return (lines + LineGeo<N>::LPB - 1) / LineGeo<N>::LPB; }
 
-static hipError_t holo_run(const HoloArgs& A, bool want_grad, hipStream_t st) {
+static hipError_t holo_run(const HoloArgs& A, bool want_grad, hipStream_t st, bool fuse = false) {
 #define K_X(KERNEL, N_, LINES) case N_: hipLaunchKernelGGL((KERNEL<N_>), dim3(blocks_for<N_>(LINES)), dim3(256), 0, st, A); break;
 #define K1(N_) K_X(holo_k1, N_, A.ny)
 #define K2(N_) case N_: hipLaunchKernelGGL((holo_k2<N_>), dim3(blocks_for<N_>(A.nx), A.nd), dim3(256), 0, st, A); break;
 #define K4(N_) case N_: hipLaunchKernelGGL((holo_k4<N_>), dim3(A.nx), dim3(256), 0, st, A); break;
-#define K5(N_) K_X(holo_k5, N_, A.ny)
+#define K5(N_) case N_: if (fuse) hipLaunchKernelGGL((holo_k5<N_, true>), dim3(blocks_for<N_>(A.ny)), dim3(256), 0, st, A); \
+                         else hipLaunchKernelGGL((holo_k5<N_, false>), dim3(blocks_for<N_>(A.ny)), dim3(256), 0, st, A); break;
 #define K3G(N_) case N_: hipLaunchKernelGGL((holo_k3<N_, true>), dim3(blocks_for<N_>(A.nd * A.ny)), dim3(256), 0, st, A); break;
 #define K3N(N_) case N_: hipLaunchKernelGGL((holo_k3<N_, false>), dim3(blocks_for<N_>(A.nd * A.ny)), dim3(256), 0, st, A); break;
     switch (A.nx) { ADM_HOLO_SIZES(K1) default: return hipErrorInvalidValue; }
@@ -617,5 +693,39 @@ extern "C" int adm_holo_fwd_adj(adm_holo* h, const float* obj, const float* prob
     A.inv_n = (float)(1.0 / (double)n);
     A.gscale = want_grad ? (float)(2.0 / ((double)n * d.n_dists)) : 0.f;
     ADM_HIP(holo_run(A, want_grad != 0, h->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_holo_fwd_adj_adam(adm_holo* h, float* obj, const float* probe, float* dists_cm, float* affine, const float* data,
+                                     const adm_holo_adam* opt, float* pred, float* loss_sum) {
+    if (!h || !obj || !probe || !dists_cm || !data || !loss_sum || !opt) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj_adam: null argument");
+    if (!opt->m_obj || !opt->v_obj) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj_adam: the object's moments are required");
+    if ((opt->m_dists == nullptr) != (opt->v_dists == nullptr) || (opt->m_affine == nullptr) != (opt->v_affine == nullptr))
+        return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj_adam: m and v of a parameter come together");
+    if (opt->m_affine && !affine) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj_adam: affine moments without affine matrices");
+    const adm_holo_desc& d = h->d;
+    const size_t n = (size_t)d.ny * d.nx;
+    HoloArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.obj = (const float2*)obj; A.probe = (const float2*)probe;
+    A.dists = dists_cm; A.affine = affine; A.data = data; A.uv2t = h->uv2t;
+    A.T1 = h->T14; A.Ft = h->Ft; A.Wq = h->Wq; A.T3 = h->T3; A.T4 = h->T14;
+    A.tw_x = h->tw_x; A.tw_y = h->tw_y;
+    A.pred = pred; A.part3 = h->part3; A.part4 = h->part4;
+    A.loss_sum = loss_sum;
+    A.ny = d.ny; A.nx = d.nx; A.nd = d.n_dists; A.real_imag = d.unknown_type; A.intensity = d.raw_intensity;
+    A.want_affine = opt->m_affine ? 1 : 0;
+    A.want_dists = opt->m_dists ? 1 : 0;
+    A.set_obj = 1;
+    A.k1 = d.k1; A.sigma = (float)d.sign_convention;
+    A.c1 = (float)(-(double)d.sign_convention * 3.14159265359 * d.lambda_nm);
+    A.inv_n = (float)(1.0 / (double)n);
+    A.gscale = (float)(2.0 / ((double)n * d.n_dists));
+    A.obj_rw = (float2*)obj; A.dists_rw = dists_cm; A.affine_rw = affine;
+    A.m_obj = opt->m_obj; A.v_obj = opt->v_obj; A.m_d = opt->m_dists; A.v_d = opt->v_dists; A.m_a = opt->m_affine; A.v_a = opt->v_affine;
+    A.a_pin = opt->affine_pin; A.a_pin_n = opt->affine_pin_n;
+    A.adam = adam_scalars(opt->i_batch, opt->step_obj, opt->b1, opt->b2, opt->eps, 0, nullptr);
+    A.step_d = (float)opt->step_dists; A.step_a = (float)opt->step_affine;
+    ADM_HIP(holo_run(A, true, h->ctx->stream, true));
     return ADM_OK;
 }

@@ -599,6 +599,24 @@ class MultiDistModel(PtychographyModel):
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         if _side_hook is not None:
             _side_hook()
+        fa = getattr(self, 'fused_adam', None)
+        if fa is not None:
+            # the driver has established that this minibatch's update is plain Adam on exactly these gradients (one rank, no
+            # regulariser / constraint / mask): gradient launch group and optimiser steps are ONE call, nothing is returned
+            nd = self.holo.n_dists
+            probe = self._probe(probe_real, probe_imag)
+            dists = self._dev('free_prop_cm', free_prop_cm, (nd,))
+            aff = self._dev('prj_affine_ls', prj_affine_ls, (nd, 2, 3)) if self.common_vars.get('optimize_prj_affine') else None
+            if (fa['dists'] is not None and not isinstance(free_prop_cm, DeviceArray)) or \
+                    (fa['affine'] is not None and not isinstance(prj_affine_ls, DeviceArray)):
+                raise RuntimeError('fused holography update: the optimised parameters must live on the device')
+            self.holo.forward_adjoint_adam(obj, probe, dists, self._data(this_i_theta), fa['obj_mv'], fa['step_obj'], fa['i_batch'], affine=aff,
+                                           dists_mv=fa['dists'][:2] if fa['dists'] else None, step_dists=fa['dists'][2] if fa['dists'] else 0.,
+                                           affine_mv=fa['affine'][:2] if fa['affine'] else None, step_affine=fa['affine'][2] if fa['affine'] else 0.,
+                                           affine_pin=fa['pin'], b1=fa['b1'], b2=fa['b2'], eps=fa['eps'])
+            datav = self.holo.loss_async()
+            self._loss_thunk = lambda: datav()
+            return tuple(None for _ in opt_args_ls)
         # _init_grad: the object-gradient buffer holds garbage -> the engine overwrites every gradient ('=' instead of '+=': no
         # zero fills on a path that is bound by the number of launches); otherwise it accumulates into zeroed small buffers
         nd = self.holo.n_dists

@@ -56,6 +56,24 @@ class HolographyEngine(object):
                                             p(grad_obj), p(grad_probe), p(grad_dists), p(grad_affine),
                                             self._pred.ptr if want_pred else None, self._pinned[self._slot].handle))
 
+    def forward_adjoint_adam(self, obj, probe, dists_cm, data, obj_mv, step_obj, i_batch, affine=None, dists_mv=None, step_dists=0.,
+                             affine_mv=None, step_affine=0., affine_pin=None, b1=0.9, b2=0.999, eps=1e-7, want_pred=False):
+        """forward_adjoint(overwrite=True) FUSED with the Adam steps of the object (always), the distances (``dists_mv`` = (m, v)
+        DeviceArrays, or None) and the affine matrices (``affine_mv``, with ``affine_pin`` = DeviceArray copied over the first
+        entries afterwards): adm_holo_fwd_adj_adam.  obj / dists_cm / affine are updated in place; no gradient is stored."""
+        from ._lib import HoloAdam
+        if want_pred and self._pred is None:
+            self._pred = DeviceArray(self.ctx, (self.n_dists, self.ny, self.nx), np.float32)
+        p = lambda a: a.ptr if a is not None else None
+        o = HoloAdam(m_obj=obj_mv[0].ptr, v_obj=obj_mv[1].ptr, step_obj=float(step_obj),
+                     m_dists=p(dists_mv[0]) if dists_mv else None, v_dists=p(dists_mv[1]) if dists_mv else None, step_dists=float(step_dists),
+                     m_affine=p(affine_mv[0]) if affine_mv else None, v_affine=p(affine_mv[1]) if affine_mv else None,
+                     step_affine=float(step_affine), affine_pin=p(affine_pin), affine_pin_n=affine_pin.size if affine_pin is not None else 0,
+                     i_batch=int(i_batch), b1=float(b1), b2=float(b2), eps=float(eps))
+        self._slot ^= 1
+        check(self.ctx.lib.adm_holo_fwd_adj_adam(self.handle, obj.ptr, probe.ptr, dists_cm.ptr, p(affine), data.ptr, C.byref(o),
+                                                 self._pred.ptr if want_pred else None, self._pinned[self._slot].handle))
+
     def loss(self):
         """mean over (distance, pixel) of the squared residual of the last launch -- blocks."""
         return self.loss_async()()

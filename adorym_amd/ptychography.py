@@ -874,6 +874,35 @@ def reconstruct_ptychography(
                 else:
                     grad_func_args[arg] = optimizable_params[arg]
             forward_model.update_loss_args(grad_func_args)
+            # Multi-distance holography whose update is exactly "Adam on what this minibatch's gradients say" -- one rank, an update per
+            # minibatch, no regulariser, constraint or mask on the object, plain Adam with common (b1, b2, eps) on the object and on
+            # whichever of free_prop_cm / prj_affine_ls are optimised: the steps run INSIDE the gradient launch group's last kernel
+            # (adm_holo_fwd_adj_adam; same arithmetic, same bits), no gradient is stored and no optimiser launch follows.
+            holo_fused = None
+            if is_multi_dist and builtin_model and init_grad and update_scheme == 'immediate' and optimize_object and fused \
+                    and opt_kind == 'adam' and n_ranks == 1 and flags == 0 and mask is None and not optimize_probe \
+                    and not optimize_all_probe_pos and not forward_model.reg_list and os.environ.get('ADM_HOLO_FUSED_ADAM', '1') == '1':
+                small_opts = [o_ for o_ in (opt_free_prop, opt_prj_affine) if o_ is not None]
+                okeys = {(float(o_.options_dict.get('b1', 0.9)), float(o_.options_dict.get('b2', 0.999)), float(o_.options_dict.get('eps', 1e-7)))
+                         for o_ in [opt] + small_opts}
+                if len(okeys) == 1 and all(type(o_) is AdamOptimizer and set(o_.options_dict) <= {'step_size', 'b1', 'b2', 'eps'}
+                                           for o_ in [opt] + small_opts):
+                    upd_small = (i_batch + i_epoch * n_batch) >= other_params_update_delay
+                    b1_, b2_, eps_ = next(iter(okeys))
+                    holo_fused = dict(obj_mv=(state.moments[0], state.moments[1]), step_obj=float(opt.options_dict.get('step_size', 0.001)),
+                                      i_batch=i_opt_batch, b1=b1_, b2=b2_, eps=eps_, dists=None, affine=None, pin=None, opts=[opt])
+                    if upd_small and opt_free_prop is not None:
+                        holo_fused['dists'] = (opt_free_prop.params_whole_array_dict['m'], opt_free_prop.params_whole_array_dict['v'],
+                                               float(opt_free_prop.options_dict.get('step_size', 0.001)))
+                        holo_fused['opts'].append(opt_free_prop)
+                    if upd_small and opt_prj_affine is not None:
+                        holo_fused['affine'] = (opt_prj_affine.params_whole_array_dict['m'], opt_prj_affine.params_whole_array_dict['v'],
+                                                float(opt_prj_affine.options_dict.get('step_size', 0.001)))
+                        holo_fused['pin'] = affine_identity_dev
+                        holo_fused['opts'].append(opt_prj_affine)
+                    state.finish_update()
+            if is_multi_dist and builtin_model:
+                forward_model.fused_adam = holo_fused
             grads = diff.get_gradients(_accumulate_into=gradient.arr, _side_hook=side_hook, _init_grad=init_grad, **grad_func_args)
             print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
             if initialize_gradients:
@@ -884,16 +913,20 @@ def reconstruct_ptychography(
                 # resampled again (the reference's TODO at :1075 says they should not be); kept literally -- golden F15
                 # pins it -- and the minibatches of an angle are not fused into one launch in this mode for that reason.
                 forward_model.resample_gradient(gradient.arr, this_i_theta)
-            if optimize_probe:
+            if holo_fused is not None:
+                for o_ in holo_fused['opts']:
+                    o_.i_batch += 1
+                grads = None
+            if optimize_probe and holo_fused is None:
                 gpd = grads[opt_probe.index_in_grad_returns]       # interleaved (real, imag) device array
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, probe_grad_dev.ptr, gpd.ptr, 1.0, gpd.size))
             if optimize_all_probe_pos:
                 gcd = grads[opt_args_ls.index(forward_model.get_argument_index('probe_pos_correction'))]
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, pos_grad_dev.ptr, gcd.ptr, 1.0, gcd.size))
-            if opt_free_prop is not None:
+            if opt_free_prop is not None and holo_fused is None:
                 gfd = grads[opt_free_prop.index_in_grad_returns]
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, free_prop_grad_dev.ptr, gfd.ptr, 1.0, gfd.size))
-            if opt_prj_affine is not None:
+            if opt_prj_affine is not None and holo_fused is None:
                 gad = grads[opt_prj_affine.index_in_grad_returns]
                 _lib.check(ctx.lib.adm_axpy(ctx.handle, affine_grad_dev.ptr, gad.ptr, 1.0, gad.size))
 
@@ -908,9 +941,9 @@ def reconstruct_ptychography(
             # arithmetic -- adam_value in adm_optim.h -- and same step counter); these paths are chains of 5-20 us kernels, where
             # a launch saved is 5 % of a minibatch.
             obj_with_small = (optimize_object and fused and opt_kind == 'adam' and n_ranks == 1 and flags == 0 and mask is None
-                              and state.n <= (1 << 22) and not restricted_exchange
+                              and state.n <= (1 << 22) and not restricted_exchange and holo_fused is None
                               and set(opt.options_dict) <= {'step_size', 'b1', 'b2', 'eps'})
-            if optimize_object and not obj_with_small:
+            if optimize_object and not obj_with_small and holo_fused is None:
                 if fused:
                     o = dict(opt.options_dict)
                     if opt_kind == 'gd':
@@ -960,7 +993,7 @@ def reconstruct_ptychography(
                 else:
                     print_flush('  Probe is not updated because current batch is out of the specified range ({}, {}).'.format(
                         probe_update_delay, probe_update_limit), 0, rank, **stdout_options)
-            if i_global >= other_params_update_delay:
+            if i_global >= other_params_update_delay and holo_fused is None:
                 if optimize_all_probe_pos:
                     # (+ "prevent position drifting": subtract the mean over (theta, position))
                     small.append(dict(opt=opt_probe_pos, x=optimizable_params['probe_pos_correction'], g=pos_grad_dev, center_cols=2, zero_grad=True))

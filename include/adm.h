@@ -440,6 +440,23 @@ int adm_holo_destroy(adm_holo* holo);
 int adm_holo_fwd_adj(adm_holo* holo, const float* obj, const float* probe, const float* dists_cm, const float* affine,
                      const float* data, int want_grad, float* grad_obj, float* grad_probe, float* grad_dists,
                      float* grad_affine, float* pred, float* loss_sum);
+/* adm_holo_fwd_adj (want_grad = 2: every gradient overwritten) FUSED with the Adam steps that consume those gradients --
+ * `opt.apply_gradient` of the object (adorym/ptychography.py:1120-1129, optimizers.py:309-318) and the updates of `free_prop_cm`
+ * and `prj_affine_ls` with the identity pin of matrix 0 (optimizers.py:1062-1083) -- in the launch group's last kernel: the object
+ * gradient never reaches memory and no optimiser launch follows (a config-5 minibatch is five dependent kernels of 8 - 19 us; the
+ * sixth launch was 7 % of it).  obj, dists_cm and affine are updated IN PLACE.  NULL moments of the distances / of the affine
+ * matrices: that parameter is left alone (its gradient is not formed).  Same arithmetic, same bits as adm_holo_fwd_adj followed by
+ * adm_adam_step_small on the three arrays.  Valid where the reference's update is exactly that: one rank, no regulariser on the
+ * object, no constraint or mask, plain Adam with common (b1, b2, eps), a minibatch per update. */
+typedef struct adm_holo_adam {
+    float* m_obj; float* v_obj; double step_obj;                 /* [ny*nx*2] each */
+    float* m_dists; float* v_dists; double step_dists;           /* [n_dists] each, or NULL */
+    float* m_affine; float* v_affine; double step_affine;        /* [n_dists*6] each, or NULL */
+    const float* affine_pin; uint64_t affine_pin_n;              /* the first affine_pin_n entries of affine are set to these afterwards */
+    int32_t i_batch; double b1, b2, eps;
+} adm_holo_adam;
+int adm_holo_fwd_adj_adam(adm_holo* h, float* obj, const float* probe, float* dists_cm, float* affine, const float* data,
+                          const adm_holo_adam* opt, float* pred, float* loss_sum);
 
 /* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
 int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);

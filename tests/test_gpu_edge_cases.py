@@ -559,3 +559,97 @@ def test_holography_gradients_at_every_line_geometry(A, ctx, shape):
     assert np.linalg.norm(eng.pred() - pred) < 5e-6 * np.linalg.norm(pred)
     for mine, ref, tol in ((g.get(), g_obj, 2e-4), (gd.get(), g_d, 2e-3), (ga.get(), g_a, max(2e-3, 3 * e_a32))):
         assert np.linalg.norm(mine - ref) < tol * np.linalg.norm(ref), (shape, np.linalg.norm(mine - ref) / np.linalg.norm(ref))
+
+
+@pytest.mark.parametrize('which', ['all', 'object_only', 'object_and_dists'])
+@pytest.mark.regression
+def test_holography_fused_adam_equals_the_separate_update_bitwise(A, ctx, which):
+    """adm_holo_fwd_adj_adam -- the Adam steps of object, distances and affine matrices inside the launch group's last kernel, no
+    gradient stored -- against adm_holo_fwd_adj (overwriting) followed by the one small-parameter Adam launch: three minibatches,
+    every array and every moment equal bit for bit, the loss too (adorym/ptychography.py:1120-1129, optimizers.py:1062-1083)."""
+    from adorym_amd.holography import HolographyEngine
+    from adorym_amd.optimizers import AdamOptimizer, apply_small_params
+    ny, nx, nd = 128, 256, 3
+    r = cases.rng(4242)
+    energy, psize = 17050., 1e-4
+    obj_h = np.stack([1 + 0.05 * r.standard_normal((ny, nx, 1)), 0.05 * r.standard_normal((ny, nx, 1))], -1).astype(np.float32)
+    d_h = np.array([3., 5., 9.], np.float32)
+    a_h = (np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1]) + 0.01 * r.uniform(-1, 1, (nd, 2, 3))).astype(np.float32)
+    data = ctx.array(((1 + 0.1 * r.standard_normal((nd, ny, nx))) ** 2).astype(np.float32))
+    probe = ctx.array(np.stack([np.ones((1, ny, nx)), np.zeros((1, ny, nx))], -1).astype(np.float32))
+    ident = ctx.array(np.array([[1., 0, 0], [0, 1., 0]], np.float32))
+    use_d, use_a = which != 'object_only', which == 'all'
+    out = []
+    for fused in (False, True):
+        eng = HolographyEngine(ctx, (ny, nx), nd, energy, psize)
+        obj, dists, aff = ctx.array(obj_h), ctx.array(d_h), ctx.array(a_h)
+        o_obj = AdamOptimizer('obj', options_dict={'step_size': 1e-2}); o_obj.create_param_arrays(list(obj.shape), device=ctx)
+        o_d = AdamOptimizer('free_prop_cm', options_dict={'step_size': 1e-1}); o_d.create_param_arrays([nd], device=ctx)
+        o_a = AdamOptimizer('prj_affine_ls', options_dict={'step_size': 1e-3}); o_a.create_param_arrays(list(aff.shape), device=ctx)
+        mv = lambda o: (o.params_whole_array_dict['m'], o.params_whole_array_dict['v'])
+        g, gd, ga = ctx.empty(obj.shape), ctx.empty((nd,)), ctx.empty(aff.shape)
+        losses = []
+        for k in range(3):
+            if fused:
+                eng.forward_adjoint_adam(obj, probe, dists, data, mv(o_obj), 1e-2, k, affine=aff,
+                                         dists_mv=mv(o_d) if use_d else None, step_dists=1e-1,
+                                         affine_mv=mv(o_a) if use_a else None, step_affine=1e-3, affine_pin=ident if use_a else None)
+            else:
+                eng.forward_adjoint(obj, probe, dists, data, affine=aff, grad_obj=g, grad_dists=gd if use_d else None,
+                                    grad_affine=ga if use_a else None, overwrite=True)
+                items = [dict(opt=o_obj, x=obj.view(0, (obj.size,)), g=g.view(0, (g.size,)))]
+                if use_d:
+                    items.append(dict(opt=o_d, x=dists, g=gd))
+                if use_a:
+                    items.append(dict(opt=o_a, x=aff, g=ga, pin=ident))
+                apply_small_params(ctx, items, k)
+            losses.append(eng.loss())
+        out.append(dict(obj=obj.get(), d=dists.get(), a=aff.get(), m=[t.get() for o in (o_obj, o_d, o_a) for t in mv(o)], losses=losses))
+    sep, fus = out
+    assert np.abs(fus['obj'] - obj_h).max() > 1e-3 and (not use_d or np.abs(fus['d'] - d_h).max() > 1e-3)
+    assert np.array_equal(sep['obj'], fus['obj']) and np.array_equal(sep['d'], fus['d']) and np.array_equal(sep['a'], fus['a'])
+    for u, v in zip(sep['m'], fus['m']):
+        assert np.array_equal(u, v)
+    assert sep['losses'] == fus['losses']
+    if use_a:
+        assert np.array_equal(fus['a'][0], np.array([[1., 0, 0], [0, 1., 0]], np.float32))       # matrix 0 stays pinned to the identity
+
+
+@pytest.mark.parametrize('delay', [0, 2])
+@pytest.mark.regression
+def test_config5_driver_fused_update_equals_separate_update_bitwise(A, ctx, tmp_path, monkeypatch, delay):
+    """The config-5 feature set through reconstruct_ptychography with the Adam steps inside the gradient launch group
+    (adm_holo_fwd_adj_adam: the default where the update is plain Adam on one rank) and with the separate small-parameter launch
+    (ADM_HOLO_FUSED_ADAM=0): the same losses, object, distances and affine matrices, bit for bit -- also when the distances and
+    matrices only start moving after `other_params_update_delay` minibatches (adorym/optimizers.py:1000-1083)."""
+    from adorym_amd import holography as H
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F12_multidist.npz'))
+    Cc = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = Cc['N']
+    calls = {'fused': 0}
+    orig = H.HolographyEngine.forward_adjoint_adam
+
+    def counting(self, *a, **k):
+        calls['fused'] += 1
+        return orig(self, *a, **k)
+
+    monkeypatch.setattr(H.HolographyEngine, 'forward_adjoint_adam', counting)
+    out = []
+    for fusedv in ('0', '1'):
+        monkeypatch.setenv('ADM_HOLO_FUSED_ADAM', fusedv)
+        calls['fused'] = 0
+        st = A.reconstruct_ptychography(
+            fname=f['data'][None], obj_size=(N, N, 1), probe_pos=np.array([[0., 0.]]), theta_st=0, theta_end=0, n_theta=1, two_d_mode=True,
+            energy_ev=Cc['energy_ev'], psize_cm=Cc['psize_cm'], free_prop_cm=np.array(inp['dists_guess']), minibatch_size=1, n_epochs=4,
+            initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='plane', raw_data_type='intensity', unknown_type='real_imag',
+            gamma=0, alpha_d=0, alpha_b=0, optimizer='adam', learning_rate=1e-2, optimize_free_prop=True, free_prop_learning_rate=1e-1,
+            optimize_prj_affine=True, prj_affine_learning_rate=1e-3, n_dp_batch=1, randomize_probe_pos=True, save_path=str(tmp_path),
+            output_folder='c5_' + fusedv, store_checkpoint=False, use_checkpoint=False, return_state=True, other_params_update_delay=delay)
+        assert calls['fused'] == (4 if fusedv == '1' else 0)
+        out.append(st)
+    a, b = out
+    assert a['losses'] == b['losses']
+    for k in ('delta', 'beta', 'free_prop_cm', 'prj_affine_ls'):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.abs(b['free_prop_cm'] - np.array(inp['dists_guess'])).max() > 1e-3
