@@ -56,6 +56,8 @@ class Context(object):
         """A context-wide pinned upload ring for small tables (rotation lookups, ...): asynchronous host-to-device."""
         ring = getattr(self, '_uploader', None)
         if ring is None or ring.slot_bytes < min_slot_bytes:
+            if ring is not None:        # copies out of the smaller ring's pinned slots may still be in flight: it stays alive
+                self.__dict__.setdefault('_retired_uploaders', []).append(ring)
             ring = self._uploader = UploadRing(self, max(int(min_slot_bytes), 1 << 20), n_slots=4)
         return ring
 

@@ -304,6 +304,11 @@ class PtychographyModel(ForwardModel):
             # first minibatch of an angle: its rotation-adjoint tables are built here, on the side stream beside the
             # multislice kernel (0.4 ms of emit + sort), not on the main stream when the back-rotation asks for them
             coords.csr(eng.plan)
+        nxt = self.__dict__.pop('prefetch_table', None)
+        if want_grad and isinstance(nxt, RotationTable):
+            # ... and the NEXT angle's (the driver hands its table over during the current angle's last minibatch): built here, beside
+            # this kernel, instead of in front of the next angle's first launch with the GPU idle behind the host
+            nxt.csr(eng.plan)
         B = len(np.asarray(this_pos_batch).reshape(-1, 2))
         early_cover = want_grad and B <= eng.N_CU
         if early_cover:
@@ -421,6 +426,41 @@ class PtychographyModel(ForwardModel):
         eng = self.engine
         self._loss_thunk = (lambda: eng.loss_result(tok) + regv()) if data_loss_fn is None else (lambda: data_loss_fn() + regv())
 
+    def _resident_enabled(self):
+        if getattr(self, '_resident', None) is None:
+            shp = getattr(self.prj, 'shape', None)
+            limit = float(os.environ.get('ADM_RESIDENT_DATA_MB', '1024')) * 2 ** 20
+            self._resident = {} if (shp is not None and len(shp) == 4 and 4.0 * np.prod(shp) <= limit) else False
+        return self._resident is not False
+
+    def prefetch_data(self, i_theta):
+        """Resident datasets only: the processed data of angle ``i_theta`` on the device, uploaded ASYNCHRONOUSLY through a pinned
+        staging ring the first time the angle is asked for (a blocking copy here drains the stream: 1.3 ms of idle GPU at every
+        first-touch angle).  The driver asks one minibatch before the angle begins, so the host-side preparation (|prj|, a copy
+        into pinned memory: ~2 ms for 529 x 72 x 72 values) overlaps the current angle's last launch.  Returns the DeviceArray,
+        or None when the dataset is streamed."""
+        if not self._resident_enabled():
+            return None
+        td = self.common_vars.get('theta_downsample') or 1
+        key = int(i_theta) * td
+        dev = self._resident.get(key)
+        if dev is None:
+            host = self.get_data(i_theta, np.arange(self.prj.shape[1]), theta_downsample=td, ds_level=self.common_vars.get('ds_level', 1))
+            host = np.ascontiguousarray(host, dtype=np.float32)
+            dev = DeviceArray(self.device, host.shape, np.float32)
+            if host.nbytes <= (64 << 20):
+                ring = getattr(self, '_data_ring', None)
+                if ring is None or ring.slot_bytes < host.nbytes:
+                    if ring is not None:
+                        self.__dict__.setdefault('_retired_rings', []).append(ring)
+                    from .device import UploadRing
+                    ring = self._data_ring = UploadRing(self.device, host.nbytes, n_slots=2)
+                ring.upload(dev, host)
+            else:
+                dev.set(host)
+            self._resident[key] = dev
+        return dev
+
     def _target(self, this_i_theta, this_ind_batch):
         """The minibatch's measured data as the loss wants it (get_data).  Small datasets -- 2-D ptychography above all, where every
         epoch revisits the same angle -- are kept RESIDENT on the device, one processed [n_pos, Py, Px] array per angle uploaded the
@@ -429,16 +469,11 @@ class PtychographyModel(ForwardModel):
         their minibatches through the pinned ring, where the host work hides behind a 2 ms GPU step.  ADM_RESIDENT_DATA_MB (1024)."""
         td = self.common_vars.get('theta_downsample') or 1
         ind = np.asarray(this_ind_batch)
-        if getattr(self, '_resident', None) is None:
-            shp = getattr(self.prj, 'shape', None)
-            limit = float(os.environ.get('ADM_RESIDENT_DATA_MB', '1024')) * 2 ** 20
-            self._resident = {} if (shp is not None and len(shp) == 4 and 4.0 * np.prod(shp) <= limit) else False
-        if self._resident is not False and len(ind) > 0 and int(ind[-1]) - int(ind[0]) == len(ind) - 1 and np.all(np.diff(ind) == 1):
+        if self._resident_enabled() and len(ind) > 0 and int(ind[-1]) - int(ind[0]) == len(ind) - 1 and np.all(np.diff(ind) == 1):
             key = int(this_i_theta) * td
             dev = self._resident.get(key)
             if dev is None:
-                host = self.get_data(this_i_theta, np.arange(self.prj.shape[1]), theta_downsample=td, ds_level=self.common_vars.get('ds_level', 1))
-                dev = self._resident[key] = self.device.array(host)
+                dev = self.prefetch_data(this_i_theta)
             n_px = dev.shape[1] * dev.shape[2]
             return dev.view(int(ind[0]) * n_px, (len(ind), dev.shape[1], dev.shape[2]))
         return self.get_data(this_i_theta, this_ind_batch, theta_downsample=td, ds_level=self.common_vars.get('ds_level', 1))

@@ -839,6 +839,22 @@ def reconstruct_ptychography(
                     touched_planes = engine.y_footprint(probe_pos_int[gb_[:, 1]])
             forward_model.restricted_planes = touched_planes
 
+            # ---- the next angle's rotation data, one minibatch ahead: when the NEXT global batch starts a new angle, its lookup table
+            # is computed and uploaded now (host work while the GPU still runs the previous minibatch) and its adjoint CSR is built on
+            # the side stream beside this minibatch's multislice kernel.  Met cold, the first launch of an angle waited 2 - 2.5 ms for
+            # the host (table: NumPy + allocation; CSR: ~25 launches); the tables are kept for the whole reconstruction either way.
+            # (The table is computed TWO minibatches ahead, the CSR and -- for datasets small enough to live on the device -- the angle's
+            # measured data ONE ahead: the host is at most a minibatch ahead of the GPU and each of these costs it 1 - 2 ms.)
+            if builtin_model and not two_d_mode and not is_multi_dist and not rool:
+                def _angle_of(i_b):
+                    nb_ = ind_list_rand[i_b]
+                    return int(nb_[min(rank * minibatch_size, len(nb_) - 1), 0])
+                if i_batch + 2 < n_batch and _angle_of(i_batch + 2) != this_i_theta:
+                    rotation_tables(_angle_of(i_batch + 2))
+                if i_batch + 1 < n_batch and _angle_of(i_batch + 1) != this_i_theta:
+                    forward_model.prefetch_table = rotation_tables(_angle_of(i_batch + 1))
+                    forward_model.prefetch_data(_angle_of(i_batch + 1))
+
             # ---- gradients (ptychography.py:1017-1066) ----
             t_grad_0 = time.time()
             side_hook, init_grad = None, False
