@@ -67,6 +67,22 @@ class Context(object):
         a.set(host)
         return a
 
+    def array_async(self, host, dtype=None, max_bytes=64 << 20):
+        """Like array(), but the upload goes through a dedicated pinned two-slot ring and the stream is NOT drained (array() blocks
+        until the copy has happened, i.e. until everything queued before it has run).  Arrays above ``max_bytes`` take the blocking
+        way.  For bulk data that is needed a minibatch later (a resident dataset's next angle)."""
+        host = np.ascontiguousarray(host, dtype=dtype)
+        if host.nbytes > max_bytes:
+            return self.array(host)
+        a = DeviceArray(self, host.shape, host.dtype)
+        ring = getattr(self, '_bulk_ring', None)
+        if ring is None or ring.slot_bytes < host.nbytes:
+            if ring is not None:        # copies out of its pinned slots may still be in flight: it stays alive
+                self.__dict__.setdefault('_retired_uploaders', []).append(ring)
+            ring = self._bulk_ring = UploadRing(self, host.nbytes, n_slots=2)
+        ring.upload(a, host)
+        return a
+
     def event(self):
         return Event(self)
 

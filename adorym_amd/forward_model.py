@@ -446,18 +446,8 @@ class PtychographyModel(ForwardModel):
         dev = self._resident.get(key)
         if dev is None:
             host = self.get_data(i_theta, np.arange(self.prj.shape[1]), theta_downsample=td, ds_level=self.common_vars.get('ds_level', 1))
-            host = np.ascontiguousarray(host, dtype=np.float32)
-            dev = DeviceArray(self.device, host.shape, np.float32)
-            if host.nbytes <= (64 << 20):
-                ring = getattr(self, '_data_ring', None)
-                if ring is None or ring.slot_bytes < host.nbytes:
-                    if ring is not None:
-                        self.__dict__.setdefault('_retired_rings', []).append(ring)
-                    from .device import UploadRing
-                    ring = self._data_ring = UploadRing(self.device, host.nbytes, n_slots=2)
-                ring.upload(dev, host)
-            else:
-                dev.set(host)
+            up = getattr(self.device, 'array_async', None) or self.device.array
+            dev = up(np.ascontiguousarray(host, dtype=np.float32))
             self._resident[key] = dev
         return dev
 
