@@ -313,6 +313,12 @@ class PtychographyModel(ForwardModel):
         early_cover = want_grad and B <= eng.N_CU
         if early_cover:
             eng.build_cover()       # the overlap-add's cover lists only need the positions: built beside the kernel
+        nb = self.__dict__.pop('next_batch', None)
+        if nb is not None and want_grad:
+            # the NEXT evaluation's measured data (the driver says which): host -> device now, beside this kernel
+            t_next = self._target(nb[0], nb[1])
+            if isinstance(t_next, np.ndarray):
+                self._staged = ((int(nb[0]), np.asarray(nb[1]).tobytes()), eng.stage_target(t_next))
         ctx.end_fork()
         gp = None
         if want_probe_grad:
@@ -501,7 +507,11 @@ class PtychographyModel(ForwardModel):
         the gradients ordered like opt_args_ls: index 0 -> grad_obj, probe_real/probe_imag indices -> host arrays.
         """
         self._check_static(probe_defocus_mm, probe_pos_offset, probe_pos_correction, prj_pos_offset)
-        target = self._target(this_i_theta, this_ind_batch)
+        staged = self.__dict__.pop('_staged', None)
+        if staged is not None and staged[0] == (int(this_i_theta), np.asarray(this_ind_batch).tobytes()):
+            target = staged[1]          # uploaded during the previous evaluation (PtychographyModel._run, next_batch)
+        else:
+            target = self._target(this_i_theta, this_ind_batch)
         i_pr, i_pi = self.get_argument_index('probe_real'), self.get_argument_index('probe_imag')
         i_pc = self.get_argument_index('probe_pos_correction')
         want_probe = (i_pr in opt_args_ls) or (i_pi in opt_args_ls)

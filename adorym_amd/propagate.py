@@ -267,6 +267,29 @@ class MultisliceEngine(object):
         self._B = B
         return B
 
+    def stage_target(self, target):
+        """Upload the measured data [B,Py,Px] of the NEXT minibatch into one of two staging buffers on the stream the context is
+        enqueuing on right now -- the drivers call it inside the side-stream region of the current minibatch -- and return the
+        DeviceArray view to hand to that minibatch's set_batch().  The copy then runs beside the current multislice launch
+        instead of in front of the next rotation on the main stream (0.66 MB per 32 positions: 13 us; 11 MB per fused angle: 0.22 ms
+        of a PCIe-inclusive step)."""
+        host = np.ascontiguousarray(target, dtype=np.float32)
+        B = host.shape[0]
+        bufs = self.__dict__.setdefault('_stage_bufs', [None, None])
+        k = self.__dict__.get('_stage_k', 0) ^ 1
+        self._stage_k = k
+        need = max(B, self.max_batch or 0)
+        if bufs[k] is None or bufs[k].shape[0] < B:
+            bufs[k] = DeviceArray(self.ctx, (need,) + tuple(self.probe_size), np.float32)
+        view = bufs[k].view(0, (B,) + tuple(self.probe_size))
+        ring = self.__dict__.get('_stage_ring')
+        if ring is None or ring.slot_bytes < host.nbytes:
+            if ring is not None:
+                self.__dict__.setdefault('_retired_rings', []).append(ring)
+            ring = self._stage_ring = UploadRing(self.ctx, max(host.nbytes, need * int(np.prod(self.probe_size)) * 4), n_slots=2)
+        ring.upload(view, host)
+        return view
+
     def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, accumulate=True,
                    shifts=None, shift_index=None, grad_shifts=None):
         """Launch the fused kernel on the batch given to set_batch().  Returns nothing; read

@@ -733,6 +733,22 @@ def reconstruct_ptychography(
                            and not any(isinstance(r_, _RW) for r_ in forward_model.reg_list)
                            and (update_scheme == 'immediate' or fuse_per_angle))
 
+    stage_next_targets = os.environ.get('ADM_STAGE_TARGETS', '1') == '1'
+
+    def _next_evaluation(i_b):
+        """(i_theta, position indices) of the evaluation that follows global batch ``i_b`` on this rank within the epoch, or None:
+        the next minibatch ('immediate'), or all minibatches of the next angle as the fused 'per angle' launch takes them."""
+        if i_b + 1 >= n_batch:
+            return None
+        th, ind = rank_batch(ind_list_rand, i_b + 1, rank, minibatch_size, n_ranks)       # (tops up a short last batch now)
+        if not (update_scheme == 'per angle' and fuse_per_angle):
+            return th, ind
+        group, j = [ind], i_b + 2
+        while j < n_batch and ind_list_rand[j][0, 0] == ind_list_rand[i_b + 1][0, 0]:
+            group.append(rank_batch(ind_list_rand, j, rank, minibatch_size, n_ranks)[1])
+            j += 1
+        return th, np.concatenate(group)
+
     def flush_log():
         if pending_log[0] is None:
             return
@@ -919,6 +935,10 @@ def reconstruct_ptychography(
                     state.finish_update()
             if is_multi_dist and builtin_model:
                 forward_model.fused_adam = holo_fused
+            # which measured data the NEXT evaluation needs, so that the model can send them to the device beside this one's launch
+            # (streamed datasets; resident ones are views of device arrays already)
+            if builtin_model and not is_multi_dist and stage_next_targets:
+                forward_model.next_batch = _next_evaluation(i_batch)
             grads = diff.get_gradients(_accumulate_into=gradient.arr, _side_hook=side_hook, _init_grad=init_grad, **grad_func_args)
             print_flush('  Gradient calculation done in {} s.'.format(time.time() - t_grad_0), sto_rank, rank, **stdout_options)
             if initialize_gradients:

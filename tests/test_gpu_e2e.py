@@ -227,3 +227,33 @@ def test_driver_through_rccl_world1_equals_local_run_bitwise(tmp_path, extra, rc
     for k in ('delta', 'beta', 'probe_real', 'probe_imag'):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
     assert np.array_equal(np.asarray(a['losses']), np.asarray(b['losses']))
+
+
+@pytest.mark.parametrize('scheme', ['immediate', 'per angle'])
+@pytest.mark.regression
+def test_streamed_data_staged_ahead_equals_upload_on_demand_bitwise(tmp_path, monkeypatch, scheme):
+    """A dataset that is STREAMED from the host (ADM_RESIDENT_DATA_MB=0 forces it: config 3's 5.5 GB takes this path; the measured
+    data of a minibatch is handed over by get_data, adorym/forward_model.py:113-119): with ADM_STAGE_TARGETS=1 the next evaluation's
+    data goes to the device during the current one (side stream, two staging buffers), with 0 it is uploaded on demand on the main
+    stream.  Same losses, same object, bit for bit -- 'immediate' (a minibatch ahead) and fused 'per angle' (an angle ahead)."""
+    from adorym_amd import propagate as P
+    monkeypatch.setenv('ADM_RESIDENT_DATA_MB', '0')
+    n_staged = {'n': 0}
+    orig = P.MultisliceEngine.stage_target
+
+    def counting(self, t):
+        n_staged['n'] += 1
+        return orig(self, t)
+
+    monkeypatch.setattr(P.MultisliceEngine, 'stage_target', counting)
+    out = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('ADM_STAGE_TARGETS', flag)
+        n_staged['n'] = 0
+        _, _, st = run(tmp_path / flag, n_epochs=2, optimizer='adam', learning_rate=1e-6, update_scheme=scheme, gamma=1e-6, alpha_d=1e-4, alpha_b=1e-5)
+        out.append(st)
+        n_eval = len(st['losses'])
+        assert n_staged['n'] == (0 if flag == '0' else n_eval - 2)      # every evaluation but the first of each epoch was staged ahead
+    a, b = out
+    assert a['losses'] == b['losses']
+    assert np.array_equal(a['delta'], b['delta']) and np.array_equal(a['beta'], b['beta'])
