@@ -82,6 +82,32 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float2* __restric
     }
 }
 
+// R objects stacked along y, block r (planes [r * Yb, (r + 1) * Yb) of the stacked rotated frame) gathered with ITS angle's table
+// from the ONE real object (adorym_amd.AngleBatch: the 16 angles of a config-2 update): one launch instead of R launches of a
+// few blocks each.  Same arithmetic per voxel as rotate_fwd_kernel.
+__global__ __launch_bounds__(256) void rotate_fwd_stack_kernel(const float2* __restrict__ obj, const uint16_t* const* __restrict__ tables,
+                                                               int Yb, float2* __restrict__ rot, float2* __restrict__ trans, float k1,
+                                                               float sigma, RotGeom g, int y_chunk) {
+    const int xr = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int zr = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (xr >= g.X || zr >= g.Z) return;
+    const int ya = blockIdx.z * y_chunk;                 // (y_chunk divides Yb: a block never straddles two angles)
+    const int r = ya / Yb;
+    const Bilin b = make_bilin(tables[r], xr, zr, g.X, g.Z);
+    const int yb = min(ya + y_chunk, g.Y);
+    const size_t plane = (size_t)g.X * g.Z;
+    for (int y = ya; y < yb; ++y) {
+        const float2* o = obj + (size_t)(y - r * Yb) * plane;
+        const float2 v00 = o[b.i00], v01 = o[b.i01], v10 = o[b.i10], v11 = o[b.i11];
+        float2 q;
+        q.x = v00.x * b.w00 + v01.x * b.w01 + v10.x * b.w10 + v11.x * b.w11;
+        q.y = v00.y * b.w00 + v01.y * b.w01 + v10.y * b.w10 + v11.y * b.w11;
+        const size_t o_rot = ((size_t)zr * g.Yp + g.pad_y0 + y) * g.Xp + g.pad_x0 + xr;
+        if (rot) rot[o_rot] = q;
+        if (trans) trans[o_rot] = slice_transmission(q, k1, sigma);
+    }
+}
+
 // No rotation (coords == nullptr) on a thin object -- the 2-D modes, Z = 1: the general kernels above would keep one thread in
 // sixteen busy (their 16 x 16 patches span (x', z')).  One thread per voxel, z fastest like the object: the same numbers (weights
 // 1, 0, 0, 0), 13-14 us -> a plain copy's time on the config-1 shape.
@@ -323,6 +349,116 @@ __global__ __launch_bounds__(256) void rotate_adj_staged_kernel(const float2* __
             }
         }
         __syncthreads();
+    }
+}
+
+// The staged adjoint for R objects stacked along y (adorym_amd.AngleBatch): block r of the stacked gradient image is back-rotated with
+// ITS angle's CSR and all R contributions are added, r ascending, to the ONE real gradient -- c = g; c += a_0; c += a_1; ... ; g = c:
+// the additions R sequential launches of rotate_adj_staged_kernel would make, in the same order, in one launch (16 launches of
+// 6 - 12 us each per config-2 update).  Same three cases per (patch, angle) as above, written without early exits so that every
+// thread reaches the barriers that separate one angle's use of the LDS stage from the next.
+struct AdjTables { const int* ptr; const int* src; const unsigned short* lsrc; const float* wgt; const int4* boxes; };
+__global__ __launch_bounds__(256) void rotate_adj_staged_stack_kernel(const float2* __restrict__ grot, const AdjTables* __restrict__ tabs,
+                                                                      int R, int Yb, float2* __restrict__ gobj, RotGeom g, int npl) {
+    __shared__ float2 stage[4 * ADM_STAGE_MAX];
+    const int y0 = blockIdx.z * npl;                     // first plane (of the REAL object, Yb planes) of this block: npl = 1, 2 or 4 planes
+    const int ny = min(npl, Yb - y0);
+    const size_t slice = (size_t)g.Yp * g.Xp;
+    const size_t plane = (size_t)g.X * g.Z;
+    const int lx = threadIdx.x >> 4, lz = threadIdx.x & 15;
+    const int x = blockIdx.x * 16 + lx, z = blockIdx.y * 16 + lz;
+    const bool ok = (x < g.X) && (z < g.Z);
+    const int t = ok ? x * g.Z + z : 0;
+    float2* o = gobj + (size_t)y0 * plane + (size_t)x * g.Z + z;
+    float2 c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (ok && i < ny) ? o[(size_t)i * plane] : make_float2(0.f, 0.f);
+    for (int r = 0; r < R; ++r) {
+        const AdjTables T = tabs[r];
+        const int4 box = T.boxes[blockIdx.y * gridDim.x + blockIdx.x];      // (x0, z0, w, h)
+        const int ys = r * Yb + y0;                     // the same planes in block r of the stacked image
+        const int bw = box.z, bh = box.w, per = bw * bh;
+        const int beg = ok ? T.ptr[t] : 0, end = ok ? T.ptr[t + 1] : 0;
+        if (bw == 0) {
+            const size_t row = (size_t)(g.pad_y0 + ys) * g.Xp;
+            float2 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = make_float2(0.f, 0.f);
+            for (int j = beg; j < end; ++j) {
+                const float w = T.wgt[j];
+                const float2* q = grot + (size_t)T.src[j] + row;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < ny) { const float2 v = q[(size_t)i * g.Xp]; a[i].x += w * v.x; a[i].y += w * v.y; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i].x += a[i].x; c[i].y += a[i].y; }
+        } else if (per <= ADM_STAGE_MAX) {
+            for (int idx = threadIdx.x; idx < npl * per; idx += 256) {
+                const int p = idx / per, rem = idx - p * per;
+                const int zz = rem / bw, xx = rem - zz * bw;
+                float2 v = make_float2(0.f, 0.f);
+                if (p < ny) v = grot[(size_t)(box.y + zz) * slice + (size_t)(g.pad_y0 + ys + p) * g.Xp + g.pad_x0 + box.x + xx];
+                stage[p * ADM_STAGE_MAX + rem] = v;
+            }
+            __syncthreads();
+            float2 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = make_float2(0.f, 0.f);
+            for (int j = beg; j < end; ++j) {
+                const float w = T.wgt[j];
+                const int q = T.lsrc[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < ny) { const float2 v = stage[i * ADM_STAGE_MAX + q]; a[i].x += w * v.x; a[i].y += w * v.y; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i].x += a[i].x; c[i].y += a[i].y; }
+        } else {
+            const int npp = (npl >= 2 && 2 * per <= 4 * ADM_STAGE_MAX) ? 2 : 1;
+            for (int p0 = 0; p0 < ny; p0 += npp) {
+                for (int idx = threadIdx.x; idx < npp * per; idx += 256) {
+                    const int pp = idx / per, rem = idx - pp * per;
+                    const int zz = rem / bw, xx = rem - zz * bw;
+                    float2 v = make_float2(0.f, 0.f);
+                    if (p0 + pp < ny) v = grot[(size_t)(box.y + zz) * slice + (size_t)(g.pad_y0 + ys + p0 + pp) * g.Xp + g.pad_x0 + box.x + xx];
+                    stage[idx] = v;
+                }
+                __syncthreads();
+                float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+                const int second = (npp == 2) ? per : 0;
+                for (int j = beg; j < end; j += 8) {
+                    float w[8];
+                    int q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int jj = min(j + u, end - 1);
+                        w[u] = (j + u < end) ? T.wgt[jj] : 0.f;
+                        q[u] = T.lsrc[jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float2 v0 = stage[q[u]];
+                        const float2 v1 = stage[q[u] + second];
+                        acc0.x += w[u] * v0.x; acc0.y += w[u] * v0.y;
+                        acc1.x += w[u] * v1.x; acc1.y += w[u] * v1.y;
+                    }
+                }
+                // (p0 is uniform: the static indices below keep c[] in registers)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i == p0) { c[i].x += acc0.x; c[i].y += acc0.y; }
+                    if (npp == 2 && i == p0 + 1) { c[i].x += acc1.x; c[i].y += acc1.y; }
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();                                 // the next angle refills the stage
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < ny) o[(size_t)i * plane] = c[i];
     }
 }
 
@@ -962,7 +1098,12 @@ extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* 
     if (y_lo < 0 || y_hi > d.obj_y || y_lo > y_hi) return fail(ADM_ERR_INVALID, "adm_rotate_fwd: bad y range");
     if (y_lo == y_hi) return ADM_OK;
     RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
-    const int y_chunk = 32;
+    // y planes per block: 32 (the (x', z') sampling weights are decoded once per block and reused) -- unless that leaves the chip
+    // empty: a 64^3 object has 16 patches x 2 chunks = 32 blocks that each walk 32 planes one dependent gather after the other
+    // (17 us per launch, 16 launches per config-2 update); then fewer planes per block, down to one
+    int y_chunk = 32;
+    const int n_patch = ((d.obj_x + 15) / 16) * ((d.obj_z + 15) / 16);
+    while (y_chunk > 1 && n_patch * ((y_hi - y_lo + y_chunk - 1) / y_chunk) < 512) y_chunk >>= 1;
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + y_chunk - 1) / y_chunk);
     // cache mode 2: only the transmissions are written (half the stores); obj_rot then merely names the image the cache holds
     float2* rot_out = (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot;
@@ -972,6 +1113,25 @@ extern "C" int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* 
     else
         hipLaunchKernelGGL(rotate_fwd_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj, coords, rot_out, plan->trans_dev,
                            d.k1, (float)d.sign_convention, g, y_lo, y_hi, y_chunk);
+    ADM_HIP(hipGetLastError());
+    if (plan->trans_dev) plan->trans_src = obj_rot;
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_fwd_stack(adm_plan* plan, const float* obj, const void* tables_dev, int n_tables, float* obj_rot) {
+    if (!plan || !obj || !tables_dev || !obj_rot) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_stack: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (n_tables < 1 || d.obj_y % n_tables) return fail(ADM_ERR_INVALID, "adm_rotate_fwd_stack: the plan's y extent is not n_tables blocks");
+    const int Yb = d.obj_y / n_tables;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    int y_chunk = 32;
+    while (y_chunk > 1 && Yb % y_chunk) y_chunk >>= 1;
+    const int n_patch = ((d.obj_x + 15) / 16) * ((d.obj_z + 15) / 16);
+    while (y_chunk > 1 && n_patch * (d.obj_y / y_chunk) < 512) y_chunk >>= 1;
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, d.obj_y / y_chunk);
+    float2* rot_out = (plan->trans_dev && plan->trans_only) ? (float2*)nullptr : (float2*)obj_rot;
+    hipLaunchKernelGGL(rotate_fwd_stack_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)obj,
+                       (const uint16_t* const*)tables_dev, Yb, rot_out, plan->trans_dev, d.k1, (float)d.sign_convention, g, y_chunk);
     ADM_HIP(hipGetLastError());
     if (plan->trans_dev) plan->trans_src = obj_rot;
     return ADM_OK;
@@ -1077,6 +1237,24 @@ extern "C" int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, cons
     dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (y_hi - y_lo + 3) / 4);
     hipLaunchKernelGGL(rotate_adj_staged_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot, csr_ptr, csr_src,
                        (const unsigned short*)csr_lsrc, csr_w, (const int4*)boxes, (float2*)grad_obj, g, y_lo, y_hi);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+extern "C" int adm_rotate_adj_staged_stack(adm_plan* plan, const float* grad_rot, const void* tables_dev, int n_tables, float* grad_obj) {
+    if (!plan || !grad_rot || !tables_dev || !grad_obj) return fail(ADM_ERR_INVALID, "adm_rotate_adj_staged_stack: null argument");
+    const adm_plan_desc& d = plan->d;
+    if (n_tables < 1 || d.obj_y % n_tables) return fail(ADM_ERR_INVALID, "adm_rotate_adj_staged_stack: the plan's y extent is not n_tables blocks");
+    const int Yb = d.obj_y / n_tables;
+    RotGeom g{d.obj_y, d.obj_x, d.obj_z, plan->Yp, plan->Xp, d.pad_y0, d.pad_x0};
+    // planes per block: four (one pass over a patch's CSR entries serves four planes) unless that leaves the chip short of blocks --
+    // every block walks the n_tables angles one after the other, so a 64^3 object wants all 1024 (patch, plane) pairs in flight
+    int npl = 4;
+    const int n_patch = ((d.obj_x + 15) / 16) * ((d.obj_z + 15) / 16);
+    while (npl > 1 && n_patch * ((Yb + npl - 1) / npl) < 1024) npl >>= 1;
+    dim3 grid((d.obj_x + 15) / 16, (d.obj_z + 15) / 16, (Yb + npl - 1) / npl);
+    hipLaunchKernelGGL(rotate_adj_staged_stack_kernel, grid, dim3(256), 0, plan->ctx->stream, (const float2*)grad_rot,
+                       (const AdjTables*)tables_dev, n_tables, Yb, (float2*)grad_obj, g, npl);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

@@ -561,6 +561,26 @@ class AngleBatch(object):
         Y, X, Z = self.obj_size
         return DeviceArray(self.ctx, (self.R * Y, X, Z, 2), np.float32, ptr=arr.ptr - r * self.block_bytes)
 
+    def rotate_all(self, obj, tables):
+        """Block r of the stacked rotated object = ``obj`` rotated with tables[r], all R blocks in ONE launch (adm_rotate_fwd_stack):
+        the table addresses go up through the pinned ring (R pointers), nothing else changes hands."""
+        eng = self.engine
+        if getattr(self, '_table_ptrs', None) is None:
+            self._table_ptrs = DeviceArray(self.ctx, (self.R,), np.uint64)
+        self.ctx.uploader().upload(self._table_ptrs, np.array([t.ptr for t in tables], dtype=np.uint64))
+        check(self.ctx.lib.adm_rotate_fwd_stack(eng.plan.handle, obj.ptr, self._table_ptrs.ptr, self.R, eng.obj_rot.ptr))
+
+    def rotate_adjoint_all(self, grad_obj, tables):
+        """grad_obj += sum over r (ascending) of R_r^T (block r of the stacked gradient image), ONE launch
+        (adm_rotate_adj_staged_stack): the same additions, in the same order, as R calls of rotate_adjoint."""
+        eng = self.engine
+        parts = [t.csr(eng.plan) for t in tables]             # (ptr, src, lsrc, w, boxes) device arrays per angle
+        if getattr(self, '_adj_ptrs', None) is None:
+            self._adj_ptrs = DeviceArray(self.ctx, (self.R, 5), np.uint64)
+        self.ctx.uploader().upload(self._adj_ptrs, np.array([[p_[0].ptr, p_[1].ptr, p_[2].ptr, p_[3].ptr, p_[4].ptr] for p_ in parts],
+                                                            dtype=np.uint64))
+        check(self.ctx.lib.adm_rotate_adj_staged_stack(eng.plan.handle, eng.grad_rot.ptr, self._adj_ptrs.ptr, self.R, grad_obj.ptr))
+
     def loss_and_grad(self, obj, grad_obj, tables, probe, targets):
         """obj, grad_obj: DeviceArray [Y,X,Z,2]; tables: R RotationTables (built for obj_size); targets [R,Py,Px] magnitudes
         (host or device).  grad_obj += sum over angles of d(mean loss of angle r)/d obj.  Returns the R losses (blocking)."""
@@ -573,12 +593,10 @@ class AngleBatch(object):
             raise ValueError('AngleBatch.loss_and_grad: targets must hold R x Py x Px = %d values, got %d' % (self.R * eng.n_det, n_t))
         # (the shifted base pointers below rely on the rotation kernels touching only the planes [r*Y, (r+1)*Y) they are given)
         eng.set_batch(self.pos, targets)
-        for r, t in enumerate(tables):
-            eng.rotate(self._shifted(obj, r), t, (r * Y, (r + 1) * Y))
+        self.rotate_all(obj, tables)
         n_det = eng.n_det
         eng.multislice(probe, grad_scale=2.0 / n_det)          # every angle is its own minibatch of one: mean over ITS pixels
-        for r, t in enumerate(tables):
-            eng.rotate_adjoint(self._shifted(grad_obj, r), t, (r * Y, (r + 1) * Y))
+        self.rotate_adjoint_all(grad_obj, tables)
         eng._check_overflow()
         sums = eng.loss_sums(self.R)
         return sums / n_det

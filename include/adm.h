@@ -222,6 +222,11 @@ size_t adm_plan_workspace_bytes(const adm_plan* plan, int batch);
  * (adorym/util.py:492-516); NULL = no rotation (two_d_mode / theta-independent copy).
  * adm_rotate_adj is its transpose (autograd of grid_sampler_2d): grad_obj += R^T grad_rot. */
 int adm_rotate_fwd(adm_plan* plan, const float* obj, const uint16_t* coords, float* obj_rot, int y_lo, int y_hi);
+/* The same gather for a plan whose y extent is n_tables blocks of equal height -- R objects stacked along y, one rotation angle
+ * each (adorym_amd.AngleBatch: BASELINE config 2's 16 angles per update, adorym/ptychography.py:342-346 forces minibatch 1 per rank
+ * there) -- all from the ONE object `obj` [obj_y / n_tables, X, Z, 2]: block r of obj_rot = obj rotated with tables_dev[r]
+ * (device array of n_tables pointers to fp16 lookup tables).  One launch instead of n_tables. */
+int adm_rotate_fwd_stack(adm_plan* plan, const float* obj, const void* tables_dev, int n_tables, float* obj_rot);
 int adm_rotate_adj(adm_plan* plan, const float* grad_rot, const uint16_t* coords, float* grad_obj, int y_lo, int y_hi);
 /* Same operator as adm_rotate_adj, evaluated as a deterministic gather: the transpose of the bilinear sampling
  * matrix of one angle in CSR form over object-plane voxels t = x*Z + z:
@@ -239,6 +244,12 @@ int adm_rotate_adj_csr(adm_plan* plan, const float* grad_rot, const int32_t* csr
  * patch without a usable box, which gathers through csr_src as adm_rotate_adj_csr does. */
 int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* csr_ptr, const int32_t* csr_src,
                           const uint16_t* csr_lsrc, const float* csr_w, const int32_t* boxes, float* grad_obj, int y_lo, int y_hi);
+/* adm_rotate_adj_staged for a plan whose y extent is n_tables stacked blocks (see adm_rotate_fwd_stack): block r of grad_rot is
+ * back-rotated with the r-th set of CSR tables and the n_tables contributions are ADDED, r ascending, into the ONE gradient
+ * grad_obj [obj_y / n_tables, X, Z, 2] -- the additions n_tables sequential calls would make (`gradient.arr = comm.allreduce(...)`
+ * of 16 single-angle ranks, adorym/ptychography.py:1113-1114), in one launch.  tables_dev: device array of n_tables records of five
+ * device pointers (csr_ptr, csr_src, csr_lsrc, csr_w, boxes: the outputs of adm_rotation_csr_build, in that order). */
+int adm_rotate_adj_staged_stack(adm_plan* plan, const float* grad_rot, const void* tables_dev, int n_tables, float* grad_obj);
 /* Builds, on the device, everything adm_rotate_adj_staged needs for one angle from the fp16 lookup table `coords`
  * (device, [X*Z][2]): csr_ptr [X*Z+1], csr_src / csr_lsrc / csr_w [4*X*Z] (only the first csr_ptr[X*Z] entries are
  * meaningful), boxes [ceil(Z/16)*ceil(X/16)][4].  Rows ordered by target voxel, entries by ascending source offset: the same

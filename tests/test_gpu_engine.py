@@ -378,6 +378,42 @@ def test_c2_sixteen_virtual_ranks_sum_vs_oracle(A, ctx):
     assert rel(g2, g) < 2e-6, rel(g2, g)          # (order of the fp32 additions per voxel differs: data terms first, L1 terms last)
 
 
+@pytest.mark.parametrize('N,R', [(64, 16), (48, 5)])
+@pytest.mark.regression
+def test_angle_batch_stacked_rotations_equal_per_angle_launches_bitwise(A, ctx, N, R):
+    """adm_rotate_fwd_stack / adm_rotate_adj_staged_stack (one launch for the R angles of an AngleBatch) against R calls of
+    adm_rotate_fwd / adm_rotate_adj_staged on the same stacked engine: the stacked rotated object, the losses and the summed
+    gradient agree bit for bit (the stacked adjoint adds the angles' contributions r ascending, as the sequence of launches
+    does).  N = 48: patches and plane groups with tails."""
+    r = cases.rng(1000 + N)
+    guess = np.stack([1e-5 * r.uniform(0.5, 1.5, (N, N, N)), 1e-7 * r.uniform(0.5, 1.5, (N, N, N))], -1).astype(np.float32)
+    thetas = np.linspace(0.1, 2 * np.pi, R, dtype='float32')
+    data = (1 + 0.05 * np.abs(r.standard_normal((R, N, N)))).astype(np.float32)
+    probe = ctx.array(c2(np.ones((N, N), complex))[None])
+    ab = A.AngleBatch(ctx, (N, N, N), (N, N), R, 800., 0.67e-7, free_prop_cm=0)
+    eng = ab.engine
+    tabs = [A.RotationTable(ctx, (N, N, N), th) for th in thetas]
+    obj = ctx.array(guess)
+    # one launch each
+    g1 = ctx.zeros((N, N, N, 2))
+    l1 = ab.loss_and_grad(obj, g1, tabs, probe, data)
+    rot1 = eng.obj_rot.get()
+    # R launches each, same engine
+    g2 = ctx.zeros((N, N, N, 2))
+    eng.set_batch(ab.pos, data)
+    for k, t in enumerate(tabs):
+        eng.rotate(ab._shifted(obj, k), t, (k * N, (k + 1) * N))
+    rot2 = eng.obj_rot.get()
+    eng.multislice(probe, grad_scale=2.0 / eng.n_det)
+    for k, t in enumerate(tabs):
+        eng.rotate_adjoint(ab._shifted(g2, k), t, (k * N, (k + 1) * N))
+    l2 = eng.loss_sums(R) / eng.n_det
+    assert np.array_equal(rot1, rot2)
+    assert np.array_equal(l1, l2)
+    a, b = g1.get(), g2.get()
+    assert np.abs(a).max() > 0 and np.array_equal(a, b)
+
+
 def c2(z):
     return np.stack([z.real, z.imag], -1).astype(np.float32)
 

@@ -101,16 +101,14 @@ def bench_c2(ctx, steps=30):
     def step_stack(k, timed):
         check(ctx.lib.adm_reg_grad_set(eng.plan.handle, obj.ptr, a_d * R, a_b * R, 0.0, grad.ptr, None))
         e2.set_batch(ab.pos, data)
-        for i, t in enumerate(tables):
-            e2.rotate(ab._shifted(obj, i), t, (i * Yb, (i + 1) * Yb))
+        ab.rotate_all(obj, tables)
         if timed:
             ev[0].record()
         e2.multislice(probe, grad_scale=2.0 / e2.n_det, accumulate=False)
         if timed:
             ev[1].record()
         e2.accumulate_tiles()
-        for i, t in enumerate(tables):
-            e2.rotate_adjoint(ab._shifted(grad, i), t, (i * Yb, (i + 1) * Yb))
+        ab.rotate_adjoint_all(grad, tables)
         st.exchange_and_update('adam', k, {'step_size': lr})
         return ev[0].elapsed_ms(ev[1]) if timed else 0.0
 
