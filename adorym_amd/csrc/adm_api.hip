@@ -442,7 +442,6 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
                                      "produced by adm_rotate_fwd on it");
     if (plan->generic) {
         if (use_t) { p.obj_rot = plan->trans_dev; p.pre_t = 1; }
-        if (per_position) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: per-position probes need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
         p.gen_py = d.probe_y; p.gen_px = d.probe_x;
         p.gen_nrx = plan->gen_nrx; p.gen_nry = plan->gen_nry;
         for (int i = 0; i < 8; ++i) { p.gen_rx[i] = plan->gen_rx[i]; p.gen_ry[i] = plan->gen_ry[i]; }

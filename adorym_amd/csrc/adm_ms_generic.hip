@@ -14,7 +14,8 @@
 //
 // Rows of the workspace (stored fields, tile gradients) are pixel-major [Py][Px]; tile_accumulate follows through
 // TileGeom::pixel_major.  Supported: delta_beta and real_imag, any binning, several probe modes, all detector / loss
-// variants, beamstop weights.  Not supported here: one probe set per position (sub-pixel position refinement).
+// variants, beamstop weights, one probe set per position (adm_multislice_fwd_adj_pp).  Not supported here: the Fourier
+// shift of the probes (adm_probe_shift: sub-pixel position refinement).
 #include <hip/hip_runtime.h>
 #include "adm_common.h"
 #include "adm_fft.h"
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(1024) void ms_generic_kernel(MsParams p) {
 
     for (int m = 0; m < M; ++m) {
         float2* stash = p.stash + ((size_t)b * M + m) * per;
-        const float2* probe = p.probe + (size_t)m * row;
+        const float2* probe = p.probe + (size_t)b * p.probe_bstride + (size_t)m * row;     // (stride 0: one probe set for all positions)
         for (int i = g.tid; i < g.n; i += g.nt) g.fld[i] = probe[i];
         __syncthreads();
         // ---------------- forward sweep ----------------

@@ -15,6 +15,7 @@ from ._lib import check
 from .device import DeviceArray
 from .propagate import RotationTable
 from .regularizers import combined_weights
+from .util import calculate_pad_len
 
 
 class ForwardModel(object):
@@ -549,6 +550,11 @@ class MultiDistModel(PtychographyModel):
     (fresnel_propagate_wrapped); the loss compares with the measured holograms, optionally registered by the affine
     matrices ``prj_affine_ls`` (w.affine_transform).  Gradients w.r.t. obj, probe, free_prop_cm and prj_affine_ls come from
     the hand-derived adjoint in adm_holo_fwd_adj.  ``common_vars_dict['holo_engine']`` is an adorym_amd.HolographyEngine.
+
+    Data divided into sub-tiles and / or propagated with a safe zone (n_blocks > 1 or safe_zone_width > 0, :884-1034):
+    ``common_vars_dict['tile_engines']`` holds one MultisliceEngine per distance -- tile = sub-hologram + 2 safe zones, near-field
+    detector at that distance, detector mask = the sub-hologram's window -- and a minibatch of tiles is n_dists launches of the
+    multislice kernel with one probe window per tile (adm_multislice_fwd_adj_pp); object gradient only.
     """
 
     def __init__(self, loss_function_type='lsq', distribution_mode=None, device=None, common_vars_dict=None,
@@ -558,6 +564,7 @@ class MultiDistModel(PtychographyModel):
         if loss_function_type != 'lsq':
             raise NotImplementedError('MultiDistModel: only the LSQ loss is on the accelerated path')
         self.holo = common_vars_dict['holo_engine'] if common_vars_dict else None
+        self.tiles = common_vars_dict.get('tile_engines') if common_vars_dict else None
         self._data_key = None
         self._data_dev = None
         self._small = {}
@@ -568,10 +575,92 @@ class MultiDistModel(PtychographyModel):
                      'optimize_ctf_lg_kappa'):
             if cv.get(flag):
                 raise NotImplementedError('%s with MultiDistModel is outside the accelerated path' % flag)
-        if safe_zone_width not in (0, None):
-            raise NotImplementedError('safe_zone_width > 0 is outside the accelerated path')
         if not cv.get('two_d_mode'):
             raise NotImplementedError('MultiDistModel is accelerated for two_d_mode (one object slice) only')
+        if self.tiles is not None:
+            if int(safe_zone_width or 0) != int(cv.get('safe_zone_width') or 0):
+                raise ValueError('safe_zone_width differs from the width the tile engines were built for')
+            for flag in ('optimize_free_prop', 'optimize_prj_affine'):
+                if cv.get(flag):
+                    raise NotImplementedError('%s with multi-distance data divided into sub-tiles is outside the accelerated path' % flag)
+        elif safe_zone_width not in (0, None):
+            raise NotImplementedError('safe_zone_width > 0 needs the tile engines (the driver builds them)')
+
+    # ------------------------------------------------------------------ sub-tiles + safe zone (forward_model.py:884-1034)
+    def _tile_probes(self, probe_real, probe_imag, pos):
+        """One probe window [1, T, T] per tile of the batch, cut from the full-field probe padded with 1 + 0i
+        (forward_model.py:916-925, 944-994).  Line :1005 passes ``subprobe_imag_ls_ls[k][i_mode, :, :]`` (no leading ':'): with
+        one mode that is the IMAGINARY window of the first tile of the n_dp_batch chunk, used for the whole chunk -- kept, it is
+        what the reference computes (golden F18 pins it with a probe that varies over the field).  The probe is not optimised on
+        this path, so the windows of a batch are built once per distinct batch and stay on the device."""
+        cv = self.common_vars
+        szw = int(cv.get('safe_zone_width') or 0)
+        T = self.tiles[0].probe_size
+        if getattr(self, '_probe_host', None) is None:
+            host = probe_real.get() if isinstance(probe_real, DeviceArray) else \
+                np.stack([np.asarray(probe_real, np.float32), np.asarray(probe_imag, np.float32)], -1)
+            self._probe_host = host.reshape(host.shape[-3], host.shape[-2], 2)
+            self._probe_cache = {}
+        key = pos.tobytes()
+        dev = self._probe_cache.get(key)
+        if dev is None:
+            pr, pi = self._probe_host[..., 0], self._probe_host[..., 1]
+            pad = np.zeros((2, 2), int)
+            if szw > 0:
+                pad = calculate_pad_len(pr.shape, pos - szw, T)
+                pr = np.pad(pr, [tuple(pad[0]), tuple(pad[1])], mode='constant', constant_values=1)
+                pi = np.pad(pi, [tuple(pad[0]), tuple(pad[1])], mode='constant', constant_values=0)
+            n_dp = int(cv.get('n_dp_batch') or len(pos))
+            host = np.empty((len(pos), 1, T[0], T[1], 2), np.float32)
+            for j, p in enumerate(pos):
+                y, x = int(p[0] + pad[0, 0] - szw), int(p[1] + pad[1, 0] - szw)
+                j0 = (j // n_dp) * n_dp
+                y0, x0 = int(pos[j0, 0] + pad[0, 0] - szw), int(pos[j0, 1] + pad[1, 0] - szw)
+                host[j, 0, :, :, 0] = pr[y:y + T[0], x:x + T[1]]
+                host[j, 0, :, :, 1] = pi[y0:y0 + T[0], x0:x0 + T[1]]
+            if len(self._probe_cache) > 4096:
+                self._probe_cache.clear()
+            dev = self._probe_cache[key] = self.device.array(host)
+        return dev
+
+    def _tile_targets(self, this_i_theta, this_ind_batch, i_dist):
+        """|prj[theta, ind + i_dist * n_blocks]| (forward_model.py:1049-1056) inside a zero frame of the tile's size: the safe zone
+        carries no data and no weight in the loss."""
+        cv = self.common_vars
+        szw = int(cv.get('safe_zone_width') or 0)
+        T = self.tiles[0].probe_size
+        n_blocks = self.prj.shape[1] // len(self.tiles)
+        ind = np.asarray(this_ind_batch) + i_dist * n_blocks
+        t = self.get_data(this_i_theta, ind, theta_downsample=cv.get('theta_downsample') or 1, ds_level=cv.get('ds_level', 1))
+        if szw == 0:
+            return t
+        full = np.zeros((len(ind), T[0], T[1]), np.float32)
+        full[:, szw:szw + t.shape[1], szw:szw + t.shape[2]] = t
+        return full
+
+    def _run_tiled(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad, grad_obj=None,
+                   want_pred=False):
+        """n_dists launches over the minibatch's tiles.  The loss is the mean over distances x tiles x sub-hologram pixels
+        (forward_model.py:1019-1029, 1087): every launch scales its gradient with 2 / (n_dists B n_sub)."""
+        szw = int(self.common_vars.get('safe_zone_width') or 0)
+        pos = np.ascontiguousarray(np.round(np.asarray(this_pos_batch)).astype(np.int64).reshape(-1, 2))
+        B, nd = len(pos), len(self.tiles)
+        probes_b = self._tile_probes(probe_real, probe_imag, pos)
+        tokens, preds = [], []
+        for i, eng in enumerate(self.tiles):
+            eng.set_batch(pos - szw, self._tile_targets(this_i_theta, this_ind_batch, i))
+            yr = eng.y_footprint(pos - szw)
+            eng.rotate(obj, None, yr)
+            eng.multislice(None, want_grad=want_grad, want_pred=want_pred, grad_scale=2.0 / (nd * B * eng.n_det), probes_b=probes_b)
+            if want_grad:
+                eng.rotate_adjoint(grad_obj, None, yr)
+            if want_pred:
+                preds.append(eng.pred()[:, szw:szw + self.prj.shape[-2], szw:szw + self.prj.shape[-1]])
+            else:
+                tokens.append((eng, eng.loss_async()))
+        if want_pred:
+            return np.concatenate(preds, 0)
+        return lambda: sum(e.loss_result(t) for e, t in tokens) / nd
 
     def _dev(self, name, value, shape):
         """Small parameter arrays: pass DeviceArrays through, upload (and cache) host values."""
@@ -610,8 +699,10 @@ class MultiDistModel(PtychographyModel):
                 probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa, prj_pos_offset):
         """Detected magnitudes [n_dists, ny, nx] (host float32), adorym/forward_model.py:819-1034."""
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
-        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True)
         self.i_call += 1
+        if self.tiles is not None:
+            return self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False, want_pred=True)
+        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True)
         return self.holo.pred()
 
     def get_loss_function(self):
@@ -619,6 +710,10 @@ class MultiDistModel(PtychographyModel):
                            probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa,
                            prj_pos_offset):
             self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
+            if self.tiles is not None:
+                datav = self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False)
+                self.current_loss = float(datav() + self._regularize(obj, None))
+                return self.current_loss
             self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False)
             self.current_loss = float(self.holo.loss() + self._regularize(obj, None))
             return self.current_loss
@@ -634,6 +729,14 @@ class MultiDistModel(PtychographyModel):
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         if _side_hook is not None:
             _side_hook()
+        if self.tiles is not None:
+            if list(opt_args_ls) != [0]:
+                raise NotImplementedError('multi-distance data divided into sub-tiles: only the object gradient is on the accelerated path')
+            # the regulariser kernel initialises the gradient buffer ('set' mode, or a zero fill), the launches add to it
+            regv = self._reg_value_async(self._regularize_launch(obj, grad_obj, init_grad=bool(_init_grad)))
+            datav = self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=True, grad_obj=grad_obj)
+            self._loss_thunk = lambda: datav() + regv()
+            return (grad_obj,)
         fa = getattr(self, 'fused_adam', None)
         if fa is not None:
             # the driver has established that this minibatch's update is plain Adam on exactly these gradients (one rank, no

@@ -291,21 +291,34 @@ class MultisliceEngine(object):
         return view
 
     def multislice(self, probe, grad_probe=None, want_grad=True, want_pred=False, grad_scale=None, accumulate=True,
-                   shifts=None, shift_index=None, grad_shifts=None):
+                   shifts=None, shift_index=None, grad_shifts=None, probes_b=None):
         """Launch the fused kernel on the batch given to set_batch().  Returns nothing; read
         results with loss() / pred().
 
         ``shifts`` (DeviceArray float [n_entries,2] = (sy, sx)) switches to one Fourier-shifted probe set per position
         (adorym/forward_model.py:296-311); position b uses entry ``shift_index[b]`` (DeviceArray int32 [B]; None = b).
         With want_grad, ``grad_probe`` (+=) and ``grad_shifts`` (float [n_entries,2], +=) then receive the gradients
-        taken through the shift."""
+        taken through the shift.
+
+        ``probes_b`` (DeviceArray [B, n_modes, Py, Px, 2]): one probe set per position handed over as it is (the windows of a
+        full-field probe that the sub-tiles of multi-distance data see, adorym/forward_model.py:944-994); ``probe`` is ignored
+        and no probe gradient is formed."""
         B = self._B
         Py, Px = self.probe_size
         if grad_scale is None:
             grad_scale = 2.0 / (B * self.n_det)       # d mean((pred-target)^2) / d pred
         lib = self.ctx.lib
         self._next_loss_buffer()
-        if shifts is None:
+        if probes_b is not None:
+            if shifts is not None or grad_probe is not None:
+                raise ValueError('probes_b excludes shifts and grad_probe')
+            if tuple(probes_b.shape) != (B, self.n_probe_modes, Py, Px, 2):
+                raise ValueError('probes_b must be [%d, %d, %d, %d, 2], got %r' % (B, self.n_probe_modes, Py, Px, tuple(probes_b.shape)))
+            check(lib.adm_multislice_fwd_adj_pp(
+                self.plan.handle, self.obj_rot.ptr, probes_b.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
+                1 if want_grad else 0, None, self._pred.ptr if want_pred else None, self._loss.ptr, float(grad_scale),
+                self._ws.ptr, self._ws.nbytes))
+        elif shifts is None:
             check(lib.adm_multislice_fwd_adj(
                 self.plan.handle, self.obj_rot.ptr, probe.ptr, self._cur_pos.ptr, B, self._cur_target.ptr,
                 1 if want_grad else 0, grad_probe.ptr if grad_probe is not None else None,

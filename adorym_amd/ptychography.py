@@ -380,17 +380,37 @@ def reconstruct_ptychography(
     if free_prop_cm is None:
         free_prop_cm = f.get('metadata/free_prop_cm')
     is_multi_dist = np.array(free_prop_cm).size != 1          # ptychography.py:296-305
+    holo_tiled = False
     if is_multi_dist:
-        # one undivided field of view (n_blocks == 1), one object slice
+        # one object slice; config 5 is one undivided field of view (n_blocks == 1) without a safe zone
         free_prop_cm = np.asarray(free_prop_cm, dtype=float).reshape(-1)
         n_dists = len(free_prop_cm)
-        _not_implemented(prj.shape[1] != n_dists or len(probe_pos) != 1, 'multi-distance data divided into sub-tiles (n_blocks > 1)')
+        safe_zone_width = int(safe_zone_width or 0)
+        if prj.shape[1] != n_dists * len(probe_pos):
+            raise ValueError('multi-distance data: prj.shape[1] = %d is not n_dists x n_blocks = %d x %d' % (prj.shape[1], n_dists, len(probe_pos)))
         _not_implemented(not two_d_mode, 'multi-distance holography of a 3-D object')
-        _not_implemented(safe_zone_width != 0, 'safe_zone_width > 0')
         _not_implemented(n_probe_modes != 1, 'several probe modes with multi-distance data')
         _not_implemented(loss_function_type != 'lsq', 'Poisson loss with multi-distance data')
         _not_implemented(optimize_all_probe_pos, 'optimize_all_probe_pos with multi-distance data')
-        _not_implemented(list(prj.shape[-2:]) != list(obj_size[:2]), 'holograms whose size differs from the object size')
+        holo_tiled = len(probe_pos) > 1 or safe_zone_width > 0
+        if holo_tiled:
+            # data divided into sub-tiles and / or a safe zone around every tile (adorym/forward_model.py:884-1034)
+            tile_size = [int(v) + 2 * safe_zone_width for v in prj.shape[-2:]]
+            _not_implemented(max(tile_size) > 128, 'sub-hologram + 2 safe zones larger than 128 pixels (%d x %d)' % tuple(tile_size))
+            _not_implemented(optimize_free_prop or optimize_prj_affine or optimize_probe,
+                             'optimize_free_prop / optimize_prj_affine / optimize_probe with multi-distance data divided into sub-tiles')
+            _not_implemented(beamstop is not None, 'a beamstop with multi-distance data divided into sub-tiles')
+            pp_ = np.round(np.asarray(probe_pos)).astype(int)
+            if safe_zone_width == 0:
+                # (:921-925 resets pad_arr to zero while the object has been padded: a tile hanging over the edge is misread there)
+                _not_implemented(bool(np.any(pp_ < 0) or np.any(pp_ + np.array(prj.shape[-2:]) > np.array(obj_size[:2]))),
+                                 'tiles hanging over the object edge with safe_zone_width = 0')
+            if len(probe_pos) > 1:
+                # (:931-943, the branch for a chunk of ONE tile, cuts object and probe to different sizes and fails in the reference)
+                mb_ = minibatch_size if minibatch_size is not None else len(probe_pos)
+                _not_implemented(mb_ % n_dp_batch == 1, 'a minibatch whose last n_dp_batch chunk holds a single tile')
+        else:
+            _not_implemented(list(prj.shape[-2:]) != list(obj_size[:2]), 'holograms whose size differs from the object size')
         probe_size = [int(v) for v in obj_size[:2]]          # subdiv_probe (ptychography.py:312-314)
     else:
         _not_implemented(optimize_free_prop or optimize_prj_affine, 'optimize_free_prop / optimize_prj_affine without multi-distance data')
@@ -421,8 +441,19 @@ def reconstruct_ptychography(
     h = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, probe_size, fresnel_approx=fresnel_approx, sign_convention=sign_convention) \
         if not is_multi_dist else None
     probe_pos_int = np.round(probe_pos).astype(int)
-    holo_engine = None
-    if is_multi_dist:
+    holo_engine = tile_engines = None
+    if holo_tiled:
+        # one engine per distance: tile = sub-hologram + 2 safe zones at (position - safe zone), Fresnel propagation to that
+        # distance after the slice (fresnel_propagate, adorym/propagate.py:282-288), loss over the sub-hologram's window only
+        # (forward_model.py:1027-1029) -- the detector mask that also serves the beamstop
+        window = np.zeros(tile_size, np.float32)
+        window[safe_zone_width:tile_size[0] - safe_zone_width, safe_zone_width:tile_size[1] - safe_zone_width] = 1
+        tile_engines = [MultisliceEngine(ctx, this_obj_size, tile_size, probe_pos_int - safe_zone_width, energy_ev, psize_cm,
+                                         free_prop_cm=float(d_), sign_convention=sign_convention, scale_ri_by_k=scale_ri_by_k,
+                                         max_batch=minibatch_size, unknown_type=unknown_type, beamstop=window)
+                        for d_ in free_prop_cm]
+        engine = tile_engines[0]            # (carries the object geometry for the regulariser kernels)
+    elif is_multi_dist:
         from .holography import HolographyEngine
         holo_engine = HolographyEngine(ctx, probe_size, n_dists, energy_ev, psize_cm, sign_convention=sign_convention,
                                        unknown_type=unknown_type, raw_data_type=raw_data_type, scale_ri_by_k=scale_ri_by_k)
@@ -527,7 +558,8 @@ def reconstruct_ptychography(
     common_vars = dict(unknown_type=unknown_type, normalize_fft=normalize_fft, sign_convention=sign_convention,
                        rotate_out_of_loop=rotate_out_of_loop, scale_ri_by_k=scale_ri_by_k, is_minus_logged=is_minus_logged,
                        forward_algorithm=forward_algorithm, stdout_options=stdout_options, poisson_multiplier=poisson_multiplier,
-                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine, holo_engine=holo_engine,
+                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine, holo_engine=holo_engine, tile_engines=tile_engines,
+                       safe_zone_width=safe_zone_width, n_dp_batch=n_dp_batch,
                        optimize_prj_affine=optimize_prj_affine, optimize_free_prop=optimize_free_prop, optimize_ctf_lg_kappa=optimize_ctf_lg_kappa,
                        rotation_tables=rotation_tables, two_d_mode=two_d_mode, theta_downsample=theta_downsample,
                        ds_level=ds_level, probe_size=probe_size, this_obj_size=this_obj_size, n_theta=n_theta,
@@ -911,7 +943,7 @@ def reconstruct_ptychography(
             # whichever of free_prop_cm / prj_affine_ls are optimised: the steps run INSIDE the gradient launch group's last kernel
             # (adm_holo_fwd_adj_adam; same arithmetic, same bits), no gradient is stored and no optimiser launch follows.
             holo_fused = None
-            if is_multi_dist and builtin_model and init_grad and update_scheme == 'immediate' and optimize_object and fused \
+            if is_multi_dist and not holo_tiled and builtin_model and init_grad and update_scheme == 'immediate' and optimize_object and fused \
                     and opt_kind == 'adam' and n_ranks == 1 and flags == 0 and mask is None and not optimize_probe \
                     and not optimize_all_probe_pos and not forward_model.reg_list and os.environ.get('ADM_HOLO_FUSED_ADAM', '1') == '1':
                 small_opts = [o_ for o_ in (opt_free_prop, opt_prj_affine) if o_ is not None]

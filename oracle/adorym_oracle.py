@@ -1132,3 +1132,120 @@ def reconstruct_multidist(data, obj_init, probe, dists_cm, energy_ev, psize_cm, 
             aff[0] = np.array([[1., 0, 0], [0, 1., 0]], dtype=dt)
         losses.append(float(loss))
     return dict(obj=obj, dists=dists, affine=aff, losses=losses, first_grad=first_grad)
+
+
+# --------------------------------------------------------------------------------------
+# f1  multi-distance holography divided into sub-tiles with a safe zone (MultiDistModel, forward_model.py:884-1034, n_blocks > 1)
+# --------------------------------------------------------------------------------------
+def multidist_subprobes(probe, pos_batch, sub_size, szw, n_dp_batch=20):
+    """forward_model.py:916-925, 944-994: the full-field probe (same size as the object, ptychography.py:312-314) is padded with
+    1 + 0i so that every (sub + 2 szw) window of the batch lies inside it (calculate_pad_len on the windows of THIS batch), and
+    position j sees the window at pos_j - szw.  Line :1005 hands multislice_propagate_batch ``subprobe_imag_ls_ls[k][i_mode, :, :]``
+    (no leading ':'): with one probe mode that is the imaginary window of the FIRST position of the n_dp_batch chunk, broadcast
+    over the chunk -- restated as it is.  Returns complex [B, Ty, Tx]."""
+    probe = np.asarray(probe)
+    pos = np.round(np.asarray(pos_batch)).astype(int).reshape(-1, 2)
+    T = (sub_size[0] + 2 * szw, sub_size[1] + 2 * szw)
+    if szw > 0:
+        pad = calculate_pad_len(probe.shape[-2:], pos - szw, T)
+        pr = np.pad(probe.real, [tuple(pad[0]), tuple(pad[1])], mode='constant', constant_values=1)
+        pi = np.pad(probe.imag, [tuple(pad[0]), tuple(pad[1])], mode='constant', constant_values=0)
+    else:
+        pad = np.zeros((2, 2), int)
+        pr, pi = probe.real, probe.imag
+    out = np.zeros((len(pos),) + T, dtype=np.result_type(probe.dtype, np.complex64))
+    for c0 in range(0, len(pos), n_dp_batch):
+        chunk = range(c0, min(c0 + n_dp_batch, len(pos)))
+        for n_, j in enumerate(chunk):
+            y, x = pos[j, 0] + pad[0, 0] - szw, pos[j, 1] + pad[1, 0] - szw
+            if n_ == 0:
+                im0 = pi[y:y + T[0], x:x + T[1]]
+            out[j] = pr[y:y + T[0], x:x + T[1]] + 1j * im0
+    return out
+
+
+def multidist_tiles_forward_adjoint(obj, probe, pos_batch, sub_size, szw, dists_cm, meas, energy_ev, psize_cm,
+                                    unknown_type='real_imag', raw_data_type='magnitude', n_dp_batch=20, dtype='float64',
+                                    sign_convention=1, scale_ri_by_k=True):
+    """MultiDistModel.predict + get_loss_function for data divided into sub-tiles (forward_model.py:884-1092, n_blocks > 1,
+    optimize_free_prop / optimize_prj_affine off) and the gradient w.r.t. the object that ``torch.autograd.grad`` returns.
+    Tile j of the batch: the object window [pos_j - szw, pos_j + sub + szw) of the object padded like pad_object (:912), lit by
+    its probe window, modulated slice by slice and Fresnel-propagated to every distance (fresnel_propagate, propagate.py:282-288);
+    the safe zone is cut off the magnitudes (:1027-1029) and the mean squared mismatch is taken over ALL distances and tiles
+    (:1054-1058, data order [i_dist * n_blocks + tile]).  ``meas`` [n_dists * B, sub_y, sub_x], distance-major.
+    Returns loss, pred [n_dists * B, sub_y, sub_x], grad_obj [Y, X, S, 2]."""
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    obj = np.asarray(obj).astype(dt, copy=False)
+    pos = np.round(np.asarray(pos_batch)).astype(int).reshape(-1, 2)
+    B = len(pos)
+    T = (sub_size[0] + 2 * szw, sub_size[1] + 2 * szw)
+    tiles, _ = extract_tiles(obj, pos - szw, T, unknown_type)
+    probes_b = multidist_subprobes(probe, pos, sub_size, szw, n_dp_batch).astype(cdt)
+    S = tiles.shape[3]
+    fields, kepts, physs = [], [], []
+    for d in dists_cm:
+        phys = Physics(T, energy_ev, psize_cm, free_prop_cm=float(d), sign_convention=sign_convention, scale_ri_by_k=scale_ri_by_k,
+                       unknown_type=unknown_type)
+        f, k = multislice_forward(tiles, probes_b, phys, dt, keep=True)
+        fields.append(f); kepts.append(k); physs.append(phys)
+    cy, cx = slice(szw, szw + sub_size[0]), slice(szw, szw + sub_size[1])
+    pred = np.concatenate([np.abs(f)[:, cy, cx] for f in fields], 0).astype(dt)
+    meas = np.asarray(meas).astype(dt, copy=False)
+    loss = mismatch_loss(pred, meas, 'lsq', raw_data_type, 1.)
+    dldp = _dloss_dpred(pred, meas, 'lsq', raw_data_type, 1.).astype(dt)
+    grad_tiles = np.zeros_like(tiles)
+    for i, (f, kept, phys) in enumerate(zip(fields, kepts, physs)):
+        full = np.zeros((B,) + T, dtype=dt)
+        full[:, cy, cx] = dldp[i * B:(i + 1) * B]
+        mag = np.abs(f)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            unit = np.where(mag > 0, f / mag, 0)
+        G = _detector_adj((full * unit).astype(cdt), phys, dt).astype(cdt)
+        h = phys.h_cast(dt)
+        k1, sg = dt.type(phys.k1), dt.type(phys.sigma)
+        for s in range(S - 1, -1, -1):               # the sweep of forward_adjoint_tiles, binning 1
+            d_, b_, lo, hi = _slice_sums(tiles, s, 1)
+            c = _modulator(d_, b_, phys, dt)
+            if unknown_type == 'real_imag':
+                zc = G * np.conj(kept[s] / c)
+                gd, gb = zc.real.astype(dt), zc.imag.astype(dt)
+            else:
+                z = np.conj(G) * kept[s]
+                gb = (-k1 * z.real).astype(dt)
+                gd = (sg * k1 * z.imag).astype(dt)
+            grad_tiles[:, :, :, lo:hi, 0] += gd[..., None]
+            grad_tiles[:, :, :, lo:hi, 1] += gb[..., None]
+            G = (G * np.conj(c)).astype(cdt)
+            if s > 0:
+                G = np.fft.ifft2(np.fft.fft2(G) * np.conj(h)).astype(cdt)
+    return loss, pred, scatter_tiles_adj(grad_tiles, pos - szw, obj.shape)
+
+
+def reconstruct_multidist_tiles(prj, obj_init, probe, probe_pos, sub_size, szw, dists_cm, energy_ev, psize_cm, n_epochs=1,
+                                minibatch_size=4, learning_rate=1e-2, unknown_type='real_imag', raw_data_type='magnitude',
+                                n_dp_batch=20, dtype='float64'):
+    """reconstruct_ptychography on multi-distance data divided into n_blocks sub-tiles (two_d_mode: one angle; the tiles are the
+    'probe positions' of the task list, ptychography.py:791-912): Adam on the object.  ``prj`` [1, n_dists * n_blocks, sub, sub]."""
+    dt = np.dtype(dtype)
+    obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
+    m, v = np.zeros_like(obj), np.zeros_like(obj)
+    pos = np.asarray(probe_pos, dtype=float)
+    n_blocks = len(pos)
+    nd = len(dists_cm)
+    losses, first_grad, first_pred = [], None, None
+    for i_epoch in range(n_epochs):
+        batches = epoch_task_list(i_epoch, 1, n_blocks, minibatch_size, 1, 'immediate', two_d_mode=True)
+        i_opt_batch = 0
+        for i_batch in range(len(batches)):
+            _, ind = rank_batch(batches, i_batch, 0, minibatch_size, 1)
+            full = np.concatenate([ind + i * n_blocks for i in range(nd)])          # forward_model.py:1051-1054
+            loss, pred, g = multidist_tiles_forward_adjoint(obj, probe, pos[ind], sub_size, szw, dists_cm, prj[0, full], energy_ev,
+                                                            psize_cm, unknown_type, raw_data_type, n_dp_batch, dt)
+            if first_grad is None:
+                first_grad, first_pred = g.copy(), pred.copy()
+            obj, m, v = adam_step(obj, g.astype(dt), m, v, i_opt_batch, step_size=learning_rate)
+            losses.append(float(loss))
+            if i_batch == len(batches) - 1:
+                i_opt_batch += 1
+    return dict(obj=obj, losses=losses, first_grad=first_grad, first_pred=first_pred)

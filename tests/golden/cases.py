@@ -201,6 +201,38 @@ def c5mini_inputs():
     return dict(truth=(mag_t, ph_t), guess=(guess_mag, guess_ph), affine_true=affine_true, dists_guess=dists_guess)
 
 
+# ---------------------------------------------------------------- f1 divided into sub-tiles with a safe zone (golden F18)
+C5TILES = dict(N=48, SUB=16, energy_ev=17050., psize_cm=1e-4, dists_cm=(40., 60., 90.), minibatch_size=4, n_epochs=2, learning_rate=1e-2,
+               runs={'ri_szw4': dict(unknown_type='real_imag', szw=4, probe='plane'),
+                     'db_szw4_probe': dict(unknown_type='delta_beta', szw=4, probe='supplied'),
+                     'ri_szw0': dict(unknown_type='real_imag', szw=0, probe='plane')})
+
+
+def c5tiles_inputs(run):
+    """A 48 x 48 one-slice object recorded at three distances as 3 x 3 holograms of 16 x 16 pixels each (n_blocks = 9); the
+    reconstruction propagates every tile with a safe zone of ``szw`` pixels around it.  'supplied': a probe that varies over the
+    field of view (real and imaginary part), so that every tile sees its own window of it."""
+    c = C5TILES
+    N, SUB = c['N'], c['SUB']
+    r = c['runs'][run]
+    pos = np.array([[y, x] for y in range(0, N, SUB) for x in range(0, N, SUB)], dtype=float)
+    if r['unknown_type'] == 'real_imag':
+        mag_t = 1 - 0.25 * smooth_field((N, N, 1), 321)
+        ph_t = 0.6 * smooth_field((N, N, 1), 322) - 0.3
+        truth = np.stack([mag_t * np.cos(ph_t), mag_t * np.sin(ph_t)], -1)
+        guess = (np.full((N, N, 1), 0.9) + 0.02 * smooth_field((N, N, 1), 323), 0.05 * smooth_field((N, N, 1), 324))   # (mag, phase)
+    else:
+        truth = np.stack([2e-6 * smooth_field((N, N, 1), 331), 2e-7 * smooth_field((N, N, 1), 332)], -1)
+        guess = (5e-7 * (1 + smooth_field((N, N, 1), 333)), 5e-8 * (1 + smooth_field((N, N, 1), 334)))                # (delta, beta)
+    if r['probe'] == 'supplied':
+        pm = 1 + 0.2 * smooth_field((N, N, 1), 341)[..., 0]
+        pp = 0.5 * smooth_field((N, N, 1), 342)[..., 0] - 0.25
+    else:
+        pm, pp = np.ones((N, N)), np.zeros((N, N))
+    return dict(pos=pos, truth=truth, guess=guess, probe_mag=pm, probe_phase=pp, szw=r['szw'], unknown_type=r['unknown_type'],
+                probe_type=r['probe'])
+
+
 # ---------------------------------------------------------------- full-size config 3 through the driver (tests/test_gpu_fullsize.py)
 FULLSIZE = dict(N=256, P=72, rows=(10, 13), theta=0.4, margin=4)
 

@@ -837,8 +837,79 @@ def gen_f15():
     save('F15_rotate_out_of_loop', **out)
 
 
+# ----------------------------------------------------------------------------- F18 (f1 row, data divided into sub-tiles + safe zone)
+def gen_f18():
+    """MultiDistModel with n_blocks > 1 and safe_zone_width >= 0 (forward_model.py:884-1034) through the reference DRIVER: the
+    holograms of a full-field propagation are cut into 3 x 3 tiles; recorded per run: the task list, the first minibatch's
+    predicted magnitudes and object gradient, every loss, the final object."""
+    import adorym.ptychography as PT  # noqa: F401
+    C = cases.C5TILES
+    N, SUB = C['N'], C['SUB']
+    dists = np.array(C['dists_cm'])
+    out = {}
+
+    class MultiDistPlugin(adorym.MultiDistModel):
+        # (see gen_f12: the 'auto' selection passes two keywords MultiDistModel.__init__ does not accept)
+        first_pred = None
+
+        def __init__(self, *a, run_bfloat16=False, run_float64=False, **k):
+            super().__init__(*a, **k)          # (reads predict's argument names: the recorder goes on afterwards)
+            inner = self.predict
+
+            def recording_predict(*pa, **pk):
+                res = inner(*pa, **pk)
+                if MultiDistPlugin.first_pred is None:
+                    MultiDistPlugin.first_pred = res.detach().numpy().copy()
+                return res
+            self.predict = recording_predict
+
+    for rn in C['runs']:
+        inp = cases.c5tiles_inputs(rn)
+        ut, szw = inp['unknown_type'], inp['szw']
+        # data: the truth lit by the run's probe, propagated as ONE field to every distance (fp64), cut into tiles
+        gs.run_fp64 = True
+        pc = inp['probe_mag'] * np.exp(1j * inp['probe_phase'])
+        holo = []
+        for d in dists:
+            er, ei = multislice_propagate_batch(torch.tensor(inp['truth'])[None], torch.tensor(pc.real), torch.tensor(pc.imag),
+                                                C['energy_ev'], C['psize_cm'], kernel=None, free_prop_cm=d,
+                                                obj_batch_shape=[1, N, N, 1], type=ut)
+            holo.append(np.sqrt(er.numpy()[0] ** 2 + ei.numpy()[0] ** 2))
+        pos = inp['pos']
+        prj = np.zeros((1, len(dists) * len(pos), SUB, SUB))
+        for i in range(len(dists)):
+            for j, (y, x) in enumerate(pos.astype(int)):
+                prj[0, i * len(pos) + j] = holo[i][y:y + SUB, x:x + SUB]
+        out[rn + '_prj'] = prj.astype(np.float32)
+        prj = out[rn + '_prj'].astype(np.float64)
+        pk = dict(probe_type='plane') if inp['probe_type'] == 'plane' else \
+            dict(probe_type='supplied', probe_initial=[inp['probe_mag'], inp['probe_phase']])
+        for fp64 in (True, False):
+            rec = {}
+            MultiDistPlugin.first_pred = None
+            run_driver(prj, [N, N, 1], pos, 0, 1,
+                       dict(minibatch_size=C['minibatch_size'], n_epochs=C['n_epochs'], two_d_mode=True, energy_ev=C['energy_ev'],
+                            psize_cm=C['psize_cm'], free_prop_cm=dists, initial_guess=[inp['guess'][0], inp['guess'][1]],
+                            raw_data_type='magnitude', unknown_type=ut, gamma=0, alpha_d=0, alpha_b=0, optimizer='adam',
+                            learning_rate=C['learning_rate'] if ut == 'real_imag' else 1e-7, n_dp_batch=20, run_float64=fp64,
+                            randomize_probe_pos=False, safe_zone_width=szw, forward_model=MultiDistPlugin, **pk), rec,
+                       ri=(ut == 'real_imag'))
+            tag = rn + ('_64' if fp64 else '_32')
+            if ut == 'real_imag':
+                out['obj_' + tag] = np.stack([rec['mag'] * np.cos(rec['phase']), rec['mag'] * np.sin(rec['phase'])], -1)
+            else:
+                out['obj_' + tag] = np.stack([rec['delta'], rec['beta']], -1)
+            out['losses_' + tag] = rec['losses']
+            out['first_grad_' + tag] = rec['first_grad']
+            out['first_pred_' + tag] = MultiDistPlugin.first_pred
+            if fp64:
+                out[rn + '_batches'] = np.stack([b[1] for b in rec['batches']])
+    gs.run_fp64 = False
+    save('F18_multidist_tiles', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13']
+    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f18']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -854,3 +925,4 @@ if __name__ == '__main__':
     if 'f15' in which: gen_f15()
     if 'f16' in which: gen_f16()
     if 'f17' in which: gen_f17()
+    if 'f18' in which: gen_f18()

@@ -532,3 +532,48 @@ def test_f13_beamstop_loss_and_gradients():
     assert abs(loss - f['loss_64']) < 1e-12 * abs(f['loss_64'])
     assert np.linalg.norm(gt - f['grad_tiles_64']) < 1e-10 * np.linalg.norm(f['grad_tiles_64'])
     assert np.linalg.norm(gp[0] - f['grad_probe_64']) < 1e-10 * np.linalg.norm(f['grad_probe_64'])
+
+
+# ------------------------------------------------------------------------------------ F18 (f1 row, sub-tiles + safe zone)
+def _f18_run(rn, dtype):
+    C = cases.C5TILES
+    f = load('F18_multidist_tiles')
+    inp = cases.c5tiles_inputs(rn)
+    ri = inp['unknown_type'] == 'real_imag'
+    g = inp['guess']
+    init = [g[0] * np.cos(g[1]), g[0] * np.sin(g[1])] if ri else [g[0], g[1]]     # mag/phase -> real/imag (ObjectFunction, ptychography.py:531-551)
+    out = O.reconstruct_multidist_tiles(f[rn + '_prj'].astype(np.float64), init, inp['probe_mag'] * np.exp(1j * inp['probe_phase']), inp['pos'],
+                                        (C['SUB'], C['SUB']), inp['szw'], C['dists_cm'], C['energy_ev'], C['psize_cm'], n_epochs=C['n_epochs'],
+                                        minibatch_size=C['minibatch_size'], learning_rate=C['learning_rate'] if ri else 1e-7,
+                                        unknown_type=inp['unknown_type'], dtype=dtype)
+    return f, out
+
+
+@pytest.mark.parametrize('rn', sorted(cases.C5TILES['runs']))
+def test_f18_multidistance_subtiles_vs_reference_driver(rn):
+    """The oracle's restatement of MultiDistModel for n_blocks > 1 (9 tiles of 16 x 16, safe zone 4 / 0, plane and field-dependent
+    probe, both unknown types) against the reference DRIVER run in fp64: first minibatch's magnitudes and object gradient, every
+    loss, the final object."""
+    f, out = _f18_run(rn, 'float64')
+    ref_pred, ref_g = f['first_pred_' + rn + '_64'], f['first_grad_' + rn + '_64']
+    assert out['first_pred'].shape == ref_pred.shape == (12, 16, 16)
+    assert np.abs(out['first_pred'] - ref_pred).max() < 1e-10
+    assert np.linalg.norm(out['first_grad'] - ref_g) < 1e-9 * np.linalg.norm(ref_g), (np.linalg.norm(out['first_grad'] - ref_g), np.linalg.norm(ref_g))
+    assert np.allclose(out['losses'], f['losses_' + rn + '_64'], rtol=1e-8)
+    ref_o = f['obj_' + rn + '_64']
+    # (the driver writes float32 TIFFs of magnitude / phase or delta / beta: the final object is compared at that precision)
+    assert np.abs(out['obj'] - ref_o).max() < 2e-6 * np.abs(ref_o).max()
+    assert np.abs(out['obj'] - np.stack(_f18_init(rn), -1)).max() > 50 * np.abs(out['obj'] - ref_o).max()      # the run moved the object
+
+
+def _f18_init(rn):
+    inp = cases.c5tiles_inputs(rn)
+    g = inp['guess']
+    return [g[0] * np.cos(g[1]), g[0] * np.sin(g[1])] if inp['unknown_type'] == 'real_imag' else [g[0], g[1]]
+
+
+def test_f18_fp32_oracle_tracks_fp32_reference():
+    f, out = _f18_run('ri_szw4', 'float32')
+    ref_g = f['first_grad_ri_szw4_32']
+    assert np.linalg.norm(out['first_grad'] - ref_g) < 1e-4 * np.linalg.norm(ref_g)
+    assert np.allclose(out['losses'], f['losses_ri_szw4_32'], rtol=1e-3)
