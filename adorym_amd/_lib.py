@@ -107,6 +107,7 @@ SIGNATURES = {
     'adm_plan_create': (_I, [_VP, C.POINTER(PlanDesc), C.POINTER(_VP)]),
     'adm_plan_destroy': (_I, [_VP]),
     'adm_plan_set_detector_mask': (_I, [_VP, _VP]),
+    'adm_plan_set_detector_kernels': (_I, [_VP, C.c_int, _VP, _VP]),
     'adm_plan_rot_elems': (_SZ, [_VP]),
     'adm_plan_workspace_bytes': (_SZ, [_VP, _I]),
     'adm_rotate_fwd': (_I, [_VP, _VP, _VP, _VP, _I, _I]),

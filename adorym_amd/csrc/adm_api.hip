@@ -280,6 +280,7 @@ extern "C" int adm_plan_create(adm_ctx* ctx, const adm_plan_desc* desc, adm_plan
     p->reg_stats = nullptr;
     p->reg_partial = nullptr;
     p->det_weight_dev = nullptr;
+    p->n_hfree = 1;
     const size_t npx = (size_t)d.probe_y * d.probe_x;
     int rc = upload_c(ctx, d.h_re, d.h_im, npx, &p->h_dev);
     if (!rc && d.det_mode == ADM_DET_FRESNEL) rc = upload_c(ctx, d.hfree_re, d.hfree_im, npx, &p->hfree_dev);
@@ -340,6 +341,32 @@ extern "C" int adm_plan_set_detector_mask(adm_plan* plan, const float* mask_host
         if (rc) return rc;
     }
     return adm_h2d(plan->ctx, plan->det_weight_dev, w.data(), n * sizeof(float));
+}
+
+extern "C" int adm_plan_set_detector_kernels(adm_plan* plan, int n, const float* hfree_re, const float* hfree_im) {
+    if (!plan || !hfree_re || !hfree_im) return fail(ADM_ERR_INVALID, "adm_plan_set_detector_kernels: null argument");
+    if (n < 1) return fail(ADM_ERR_INVALID, "adm_plan_set_detector_kernels: n must be >= 1");
+    if (plan->d.det_mode != ADM_DET_FRESNEL) return fail(ADM_ERR_INVALID, "adm_plan_set_detector_kernels: the plan's det_mode is not ADM_DET_FRESNEL");
+    const size_t npx = (size_t)plan->d.probe_y * plan->d.probe_x, tot = npx * (size_t)n;
+    float2 *a = nullptr, *b = nullptr;
+    int rc = upload_c(plan->ctx, hfree_re, hfree_im, tot, &a);
+    if (!rc) {      // the any-size kernel's copy: H / (Py*Px), one rounding per element
+        std::vector<float> re(tot), im(tot);
+        for (size_t i = 0; i < tot; ++i) { re[i] = (float)((double)hfree_re[i] / (double)npx); im[i] = (float)((double)hfree_im[i] / (double)npx); }
+        rc = upload_c(plan->ctx, re.data(), im.data(), tot, &b);
+    }
+    if (rc) {
+        if (a) adm_free(plan->ctx, a);
+        return rc;
+    }
+    // (launches already queued on the plan's stream may still read the old kernels: free them behind those launches)
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    if (plan->hfree_dev) adm_free(plan->ctx, plan->hfree_dev);
+    if (plan->hfree_s_dev) adm_free(plan->ctx, plan->hfree_s_dev);
+    plan->hfree_dev = a;
+    plan->hfree_s_dev = b;
+    plan->n_hfree = n;
+    return ADM_OK;
 }
 
 extern "C" size_t adm_plan_rot_elems(const adm_plan* plan) {
@@ -406,6 +433,7 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
         return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: several probe modes need the workspace even for want_grad = 0");
     p.h = plan->h_dev;
     p.hfree = plan->hfree_dev;
+    p.n_hfree = plan->n_hfree;
     p.twid = plan->twid_dev;
     p.Z = d.obj_z;
     p.Yp = plan->Yp;
@@ -426,6 +454,10 @@ int adm::multislice_impl(adm_plan* plan, const float* obj_rot, const float* prob
     p.poisson_mult = d.poisson_multiplier;
     p.real_imag = d.unknown_type;
     p.det_weight = plan->det_weight_dev;
+    if (plan->n_hfree > 1 && batch % plan->n_hfree != 0)
+        return fail(ADM_ERR_INVALID, "adm_multislice_fwd_adj: the plan holds several detector kernels (position b uses kernel b % n): batch must be a multiple of n");
+    if (plan->n_hfree > 1 && !per_position && !plan->generic)
+        return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj: a plan with several detector kernels is launched through adm_multislice_fwd_adj_pp (one probe set per position)");
     const size_t probe_elems = (size_t)d.n_modes * d.probe_y * d.probe_x;
     if (per_position) {
         if (d.binning != 1) return fail(ADM_ERR_UNSUPPORTED, "adm_multislice_fwd_adj_pp: binning > 1 is not implemented with per-position probes");

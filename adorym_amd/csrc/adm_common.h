@@ -29,7 +29,8 @@ struct adm_plan {
     int Yp, Xp;            // padded rotated-frame extents
     int n_steps;           // ceil(obj_z / binning)
     float2* h_dev;         // [Py*Px] slice transfer function
-    float2* hfree_dev;     // [Py*Px] or nullptr
+    float2* hfree_dev;     // [n_hfree][Py*Px] or nullptr
+    int n_hfree;           // detector-plane Fresnel kernels held (1; adm_plan_set_detector_kernels: the distances of multi-distance data)
     float2* twid_dev;      // [Px] exp(-2 pi i j / N)
     float* det_weight_dev; // [Py*Px] beamstop weights or nullptr (adm_plan_set_detector_mask)
     float* reg_stats;      // 2 floats of scratch for the real_imag L1 regulariser (lazily allocated)
@@ -64,7 +65,7 @@ struct MsParams {
     float2* stash;             // [B][n_steps][R1][NT] post-modulation wavefields
     float2* gtile;             // [B][n_steps][R1][NT] per-position tile gradients (d/ddelta, d/dbeta)
     const float2* h;           // [P][P] natural order, unscaled
-    const float2* hfree;       // [P][P] or nullptr
+    const float2* hfree;       // [n_hfree][P][P] or nullptr
     const float2* twid;        // [N] exp(-2 pi i j / N)
     int Z, Yp, Xp, pad_y0, pad_x0;
     int binning, n_steps;
@@ -85,7 +86,9 @@ struct MsParams {
     int gen_py, gen_px, gen_nrx, gen_nry, gen_rx[8], gen_ry[8];
     const float2* gen_twid_y;  // [Py]; twid is [Px]
     const float2* gen_hs;      // [Py][Px] H / (Py*Px)
-    const float2* gen_hfree_s; // [Py][Px] or nullptr
+    const float2* gen_hfree_s; // [n_hfree][Py][Px] or nullptr
+    // (last, so that the fields above keep their kernel-argument offsets)
+    int n_hfree;               // detector-plane kernels in hfree / gen_hfree_s: position b is propagated with kernel b % n_hfree
 };
 // per-position sub-pixel probe shifts (adorym/util.py:380-397, forward_model.py:296-311)
 struct ShiftParams {

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void ms_generic_kernel(MsParams p) {
             if (step < p.n_steps - 1) gen_convolve<false>(g, p, p.gen_hs, v);
         }
         // ---------------- detector plane ----------------
-        if (p.det_mode == ADM_DET_FRESNEL_) gen_convolve<false>(g, p, p.gen_hfree_s, v);
+        if (p.det_mode == ADM_DET_FRESNEL_) gen_convolve<false>(g, p, p.gen_hfree_s + (p.n_hfree > 1 ? (size_t)(b % p.n_hfree) * g.n : 0), v);
         else if (far) { if (p.det_inverse) gen_fft2<true>(g, p, v); else gen_fft2<false>(g, p, v); }
         if (M > 1) {
             float2* dq = p.det + ((size_t)b * M + m) * row;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void ms_generic_kernel(MsParams p) {
         }
         __syncthreads();
         if (far) { if (p.det_inverse) gen_fft2<false>(g, p, v); else gen_fft2<true>(g, p, v); }
-        else if (p.det_mode == ADM_DET_FRESNEL_) gen_convolve<true>(g, p, p.gen_hfree_s, v);
+        else if (p.det_mode == ADM_DET_FRESNEL_) gen_convolve<true>(g, p, p.gen_hfree_s + (p.n_hfree > 1 ? (size_t)(b % p.n_hfree) * g.n : 0), v);
         // ---------------- reverse sweep ----------------
         const float sk1 = p.sigma * p.k1;
         for (int step = p.n_steps - 1; step >= 0; --step) {

@@ -369,23 +369,26 @@ __device__ __forceinline__ void rev_sweep(Ctx<N, R1, R2>& c, cf (&a)[R1], const 
     ADM_STAMP_ON(false);
 }
 
-template <int N, int R1, int R2>
-__device__ __forceinline__ void load_hfree(cf (&hf)[R2], const MsParams& p, int kx, int tc2) {
+// (a plan may hold several detector-plane kernels -- the distances of multi-distance data: position b takes kernel b % n_hfree.
+// Only in the per-position-probe instantiations, which is where such launches come from: the default kernel's code is untouched.)
+template <int N, int R1, int R2, bool PP>
+__device__ __forceinline__ void load_hfree(cf (&hf)[R2], const MsParams& p, int kx, int tc2, int b) {
     const double n2 = (double)(N * N);
+    const cf* hsel = PP ? p.hfree + (size_t)(b % p.n_hfree) * (N * N) : p.hfree;
 #pragma unroll
     for (int k = 0; k < R2; ++k) {
-        const cf h = p.hfree[(tc2 + R1 * k) * N + kx];
+        const cf h = hsel[(tc2 + R1 * k) * N + kx];
         hf[k] = make_float2((float)((double)h.x / n2), (float)((double)h.y / n2));
     }
 }
 
 // exit wave `a` -> detector plane.  Far field: unnormalised spectrum left in bb (pass-2 column role);
 // near field / Fresnel: the detector field stays in `a` (real space).
-template <int N, int R1, int R2>
-__device__ __forceinline__ void detector_forward(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2) {
+template <int N, int R1, int R2, bool PP>
+__device__ __forceinline__ void detector_forward(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2, int b) {
     if (p.det_mode == ADM_DET_FRESNEL_) {
         cf hf[R2];
-        load_hfree<N, R1, R2>(hf, p, kx, tc2);
+        load_hfree<N, R1, R2, PP>(hf, p, kx, tc2, b);
         convolve<N, R1, R2, false>(c, a, hf);
     } else if (p.det_mode == ADM_DET_FARFIELD_) {
         // Psi = scale * F(psi)  (F forward, or inverse via conjugation when det_inverse)
@@ -397,8 +400,8 @@ __device__ __forceinline__ void detector_forward(Ctx<N, R1, R2>& c, cf (&a)[R1],
     }
 }
 // dL/d(detector field) (in bb for the far field, in `a` otherwise) -> dL/d(exit wave) in `a`
-template <int N, int R1, int R2>
-__device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2) {
+template <int N, int R1, int R2, bool PP>
+__device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1], cf (&bb)[R2], const MsParams& p, int kx, int tc2, int b) {
     if (p.det_mode == ADM_DET_FARFIELD_) {
         ifft2_from_regs<N, R1, R2>(c, bb, a);
         if (p.det_inverse) {
@@ -407,7 +410,7 @@ __device__ __forceinline__ void detector_adjoint(Ctx<N, R1, R2>& c, cf (&a)[R1],
         }
     } else if (p.det_mode == ADM_DET_FRESNEL_) {
         cf hf[R2];
-        load_hfree<N, R1, R2>(hf, p, kx, tc2);
+        load_hfree<N, R1, R2, PP>(hf, p, kx, tc2, b);
         convolve<N, R1, R2, true>(c, a, hf);
     }
 }
@@ -484,7 +487,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         // ================= single probe mode: everything stays in registers =================
         load_probe<N, R1, R2>(c, a, PP ? p.probe + (size_t)b * p.probe_bstride : p.probe);
         fwd_sweep<N, R1, R2, BIN1, MODE>(c, a, hs, p, stash, tile_base, slice_stride, do_grad);
-        detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
+        detector_forward<N, R1, R2, PP>(c, a, bb, p, kx, tc2, b);
         if (p.det_mode == ADM_DET_FARFIELD_) {
             if (c.act2) {
                 const int mx = (kx + N / 2) % N;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         }
         block_loss<N, R1, R2>(lsum, red, p.loss_sum + b, tid, wave, lane);
         if (!do_grad) return;
-        detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
+        detector_adjoint<N, R1, R2, PP>(c, a, bb, p, kx, tc2, b);
         rev_sweep<N, R1, R2, BIN1, false, MODE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
         add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride : nullptr, p.gprobe_bstride != 0);
     } else {
@@ -531,7 +534,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
         for (int m = 0; m < M; ++m) {
             load_probe<N, R1, R2>(c, a, p.probe + (PP ? (size_t)b * p.probe_bstride : 0) + (size_t)m * N * N);
             fwd_sweep<N, R1, R2, BIN1, MODE>(c, a, hs, p, stash + (size_t)m * per, tile_base, slice_stride, do_grad);
-            detector_forward<N, R1, R2>(c, a, bb, p, kx, tc2);
+            detector_forward<N, R1, R2, PP>(c, a, bb, p, kx, tc2, b);
             float2* dq = p.det + ((size_t)b * M + m) * GE::G * GE::NT + tid;
             if (far) {
                 if (c.act2) {
@@ -590,7 +593,7 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void ms_fwd_adj_kernel(MsPara
 #pragma unroll
                 for (int k = 0; k < R1; ++k) a[k] = cscale(dq[(size_t)k * GE::NT], gf[k]);
             }
-            detector_adjoint<N, R1, R2>(c, a, bb, p, kx, tc2);
+            detector_adjoint<N, R1, R2, PP>(c, a, bb, p, kx, tc2, b);
             if (m == 0) rev_sweep<N, R1, R2, BIN1, false, MODE>(c, a, hs, p, stash, gtile, tile_base, slice_stride);
             else rev_sweep<N, R1, R2, BIN1, true, MODE>(c, a, hs, p, stash + (size_t)m * per, gtile, tile_base, slice_stride);
             add_probe_grad<N, R1, R2>(c, a, p.grad_probe ? p.grad_probe + (size_t)b * p.gprobe_bstride + (size_t)m * N * N : nullptr,

@@ -342,6 +342,14 @@ class Plan(object):
         call before the first workspace is sized."""
         check(self.ctx.lib.adm_plan_set_generic(self.handle, 1 if on else 0))
 
+    def set_detector_kernels(self, kernels):
+        """adm_plan_set_detector_kernels: position b of a launch is propagated to the detector with kernels[b % n] (complex
+        [Py,Px] each; real / imaginary parts cast separately like h)."""
+        k = np.stack([np.asarray(x) for x in kernels])
+        re = np.ascontiguousarray(k.real, dtype=np.float32)
+        im = np.ascontiguousarray(k.imag, dtype=np.float32)
+        check(self.ctx.lib.adm_plan_set_detector_kernels(self.handle, len(k), re.ctypes.data, im.ctypes.data))
+
     def set_transmission_cache(self, on=True):
         """adm_rotate_fwd also stores the slice transmission of every voxel it writes and the multislice kernel multiplies
         with it instead of evaluating exp / sincos per covering position (delta_beta unknowns, binning 1; bit-identical)."""

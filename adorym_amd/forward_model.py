@@ -552,9 +552,10 @@ class MultiDistModel(PtychographyModel):
     the hand-derived adjoint in adm_holo_fwd_adj.  ``common_vars_dict['holo_engine']`` is an adorym_amd.HolographyEngine.
 
     Data divided into sub-tiles and / or propagated with a safe zone (n_blocks > 1 or safe_zone_width > 0, :884-1034):
-    ``common_vars_dict['tile_engines']`` holds one MultisliceEngine per distance -- tile = sub-hologram + 2 safe zones, near-field
-    detector at that distance, detector mask = the sub-hologram's window -- and a minibatch of tiles is n_dists launches of the
-    multislice kernel with one probe window per tile (adm_multislice_fwd_adj_pp); object gradient only.
+    ``common_vars_dict['tile_engine']`` is a MultisliceEngine built for the sequence of distances -- tile = sub-hologram + 2 safe
+    zones, one detector-plane Fresnel kernel per distance in the plan (adm_plan_set_detector_kernels), detector mask = the
+    sub-hologram's window -- and a minibatch of tiles at all distances is ONE launch of the multislice kernel with one probe
+    window per entry (adm_multislice_fwd_adj_pp); object gradient only.
     """
 
     def __init__(self, loss_function_type='lsq', distribution_mode=None, device=None, common_vars_dict=None,
@@ -564,7 +565,7 @@ class MultiDistModel(PtychographyModel):
         if loss_function_type != 'lsq':
             raise NotImplementedError('MultiDistModel: only the LSQ loss is on the accelerated path')
         self.holo = common_vars_dict['holo_engine'] if common_vars_dict else None
-        self.tiles = common_vars_dict.get('tile_engines') if common_vars_dict else None
+        self.tile_engine = common_vars_dict.get('tile_engine') if common_vars_dict else None
         self._data_key = None
         self._data_dev = None
         self._small = {}
@@ -577,25 +578,30 @@ class MultiDistModel(PtychographyModel):
                 raise NotImplementedError('%s with MultiDistModel is outside the accelerated path' % flag)
         if not cv.get('two_d_mode'):
             raise NotImplementedError('MultiDistModel is accelerated for two_d_mode (one object slice) only')
-        if self.tiles is not None:
+        if self.tile_engine is not None:
             if int(safe_zone_width or 0) != int(cv.get('safe_zone_width') or 0):
-                raise ValueError('safe_zone_width differs from the width the tile engines were built for')
+                raise ValueError('safe_zone_width differs from the width the tile engine was built for')
             for flag in ('optimize_free_prop', 'optimize_prj_affine'):
                 if cv.get(flag):
                     raise NotImplementedError('%s with multi-distance data divided into sub-tiles is outside the accelerated path' % flag)
         elif safe_zone_width not in (0, None):
-            raise NotImplementedError('safe_zone_width > 0 needs the tile engines (the driver builds them)')
+            raise NotImplementedError('safe_zone_width > 0 needs the tile engine (the driver builds it)')
 
     # ------------------------------------------------------------------ sub-tiles + safe zone (forward_model.py:884-1034)
+    # One engine serves all distances: its plan holds the n_dists detector-plane kernels and a launch lists every tile of the
+    # minibatch n_dists times in a row ("tile-major": tile j at every distance, then tile j + 1), so entry b belongs to tile
+    # b // n_dists and distance b % n_dists.  The reference's order -- predictions and data -- is distance-major
+    # [i_dist * n_blocks + tile] (:1019-1021, 1051-1054); only predict() has to put its output back into it.
     def _tile_probes(self, probe_real, probe_imag, pos):
-        """One probe window [1, T, T] per tile of the batch, cut from the full-field probe padded with 1 + 0i
+        """One probe window [1, T, T] per launch entry, cut from the full-field probe padded with 1 + 0i
         (forward_model.py:916-925, 944-994).  Line :1005 passes ``subprobe_imag_ls_ls[k][i_mode, :, :]`` (no leading ':'): with
         one mode that is the IMAGINARY window of the first tile of the n_dp_batch chunk, used for the whole chunk -- kept, it is
         what the reference computes (golden F18 pins it with a probe that varies over the field).  The probe is not optimised on
         this path, so the windows of a batch are built once per distinct batch and stay on the device."""
         cv = self.common_vars
         szw = int(cv.get('safe_zone_width') or 0)
-        T = self.tiles[0].probe_size
+        eng = self.tile_engine
+        T, nd = eng.probe_size, eng.n_dists
         if getattr(self, '_probe_host', None) is None:
             host = probe_real.get() if isinstance(probe_real, DeviceArray) else \
                 np.stack([np.asarray(probe_real, np.float32), np.asarray(probe_imag, np.float32)], -1)
@@ -620,17 +626,20 @@ class MultiDistModel(PtychographyModel):
                 host[j, 0, :, :, 1] = pi[y0:y0 + T[0], x0:x0 + T[1]]
             if len(self._probe_cache) > 4096:
                 self._probe_cache.clear()
-            dev = self._probe_cache[key] = self.device.array(host)
+            dev = self._probe_cache[key] = self.device.array(np.repeat(host, nd, axis=0))
         return dev
 
-    def _tile_targets(self, this_i_theta, this_ind_batch, i_dist):
-        """|prj[theta, ind + i_dist * n_blocks]| (forward_model.py:1049-1056) inside a zero frame of the tile's size: the safe zone
-        carries no data and no weight in the loss."""
+    def _tile_frames(self, this_i_theta, tiles):
+        """The measured holograms of ``tiles`` at every distance, tile-major, each inside a zero frame of the tile's size (the
+        safe zone carries no data and no weight in the loss): |prj[theta, i_dist * n_blocks + tile]| through get_data
+        (forward_model.py:1049-1056)."""
         cv = self.common_vars
         szw = int(cv.get('safe_zone_width') or 0)
-        T = self.tiles[0].probe_size
-        n_blocks = self.prj.shape[1] // len(self.tiles)
-        ind = np.asarray(this_ind_batch) + i_dist * n_blocks
+        eng = self.tile_engine
+        T, nd = eng.probe_size, eng.n_dists
+        n_blocks = self.prj.shape[1] // nd
+        tiles = np.asarray(tiles)
+        ind = (tiles[:, None] + n_blocks * np.arange(nd)[None, :]).reshape(-1)
         t = self.get_data(this_i_theta, ind, theta_downsample=cv.get('theta_downsample') or 1, ds_level=cv.get('ds_level', 1))
         if szw == 0:
             return t
@@ -638,29 +647,56 @@ class MultiDistModel(PtychographyModel):
         full[:, szw:szw + t.shape[1], szw:szw + t.shape[2]] = t
         return full
 
+    def _tile_targets(self, this_i_theta, this_ind_batch):
+        """Datasets whose framed copy fits ADM_RESIDENT_DATA_MB live on the device, one tile-major [n_blocks * n_dists, Ty, Tx] array
+        per angle: a minibatch that is a run of consecutive tiles (the reference sorts a minibatch's indices,
+        adorym/ptychography.py:907) is a view of it -- no host work, no copy."""
+        eng = self.tile_engine
+        T, nd = eng.probe_size, eng.n_dists
+        n_blocks = self.prj.shape[1] // nd
+        ind = np.asarray(this_ind_batch)
+        if getattr(self, '_tiles_resident', None) is None:
+            limit = float(os.environ.get('ADM_RESIDENT_DATA_MB', '1024')) * 2 ** 20
+            self._tiles_resident = {} if 4.0 * self.prj.shape[0] * self.prj.shape[1] * T[0] * T[1] <= limit else False
+        if self._tiles_resident is not False and len(ind) > 0 and int(ind[-1]) - int(ind[0]) == len(ind) - 1 and np.all(np.diff(ind) == 1):
+            key = int(this_i_theta)
+            dev = self._tiles_resident.get(key)
+            if dev is None:
+                dev = self._tiles_resident[key] = self.device.array(self._tile_frames(this_i_theta, np.arange(n_blocks)))
+            return dev.view(int(ind[0]) * nd * T[0] * T[1], (len(ind) * nd, T[0], T[1]))
+        return self._tile_frames(this_i_theta, ind)
+
     def _run_tiled(self, obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad, grad_obj=None,
                    want_pred=False):
-        """n_dists launches over the minibatch's tiles.  The loss is the mean over distances x tiles x sub-hologram pixels
-        (forward_model.py:1019-1029, 1087): every launch scales its gradient with 2 / (n_dists B n_sub)."""
+        """ONE launch over (tiles of the minibatch) x (distances).  The loss is the mean over distances x tiles x sub-hologram
+        pixels (forward_model.py:1019-1029, 1087) -- the engine's mean over its n_dists * B entries and the kept detector pixels."""
         szw = int(self.common_vars.get('safe_zone_width') or 0)
+        eng = self.tile_engine
+        nd = eng.n_dists
         pos = np.ascontiguousarray(np.round(np.asarray(this_pos_batch)).astype(np.int64).reshape(-1, 2))
-        B, nd = len(pos), len(self.tiles)
+        B = len(pos)
         probes_b = self._tile_probes(probe_real, probe_imag, pos)
-        tokens, preds = [], []
-        for i, eng in enumerate(self.tiles):
-            eng.set_batch(pos - szw, self._tile_targets(this_i_theta, this_ind_batch, i))
-            yr = eng.y_footprint(pos - szw)
-            eng.rotate(obj, None, yr)
-            eng.multislice(None, want_grad=want_grad, want_pred=want_pred, grad_scale=2.0 / (nd * B * eng.n_det), probes_b=probes_b)
-            if want_grad:
-                eng.rotate_adjoint(grad_obj, None, yr)
-            if want_pred:
-                preds.append(eng.pred()[:, szw:szw + self.prj.shape[-2], szw:szw + self.prj.shape[-1]])
-            else:
-                tokens.append((eng, eng.loss_async()))
+        tpos = np.repeat(pos - szw, nd, axis=0)
+        eng.set_batch(tpos, self._tile_targets(this_i_theta, this_ind_batch))
+        yr = eng.y_footprint(tpos)
+        eng.rotate(obj, None, yr)
+        if want_grad:
+            # the overlap-add's cover lists only need the positions: built on the side stream, beside the launch
+            self.device.fork()
+            eng.flush_loss_copy()
+            eng.build_cover()
+            self.device.end_fork()
+        eng.multislice(None, want_grad=want_grad, want_pred=want_pred, probes_b=probes_b, accumulate=False)
+        if want_grad:
+            self.device.join()
+            eng.accumulate_tiles()
+            eng.rotate_adjoint(grad_obj, None, yr)
         if want_pred:
-            return np.concatenate(preds, 0)
-        return lambda: sum(e.loss_result(t) for e, t in tokens) / nd
+            sy, sx = self.prj.shape[-2:]
+            p = eng.pred()[:, szw:szw + sy, szw:szw + sx]
+            return np.ascontiguousarray(p.reshape(B, nd, sy, sx).transpose(1, 0, 2, 3).reshape(nd * B, sy, sx))
+        tok = eng.loss_async()
+        return lambda: eng.loss_result(tok)
 
     def _dev(self, name, value, shape):
         """Small parameter arrays: pass DeviceArrays through, upload (and cache) host values."""
@@ -700,7 +736,7 @@ class MultiDistModel(PtychographyModel):
         """Detected magnitudes [n_dists, ny, nx] (host float32), adorym/forward_model.py:819-1034."""
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         self.i_call += 1
-        if self.tiles is not None:
+        if self.tile_engine is not None:
             return self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False, want_pred=True)
         self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True)
         return self.holo.pred()
@@ -710,7 +746,7 @@ class MultiDistModel(PtychographyModel):
                            probe_pos_correction, this_ind_batch, free_prop_cm, safe_zone_width, prj_affine_ls, ctf_lg_kappa,
                            prj_pos_offset):
             self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
-            if self.tiles is not None:
+            if self.tile_engine is not None:
                 datav = self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False)
                 self.current_loss = float(datav() + self._regularize(obj, None))
                 return self.current_loss
@@ -729,7 +765,7 @@ class MultiDistModel(PtychographyModel):
         self._check(safe_zone_width, ctf_lg_kappa, probe_pos_correction)
         if _side_hook is not None:
             _side_hook()
-        if self.tiles is not None:
+        if self.tile_engine is not None:
             if list(opt_args_ls) != [0]:
                 raise NotImplementedError('multi-distance data divided into sub-tiles: only the object gradient is on the accelerated path')
             # the regulariser kernel initialises the gradient buffer ('set' mode, or a zero fill), the launches add to it

@@ -106,6 +106,9 @@ class MultisliceEngine(object):
                  fresnel_approx=True, sign_convention=1, normalize_fft=False, kernel=None, scale_ri_by_k=True,
                  n_probe_modes=1, max_batch=None, loss_function_type='lsq', poisson_multiplier=1., unknown_type='delta_beta',
                  beamstop=None, generic=False, transmission_cache=True, transmissions_only=False):
+        """``free_prop_cm``: 0 / None (exit wave), 'inf' (far field), a distance in cm (Fresnel propagation to the detector), or
+        a SEQUENCE of n distances: position b of every launch is propagated to distance b % n (multi-distance data divided into
+        sub-tiles, adorym/forward_model.py:999-1018 -- the caller lists every tile n times in a row, ``n_dists`` = n)."""
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
         self.probe_size = tuple(int(v) for v in probe_size)
@@ -120,6 +123,13 @@ class MultisliceEngine(object):
             kernel = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, self.probe_size, fresnel_approx=fresnel_approx,
                                 sign_convention=sign_convention)
         h_free = None
+        dists = None
+        if not isinstance(free_prop_cm, str) and np.ndim(free_prop_cm) > 0:
+            dists = [float(d_) for d_ in np.asarray(free_prop_cm).reshape(-1)]
+            if len(dists) == 0 or any(d_ == 0 for d_ in dists):
+                raise ValueError('free_prop_cm: a sequence of distances must be non-empty and non-zero')
+            free_prop_cm = dists[0]
+        self.n_dists = len(dists) if dists else 1
         if free_prop_cm in (0, None):
             det = _lib.DET_NONE
         elif isinstance(free_prop_cm, str) and free_prop_cm == 'inf':
@@ -134,6 +144,9 @@ class MultisliceEngine(object):
                          normalize_fft=normalize_fft, h_free=h_free,
                          loss_type={'lsq': _lib.LOSS_LSQ, 'poisson': _lib.LOSS_POISSON}[loss_function_type],
                          poisson_multiplier=poisson_multiplier, unknown_type=unknown_type)
+        if dists and len(dists) > 1:
+            self.plan.set_detector_kernels([get_kernel(d_ * 1e7, lmbda_nm, voxel_nm, self.probe_size, sign_convention=sign_convention)
+                                            for d_ in dists])
         if generic:
             self.plan.set_generic(True)       # the any-size kernel even where a tuned one exists (tests, A/B timing)
         # slice transmissions cached per rotated-frame voxel by rotate() (include/adm.h: adm_plan_set_transmission_cache)

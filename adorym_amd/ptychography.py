@@ -441,18 +441,18 @@ def reconstruct_ptychography(
     h = get_kernel(delta_nm * binning, lmbda_nm, voxel_nm, probe_size, fresnel_approx=fresnel_approx, sign_convention=sign_convention) \
         if not is_multi_dist else None
     probe_pos_int = np.round(probe_pos).astype(int)
-    holo_engine = tile_engines = None
+    holo_engine = tile_engine = None
     if holo_tiled:
-        # one engine per distance: tile = sub-hologram + 2 safe zones at (position - safe zone), Fresnel propagation to that
-        # distance after the slice (fresnel_propagate, adorym/propagate.py:282-288), loss over the sub-hologram's window only
-        # (forward_model.py:1027-1029) -- the detector mask that also serves the beamstop
+        # one engine for all distances: tile = sub-hologram + 2 safe zones at (position - safe zone), every tile listed n_dists
+        # times in a row and entry b Fresnel-propagated to distance b % n_dists after the slice (fresnel_propagate,
+        # adorym/propagate.py:282-288), loss over the sub-hologram's window only (forward_model.py:1027-1029) -- the detector mask
+        # that also serves the beamstop
         window = np.zeros(tile_size, np.float32)
         window[safe_zone_width:tile_size[0] - safe_zone_width, safe_zone_width:tile_size[1] - safe_zone_width] = 1
-        tile_engines = [MultisliceEngine(ctx, this_obj_size, tile_size, probe_pos_int - safe_zone_width, energy_ev, psize_cm,
-                                         free_prop_cm=float(d_), sign_convention=sign_convention, scale_ri_by_k=scale_ri_by_k,
-                                         max_batch=minibatch_size, unknown_type=unknown_type, beamstop=window)
-                        for d_ in free_prop_cm]
-        engine = tile_engines[0]            # (carries the object geometry for the regulariser kernels)
+        engine = tile_engine = MultisliceEngine(ctx, this_obj_size, tile_size, np.repeat(probe_pos_int - safe_zone_width, n_dists, axis=0),
+                                                energy_ev, psize_cm, free_prop_cm=free_prop_cm, sign_convention=sign_convention,
+                                                scale_ri_by_k=scale_ri_by_k, max_batch=minibatch_size * n_dists, unknown_type=unknown_type,
+                                                beamstop=window)
     elif is_multi_dist:
         from .holography import HolographyEngine
         holo_engine = HolographyEngine(ctx, probe_size, n_dists, energy_ev, psize_cm, sign_convention=sign_convention,
@@ -558,7 +558,7 @@ def reconstruct_ptychography(
     common_vars = dict(unknown_type=unknown_type, normalize_fft=normalize_fft, sign_convention=sign_convention,
                        rotate_out_of_loop=rotate_out_of_loop, scale_ri_by_k=scale_ri_by_k, is_minus_logged=is_minus_logged,
                        forward_algorithm=forward_algorithm, stdout_options=stdout_options, poisson_multiplier=poisson_multiplier,
-                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine, holo_engine=holo_engine, tile_engines=tile_engines,
+                       common_probe_pos=common_probe_pos, binning=binning, prj=prj, engine=engine, holo_engine=holo_engine, tile_engine=tile_engine,
                        safe_zone_width=safe_zone_width, n_dp_batch=n_dp_batch,
                        optimize_prj_affine=optimize_prj_affine, optimize_free_prop=optimize_free_prop, optimize_ctf_lg_kappa=optimize_ctf_lg_kappa,
                        rotation_tables=rotation_tables, two_d_mode=two_d_mode, theta_downsample=theta_downsample,

@@ -175,6 +175,15 @@ def cpu_baseline_c5(obj_h, d_h, a_h, data_h, N, energy, psize):
     return time.perf_counter() - t1
 
 
+def cpu_baseline_tiles(obj_h, pos, sub, szw, d_h, meas, energy, psize):
+    """CPU leg of tools/bench_rows.py (multi-distance data divided into sub-tiles): seconds for the oracle's fwd + adjoint of one
+    minibatch of tiles at every distance."""
+    from oracle import adorym_oracle as O
+    t1 = time.perf_counter()
+    O.multidist_tiles_forward_adjoint(obj_h, np.ones(obj_h.shape[:2], complex), pos, (sub, sub), szw, d_h, meas, energy, psize, dtype='float32')
+    return time.perf_counter() - t1
+
+
 def fused_batch_measure(ctx, eng, state, probe, tables, cfg, targets, check, n_groups, label, reps=3, comm=None, rank=0, world=1):
     """Secondary figures (not `value`): steps whose global batch holds `n_groups` reference minibatches of ONE angle, fused
     into one launch so that every CU has work.  Two reference semantics give such a step:

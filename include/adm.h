@@ -207,6 +207,13 @@ int adm_plan_destroy(adm_plan* plan);
  * mask >= 1e-5 take part in the loss, the others are dropped.  The per-position loss sums then run over the kept pixels only
  * and the caller's grad_scale / mean use their count.  NULL removes the mask. */
 int adm_plan_set_detector_mask(adm_plan* plan, const float* mask_host);
+/* Several detector-plane Fresnel kernels in one plan (det_mode ADM_DET_FRESNEL): multi-distance data divided into sub-tiles
+ * propagates the SAME tiles to every distance (adorym/forward_model.py:999-1018, one multislice_propagate_batch per distance).
+ * hfree_re / hfree_im: host [n][Py*Px], kernel i as adm_plan_desc.hfree_* would hold it for distance i.  Afterwards position b
+ * of a launch is propagated with kernel b % n (a launch of n * B positions, tile-major: tile j at every distance, then tile
+ * j + 1); such launches go through adm_multislice_fwd_adj_pp (every tile brings its own probe window) and their batch must
+ * be a multiple of n.  n = 1 restores the one-kernel behaviour. */
+int adm_plan_set_detector_kernels(adm_plan* plan, int n, const float* hfree_re, const float* hfree_im);
 /* number of floats of one rotated-frame buffer: obj_z * (obj_y+pads) * (obj_x+pads) * 2.
  * Internal layout is slice-major [Z][Yp][Xp][2] so that a tile slice is Py contiguous rows. */
 size_t adm_plan_rot_elems(const adm_plan* plan);

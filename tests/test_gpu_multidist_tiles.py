@@ -35,18 +35,19 @@ def _init(inp):
 
 
 def _model(A, ctx, rn, prj):
-    """MultiDistModel over tile engines, put together the way reconstruct_ptychography does."""
+    """MultiDistModel over the tile engine, put together the way reconstruct_ptychography does."""
     from adorym_amd.forward_model import MultiDistModel
     C = cases.C5TILES
     inp = cases.c5tiles_inputs(rn)
     N, SUB, szw = C['N'], C['SUB'], inp['szw']
     T = SUB + 2 * szw
+    nd = len(C['dists_cm'])
     window = np.zeros((T, T), np.float32)
     window[szw:T - szw, szw:T - szw] = 1
     pos = np.round(inp['pos']).astype(int)
-    engines = [A.MultisliceEngine(ctx, (N, N, 1), (T, T), pos - szw, C['energy_ev'], C['psize_cm'], free_prop_cm=float(d),
-                                  max_batch=C['minibatch_size'], unknown_type=inp['unknown_type'], beamstop=window) for d in C['dists_cm']]
-    cv = dict(unknown_type=inp['unknown_type'], prj=prj, engine=engines[0], tile_engines=engines, holo_engine=None, two_d_mode=True,
+    eng = A.MultisliceEngine(ctx, (N, N, 1), (T, T), np.repeat(pos - szw, nd, axis=0), C['energy_ev'], C['psize_cm'], free_prop_cm=C['dists_cm'],
+                             max_batch=C['minibatch_size'] * nd, unknown_type=inp['unknown_type'], beamstop=window)
+    cv = dict(unknown_type=inp['unknown_type'], prj=prj, engine=eng, tile_engine=eng, holo_engine=None, two_d_mode=True,
               safe_zone_width=szw, n_dp_batch=20, sign_convention=1, scale_ri_by_k=True)
     return MultiDistModel(device=ctx, common_vars_dict=cv, raw_data_type='magnitude'), inp
 
@@ -189,3 +190,43 @@ def test_probe_windows_through_the_any_size_kernel(A, ctx):
     assert abs(out[0][0] - out[1][0]) < 1e-5 * abs(out[0][0])
     assert np.linalg.norm(out[0][1] - out[1][1]) < 1e-5 * np.linalg.norm(out[0][1])
     assert np.linalg.norm(out[0][2] - out[1][2]) < 1e-5 * np.linalg.norm(out[0][2]) and np.abs(out[0][2]).max() > 0
+
+
+@pytest.mark.regression
+@pytest.mark.parametrize('T', [24, 40])
+def test_one_launch_over_all_distances_equals_one_engine_per_distance(A, ctx, T):
+    """adm_plan_set_detector_kernels: a plan with n detector-plane kernels propagates entry b of a launch with kernel b % n.  Against
+    n engines with one kernel each on the same tiles: per-entry loss sums and predictions bit for bit, the summed gradient to
+    rounding (the overlap-add adds the n contributions of a pixel in another order).  T = 24: tuned kernel; 40: the any-size one."""
+    r = cases.rng(1803 + T)
+    N, B, dists = 56, 6, (25., 45., 80.)
+    nd = len(dists)
+    pos = np.stack([r.integers(-4, N - T + 4, B), r.integers(-4, N - T + 4, B)], 1)
+    obj = ctx.array(np.stack([1 + 0.1 * r.standard_normal((N, N, 1)), 0.1 * r.standard_normal((N, N, 1))], -1).astype(np.float32))
+    probes = r.standard_normal((B, 1, T, T, 2)).astype(np.float32)
+    meas = np.abs(r.standard_normal((B, nd, T, T))).astype(np.float32)              # [tile][distance]
+    kw = dict(max_batch=B * nd, unknown_type='real_imag')
+    stack = A.MultisliceEngine(ctx, (N, N, 1), (T, T), np.repeat(pos, nd, 0), 17050., 1e-4, free_prop_cm=dists, **kw)
+    assert stack.n_dists == nd
+    stack.set_batch(np.repeat(pos, nd, 0), meas.reshape(B * nd, T, T))
+    stack.rotate(obj, None, None)
+    stack.multislice(None, want_pred=True, probes_b=ctx.array(np.repeat(probes, nd, 0)))
+    g1 = ctx.zeros(obj.shape)
+    stack.rotate_adjoint(g1, None, None)
+    sums1, pred1 = stack.loss_sums(B * nd).reshape(B, nd), stack.pred().reshape(B, nd, T, T)
+    g2 = ctx.zeros(obj.shape)
+    pb = ctx.array(probes)
+    for i, d in enumerate(dists):
+        e = A.MultisliceEngine(ctx, (N, N, 1), (T, T), pos, 17050., 1e-4, free_prop_cm=d, **kw)
+        e.set_batch(pos, meas[:, i])
+        e.rotate(obj, None, None)
+        e.multislice(None, want_pred=True, probes_b=pb, grad_scale=2.0 / (B * nd * e.n_det))
+        e.rotate_adjoint(g2, None, None)
+        assert np.array_equal(e.loss_sums(B), sums1[:, i])
+        assert np.array_equal(e.pred(), pred1[:, i])
+    a, b = g1.get(), g2.get()
+    assert np.abs(a).max() > 0 and np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+    # a batch that is not a multiple of the number of kernels is refused
+    stack.set_batch(np.repeat(pos, nd, 0)[:B * nd - 1], meas.reshape(B * nd, T, T)[:B * nd - 1])
+    with pytest.raises(Exception, match='multiple of n'):
+        stack.multislice(None, probes_b=ctx.array(np.repeat(probes, nd, 0)[:B * nd - 1]))

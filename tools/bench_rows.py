@@ -11,6 +11,8 @@ C1 shape: 2-D ptychography, 618 x 606 x 1 real_imag object, 5 incoherent probe m
           data, Adam on object + probe + sub-pixel probe positions, TV regulariser  (demos/2d_ptychography_experimental_data.py)
 C5 shape: multi-distance holography, 512 x 512 x 1 real_imag object, plane probe, 4 distances, Adam on object +
           distances + affine registration  (demos/2d_multidist_holography_w_affine.py)
+tiles:    the same kind of data divided into sub-tiles with a safe zone (adorym/forward_model.py:884-1034), 480 x 480, 4 distances,
+          100 holograms of 48 x 48 per distance, safe zone 12, minibatch 50 tiles
 """
 import json
 import os
@@ -309,10 +311,83 @@ def bench_c5(ctx, steps=50):
                              'sample': 'one fwd+adjoint of the 4-distance chain, oracle fp32 (optimiser excluded)'}}
 
 
+def bench_tiles(ctx, steps=50):
+    """f1 with the data divided into sub-tiles (adorym/forward_model.py:884-1034): a 480 x 480 object recorded at 4 distances as
+    10 x 10 holograms of 48 x 48 pixels, safe zone 12 (tile 72 x 72: the tuned kernel), minibatch 50 tiles, Adam on the object.
+    Timed through MultiDistModel.loss_and_gradients + the optimiser kernel, as the driver runs it."""
+    from adorym_amd.forward_model import MultiDistModel
+    from adorym_amd.dp import HipOps
+    N, SUB, szw, nd, mb = 480, 48, 12, 4, 50
+    T = SUB + 2 * szw
+    r = np.random.default_rng(2)
+    energy, psize = 17050., 1e-4
+    d_h = np.array([40., 60., 90., 140.])
+    pos = np.array([[y, x] for y in range(0, N, SUB) for x in range(0, N, SUB)])
+    window = np.zeros((T, T), np.float32)
+    window[szw:T - szw, szw:T - szw] = 1
+    eng = A.MultisliceEngine(ctx, (N, N, 1), (T, T), np.repeat(pos - szw, nd, axis=0), energy, psize, free_prop_cm=d_h, max_batch=mb * nd,
+                             unknown_type='real_imag', beamstop=window)
+    prj = (1 + 0.1 * r.standard_normal((1, nd * len(pos), SUB, SUB))).astype(np.float32)
+    cv = dict(unknown_type='real_imag', prj=prj, engine=eng, tile_engine=eng, holo_engine=None, two_d_mode=True, safe_zone_width=szw,
+              n_dp_batch=20, sign_convention=1, scale_ri_by_k=True)
+    fm = MultiDistModel(device=ctx, common_vars_dict=cv, raw_data_type='magnitude')
+    obj_h = np.stack([r.normal(1, 0.01, (N, N, 1)), r.normal(0, 0.01, (N, N, 1))], -1).astype(np.float32)
+    obj = ctx.array(obj_h)
+    g, m, v = ctx.empty(obj.shape), ctx.zeros((obj.size,)), ctx.zeros((obj.size,))
+    probe = ctx.array(np.stack([np.ones((1, N, N)), np.zeros((1, N, N))], -1).astype(np.float32))
+    ops = HipOps(ctx)
+    batches = [np.arange(0, mb), np.arange(mb, 2 * mb)]
+    ev = [ctx.event(), ctx.event()]
+    pending = [None]
+
+    def step(k, timed=False):
+        ind = batches[k % 2]
+        if timed:
+            ev[0].record()
+        fm.loss_and_gradients([0], g, obj, probe, None, 0., None, 0, pos[ind], prj, None, ind, d_h, szw, None, None, None, _init_grad=True)
+        if timed:
+            ev[1].record()
+        ops.adam(obj, g, 0, m, v, 0, 0, obj.size, k, 1e-3, 0.9, 0.999, 1e-7, 0, None)
+        tok = fm.take_loss_thunk()
+        out = pending[0]() if pending[0] is not None else None
+        pending[0] = tok
+        return out
+
+    for k in range(4):
+        step(k)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    ti = (time.perf_counter() - t0) / steps
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    ks = []
+    for k in range(10):
+        step(k, True)
+        ctx.sync()
+        ks.append(ev[0].elapsed_ms(ev[1]))
+    kern = float(np.median(ks))
+    full = np.concatenate([batches[0] + i * len(pos) for i in range(nd)])
+    tc = bench.cpu_baseline_tiles(obj_h.astype(np.float64), pos[batches[0]], SUB, szw, d_h, prj[0, full].astype(np.float64), energy, psize)
+    # compulsory traffic of one minibatch: per distance and tile the object window in (T^2 x 8 B), its probe window in (T^2 x 8), the
+    # sub-hologram in (SUB^2 x 4), the window's gradient out (T^2 x 8); object gradient written once (N^2 x 8)
+    alg = nd * mb * (3 * T * T * 8 + SUB * SUB * 4) + N * N * 8
+    return {'row': 'f1 / sub-tiles + safe zone', 'dtype': 'f32',
+            'workload': 'multi-distance holography 480x480x1 real_imag, 4 distances, 100 holograms of 48x48 per distance, safe zone 12 (tiles 72x72), minibatch 50 tiles, Adam',
+            'value': mb / dt, 'unit': 'tiles/s (each at 4 distances)', 'ms_per_step': 1e3 * dt, 'host_issue_ms_per_step': 1e3 * ti,
+            'roofline': {'bound': 'latency (rotation copy, ONE launch of 200 workgroups = 50 tiles x 4 distances, overlap-add, back-copy) -- priced against hbm',
+                         'kernel': 'the forward+adjoint launch group of one minibatch (rotate_fwd, ms_fwd_adj_kernel<72,8,9,...,PP>, cover_build, tile_accumulate, rotate_adj), HIP events',
+                         'achieved': alg / (kern * 1e-3) / 1e9, 'peak': bench.PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': alg / (kern * 1e-3) / 1e9 / bench.PEAK_HBM_GBS,
+                         'kernel_ms': kern, 'algorithmic_bytes_per_launch': alg, 'whole_step_frac': alg / dt / 1e9 / bench.PEAK_HBM_GBS, 'traffic': None},
+            'cpu_baseline': {'value': mb / tc, 'unit': 'tiles/s', 'cores': 1, 'kind': 'port',
+                             'sample': 'one minibatch (50 tiles x 4 distances) fwd+adjoint, oracle fp32 (optimiser excluded)'}}
+
+
 if __name__ == '__main__':
-    # python tools/bench_rows.py [c2] [c1] [c5]   (default: all three; one name = one row, e.g. under rocprofv3 --stats)
-    rows = {'c2': bench_c2, 'c1': bench_c1, 'c5': bench_c5}
-    want = [a for a in sys.argv[1:] if a in rows] or ['c2', 'c1', 'c5']
+    # python tools/bench_rows.py [c2] [c1] [c5] [tiles]   (default: all; one name = one row, e.g. under rocprofv3 --stats)
+    rows = {'c2': bench_c2, 'c1': bench_c1, 'c5': bench_c5, 'tiles': bench_tiles}
+    want = [a for a in sys.argv[1:] if a in rows] or ['c2', 'c1', 'c5', 'tiles']
     ctx = A.Context(0)
     for name in want:
         print(json.dumps(rows[name](ctx)))
