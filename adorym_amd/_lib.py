@@ -51,6 +51,7 @@ _VP, _SZ, _I, _F, _D = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_double
 SIGNATURES = {
     'adm_version': (_I, []),
     'adm_last_error': (C.c_char_p, []),
+    'adm_crash_line_set': (_I, [C.c_char_p, C.c_int]),
     'adm_device_count': (_I, []),
     'adm_mem_info': (_I, [_VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
     'adm_ctx_create': (_I, [_I, _VP, C.POINTER(_VP)]),

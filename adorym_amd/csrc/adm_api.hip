@@ -3,6 +3,8 @@
 #include <cmath>
 #include <vector>
 #include <cstring>
+#include <csignal>
+#include <unistd.h>
 #include "adm_common.h"
 
 namespace adm {
@@ -22,6 +24,49 @@ using namespace adm;
 
 extern "C" int adm_version(void) { return ADM_VERSION; }
 extern "C" const char* adm_last_error(void) { return g_err.c_str(); }
+
+// A line to leave on stdout if the process is killed by SIGABRT / SIGSEGV / SIGBUS (the ROCm runtime abort()s on a GPU memory
+// fault): write(2) + _exit only, both async-signal-safe.  bench.py arms it around the secondary legs of a multi-rank run, whose
+// transports have never seen several GPUs, so that a fault in one of them still leaves the measured headline line behind.
+static char g_crash_line[1 << 17];
+static volatile size_t g_crash_len = 0;
+static volatile int g_crash_code = 1;
+static bool g_crash_installed = false;
+static void crash_handler(int sig) {
+    const size_t n = g_crash_len;
+    if (n) {
+        size_t off = 0;
+        while (off < n) {
+            const ssize_t w = write(1, g_crash_line + off, n - off);
+            if (w <= 0) break;
+            off += (size_t)w;
+        }
+        _exit(g_crash_code);
+    }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+extern "C" int adm_crash_line_set(const char* line, int exit_code) {
+    g_crash_len = 0;
+    if (!line) return ADM_OK;
+    const size_t n = std::strlen(line);
+    if (n + 2 > sizeof(g_crash_line)) return fail(ADM_ERR_INVALID, "adm_crash_line_set: line too long");
+    std::memcpy(g_crash_line, line, n);
+    g_crash_line[n] = '\n';
+    g_crash_code = exit_code;
+    if (!g_crash_installed) {
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = crash_handler;
+        sigemptyset(&sa.sa_mask);
+        sigaction(SIGABRT, &sa, nullptr);
+        sigaction(SIGSEGV, &sa, nullptr);
+        sigaction(SIGBUS, &sa, nullptr);
+        g_crash_installed = true;
+    }
+    g_crash_len = n + 1;
+    return ADM_OK;
+}
 
 extern "C" int adm_ctx_create(int device, void* stream, adm_ctx** out) {
     if (!out) return fail(ADM_ERR_INVALID, "adm_ctx_create: out is null");

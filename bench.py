@@ -378,6 +378,7 @@ def main():
                     help='N > 1: seconds a secondary leg may take before it is abandoned and the line is printed without it (0 = no watchdog)')
     ap.add_argument('--no-p2p-leg', action='store_true', help='N > 1: skip the extra leg that repeats the headline loop through the peer-to-peer transport')
     ap.add_argument('--test-hang-leg', action='store_true', help=argparse.SUPPRESS)     # tests/: the last secondary leg never returns
+    ap.add_argument('--test-crash-leg', action='store_true', help=argparse.SUPPRESS)    # tests/: rank 0 abort()s inside the last secondary leg
     ap.add_argument('--restricted-exchange', action='store_true',
                     help='N > 1 experiment: sum only the y-planes the global batch touches, each part onto its owner; the owners add '
                          'the regulariser term N-fold (DESIGN.md section 6; tests/test_gpu_world2.py).  Off by default.')
@@ -690,6 +691,13 @@ def main():
             self.t = None
 
         def __enter__(self):
+            if use_dist and world > 1 and out is not None:
+                # a hard fault inside the leg (the runtime abort()s on a GPU memory fault) must not take the measured line with it
+                crashed = dict(out)
+                crashed['legs_abandoned'] = out.get('legs_abandoned', []) + [self.what]
+                crashed['comm'] = dict(out['comm'], note=((out['comm']['note'] + '; ') if out['comm']['note'] else '') +
+                                       "the process was killed by a signal inside leg '%s'" % self.what)
+                ctx.lib.adm_crash_line_set(json.dumps(crashed).encode(), EXIT_LEG_ABANDONED)
             if use_dist and world > 1 and args.leg_timeout > 0:
                 comm.barrier()
 
@@ -709,6 +717,8 @@ def main():
         def __exit__(self, *exc):
             if self.t is not None:
                 self.t.cancel()
+            if use_dist and world > 1 and out is not None:
+                ctx.lib.adm_crash_line_set(None, 0)
             return False
 
     # secondary leg on EVERY rank count: update_scheme='per angle' -- all minibatches of an angle fused, ONE exchange per step.
@@ -728,6 +738,8 @@ def main():
         with Watchdog('immediate_restricted' if not leg['restricted'] else 'immediate_full_exchange'):
             if args.test_hang_leg:
                 time.sleep(10 ** 6)
+            if args.test_crash_leg and rank == 0:
+                os.abort()
             leg['restricted'] = not leg['restricted']
             reset_state()
             dt2, kern2, ph2 = timed_loop()

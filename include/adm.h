@@ -41,6 +41,10 @@ typedef struct adm_plan adm_plan;
 /* ---- library / context ------------------------------------------------------------ */
 int adm_version(void);
 const char* adm_last_error(void);
+/* (no reference counterpart) A line to leave on stdout should the process be killed by SIGABRT / SIGSEGV / SIGBUS -- the ROCm
+ * runtime abort()s on a GPU memory fault -- followed by _exit(exit_code).  NULL disarms.  bench.py arms it around the secondary
+ * legs of a multi-rank run so that a fault inside one of them still leaves the measured headline line behind. */
+int adm_crash_line_set(const char* line, int exit_code);
 /* Number of GPUs visible to the process (0 if none / on error); creates no context.  Replaces the device enumeration
  * behind `gpu_index` (adorym/ptychography.py:203-205) for launchers that map local ranks to devices. */
 int adm_device_count(void);

@@ -113,3 +113,22 @@ def test_sharded_checkpoint_files_round_trip(tmp_path):
         restore_checkpoint(str(tmp_path), 2, rank=0, n_ranks=2, obj_shape=obj.shape, shard_size=60)
     with pytest.raises(ValueError, match='shape'):
         restore_checkpoint(str(tmp_path), 2, rank=0, n_ranks=2, obj_shape=(4, 5, 7, 2), shard_size=120)
+
+
+def test_crash_line_is_left_behind_when_the_process_is_killed_by_a_signal():
+    """adm_crash_line_set: after abort() -- what the ROCm runtime does on a GPU memory fault -- the armed line is on stdout and the
+    exit code is the one given; disarmed, the signal takes its default course.  (bench.py arms it around the secondary legs of a
+    multi-rank run.)  No GPU involved."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "from adorym_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "assert lib.adm_crash_line_set(b'{\"value\": 1.5, \"legs_abandoned\": [\"x\"]}', 5) == 0\n"
+            "%s"
+            "os.abort()\n") % (root, '%s')
+    r = subprocess.run([sys.executable, '-c', code % ''], capture_output=True, timeout=120)
+    assert r.returncode == 5 and r.stdout.decode().strip().splitlines()[-1] == '{"value": 1.5, "legs_abandoned": ["x"]}'
+    r = subprocess.run([sys.executable, '-c', code % 'lib.adm_crash_line_set(None, 0)\n'], capture_output=True, timeout=120)
+    assert r.returncode < 0 and r.stdout == b''
