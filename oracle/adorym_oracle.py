@@ -1224,28 +1224,37 @@ def multidist_tiles_forward_adjoint(obj, probe, pos_batch, sub_size, szw, dists_
 
 def reconstruct_multidist_tiles(prj, obj_init, probe, probe_pos, sub_size, szw, dists_cm, energy_ev, psize_cm, n_epochs=1,
                                 minibatch_size=4, learning_rate=1e-2, unknown_type='real_imag', raw_data_type='magnitude',
-                                n_dp_batch=20, dtype='float64'):
+                                n_dp_batch=20, dtype='float64', n_ranks=1):
     """reconstruct_ptychography on multi-distance data divided into n_blocks sub-tiles (two_d_mode: one angle; the tiles are the
-    'probe positions' of the task list, ptychography.py:791-912): Adam on the object.  ``prj`` [1, n_dists * n_blocks, sub, sub]."""
+    'probe positions' of the task list, ptychography.py:791-912): Adam on the object.  ``prj`` [1, n_dists * n_blocks, sub, sub].
+    ``n_ranks`` > 1: `mpirun -n R` -- every rank evaluates its slice of the global batch (:905-909), the gradients are summed
+    (:1113-1114), one Adam step; ``losses`` are rank 0's, ``losses_by_rank`` everyone's."""
     dt = np.dtype(dtype)
     obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
     m, v = np.zeros_like(obj), np.zeros_like(obj)
     pos = np.asarray(probe_pos, dtype=float)
     n_blocks = len(pos)
     nd = len(dists_cm)
-    losses, first_grad, first_pred = [], None, None
+    losses, first_grad, first_pred = [[] for _ in range(n_ranks)], None, None
+    inds = [[] for _ in range(n_ranks)]
     for i_epoch in range(n_epochs):
-        batches = epoch_task_list(i_epoch, 1, n_blocks, minibatch_size, 1, 'immediate', two_d_mode=True)
+        batches = epoch_task_list(i_epoch, 1, n_blocks, minibatch_size, n_ranks, 'immediate', two_d_mode=True)
         i_opt_batch = 0
         for i_batch in range(len(batches)):
-            _, ind = rank_batch(batches, i_batch, 0, minibatch_size, 1)
-            full = np.concatenate([ind + i * n_blocks for i in range(nd)])          # forward_model.py:1051-1054
-            loss, pred, g = multidist_tiles_forward_adjoint(obj, probe, pos[ind], sub_size, szw, dists_cm, prj[0, full], energy_ev,
-                                                            psize_cm, unknown_type, raw_data_type, n_dp_batch, dt)
+            g = None
+            for r in range(n_ranks):
+                _, ind = rank_batch(batches, i_batch, r, minibatch_size, n_ranks)
+                full = np.concatenate([ind + i * n_blocks for i in range(nd)])          # forward_model.py:1051-1054
+                loss, pred, gr = multidist_tiles_forward_adjoint(obj, probe, pos[ind], sub_size, szw, dists_cm, prj[0, full], energy_ev,
+                                                                 psize_cm, unknown_type, raw_data_type, n_dp_batch, dt)
+                g = gr if g is None else g + gr
+                losses[r].append(float(loss))
+                inds[r].append(ind)
+                if first_pred is None:
+                    first_pred = pred.copy()
             if first_grad is None:
-                first_grad, first_pred = g.copy(), pred.copy()
+                first_grad = g.copy()
             obj, m, v = adam_step(obj, g.astype(dt), m, v, i_opt_batch, step_size=learning_rate)
-            losses.append(float(loss))
             if i_batch == len(batches) - 1:
                 i_opt_batch += 1
-    return dict(obj=obj, losses=losses, first_grad=first_grad, first_pred=first_pred)
+    return dict(obj=obj, losses=losses[0], losses_by_rank=losses, batches_by_rank=inds, first_grad=first_grad, first_pred=first_pred)

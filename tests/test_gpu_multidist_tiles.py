@@ -230,3 +230,62 @@ def test_one_launch_over_all_distances_equals_one_engine_per_distance(A, ctx, T)
     stack.set_batch(np.repeat(pos, nd, 0)[:B * nd - 1], meas.reshape(B * nd, T, T)[:B * nd - 1])
     with pytest.raises(Exception, match='multiple of n'):
         stack.multislice(None, probes_b=ctx.array(np.repeat(probes, nd, 0)[:B * nd - 1]))
+
+
+# ------------------------------------------------------------------------------------ two ranks (tiles shard like probe positions)
+def _w2_worker(rank, world, port, tmp, q, transport):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests', 'golden'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), ADM_COMM=transport)
+    try:
+        import adorym_amd as A
+        from adorym_amd import comm as Cm
+        import cases as cs
+        C = cs.C5TILES
+        inp = cs.c5tiles_inputs('ri_szw4')
+        N = C['N']
+        comm = Cm.from_env()
+        assert comm.size == world
+        st = A.reconstruct_ptychography(
+            comm=comm, fname=np.load(F18)['ri_szw4_prj'], obj_size=(N, N, 1), probe_pos=inp['pos'], theta_st=0, theta_end=0, n_theta=1,
+            two_d_mode=True, energy_ev=C['energy_ev'], psize_cm=C['psize_cm'], free_prop_cm=np.array(C['dists_cm']), minibatch_size=2,
+            n_epochs=C['n_epochs'], initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='plane', raw_data_type='magnitude',
+            unknown_type='real_imag', gamma=0, alpha_d=0, alpha_b=0, optimizer='adam', learning_rate=C['learning_rate'], n_dp_batch=20,
+            randomize_probe_pos=False, safe_zone_width=inp['szw'], save_path=tmp, output_folder='w2', store_checkpoint=False,
+            use_checkpoint=False, return_state=True)
+        comm.close()
+        q.put(dict(rank=rank, obj=np.stack([st['delta'], st['beta']], -1), losses=np.array(st['losses'])))
+    except Exception as e:
+        import traceback
+        q.put(dict(rank=rank, error='%r\n%s' % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize('transport', ['host', 'p2p'])
+def test_two_ranks_vs_reference_driver_as_two_processes(tmp_path, transport):
+    """The tiled run at world size 2 -- two fresh processes sharing GPU 0, minibatch 2 tiles per rank, gradients summed by the
+    host-staged transport or by the direct exchange -- against golden F18_world2 (the reference driver as two processes): both
+    ranks' losses, the final object (3x rule), identical replicas."""
+    import multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_w2_worker, args=(r, 2, port, str(tmp_path), q, transport)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r['rank'])
+    [p.join(60) for p in procs]
+    for r in res:
+        assert 'error' not in r, r['error']
+    w2 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F18_world2.npz'))
+    assert np.array_equal(res[0]['obj'], res[1]['obj'])
+    for r in res:
+        l64, l32 = w2['r%d_losses_64' % r['rank']], w2['r%d_losses_32' % r['rank']]
+        assert np.all(np.abs(r['losses'] - l64) <= np.maximum(2e-4 * np.abs(l64), 3 * np.abs(l32 - l64))), (r['losses'], l64)
+    inp = cases.c5tiles_inputs('ri_szw4')
+    o64, o32 = w2['obj_64'], w2['obj_32']
+    upd = np.linalg.norm(o64 - np.stack(_init(inp), -1))
+    e, e_ref = np.linalg.norm(res[0]['obj'] - o64) / upd, np.linalg.norm(o32 - o64) / upd
+    print('world 2 (%s): final object vs the reference two-process run, relative to the update: %.2e (reference fp32: %.2e)' % (transport, e, e_ref))
+    assert e < max(5e-3, 3 * e_ref), (e, e_ref)

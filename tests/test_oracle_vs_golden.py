@@ -577,3 +577,20 @@ def test_f18_fp32_oracle_tracks_fp32_reference():
     ref_g = f['first_grad_ri_szw4_32']
     assert np.linalg.norm(out['first_grad'] - ref_g) < 1e-4 * np.linalg.norm(ref_g)
     assert np.allclose(out['losses'], f['losses_ri_szw4_32'], rtol=1e-3)
+
+
+def test_f18_two_ranks_vs_reference_driver_as_two_processes():
+    """The tiled multi-distance run as `mpirun -n 2` (golden F18_world2: the reference driver as two processes, minibatch 2 tiles
+    per rank): the ranks' tile batches, both ranks' losses, the first summed gradient, the final object."""
+    C = cases.C5TILES
+    f, w2 = load('F18_multidist_tiles'), load('F18_world2')
+    inp = cases.c5tiles_inputs('ri_szw4')
+    out = O.reconstruct_multidist_tiles(f['ri_szw4_prj'].astype(np.float64), _f18_init('ri_szw4'), np.ones((C['N'], C['N']), complex), inp['pos'],
+                                        (C['SUB'], C['SUB']), inp['szw'], C['dists_cm'], C['energy_ev'], C['psize_cm'], n_epochs=C['n_epochs'],
+                                        minibatch_size=2, learning_rate=C['learning_rate'], n_ranks=2)
+    for r in range(2):
+        assert np.array_equal(np.stack(out['batches_by_rank'][r]), w2['r%d_ind_64' % r])
+        assert np.allclose(out['losses_by_rank'][r], w2['r%d_losses_64' % r], rtol=1e-8)
+    g = w2['first_grad_sum_64']
+    assert np.linalg.norm(out['first_grad'] - g) < 1e-9 * np.linalg.norm(g)
+    assert np.abs(out['obj'] - w2['obj_64']).max() < 2e-6 * np.abs(w2['obj_64']).max()
