@@ -602,11 +602,19 @@ class MultiDistModel(PtychographyModel):
         szw = int(cv.get('safe_zone_width') or 0)
         eng = self.tile_engine
         T, nd = eng.probe_size, eng.n_dists
-        if getattr(self, '_probe_host', None) is None:
-            host = probe_real.get() if isinstance(probe_real, DeviceArray) else \
-                np.stack([np.asarray(probe_real, np.float32), np.asarray(probe_imag, np.float32)], -1)
+        # which probe the cached windows were cut from: a device array by identity (nothing updates it on this path: the driver
+        # refuses optimize_probe with tiles), host arrays by content
+        if isinstance(probe_real, DeviceArray):
+            ident = ('dev', probe_real.ptr, tuple(probe_real.shape))
+        else:
+            host = np.stack([np.asarray(probe_real, np.float32), np.asarray(probe_imag, np.float32)], -1)
+            ident = ('host', host.shape, host.tobytes())
+        if getattr(self, '_probe_ident', None) != ident:
+            if isinstance(probe_real, DeviceArray):
+                host = probe_real.get()
             self._probe_host = host.reshape(host.shape[-3], host.shape[-2], 2)
             self._probe_cache = {}
+            self._probe_ident = ident
         key = pos.tobytes()
         dev = self._probe_cache.get(key)
         if dev is None:

@@ -1055,12 +1055,36 @@ def affine_sample(img, theta, want_grad_theta=False, cot=None):
     return out, g
 
 
+def fourier_shift_real(img, shift, dtype='float64', want_derivatives=False):
+    """realign_image_fourier (util.py:380-397) of a real image with a zero imaginary part, REAL part of the result -- what
+    MultiDistModel keeps of it (forward_model.py:1075-1085: ``this_prj_batch_idist, _ = realign_image_fourier(...)``):
+    Re IFFT2( FFT2(img) * exp(-2 PI i (fx * shift[1] + fy * shift[0])) ), fx / fy = np.fft.fftfreq along columns / rows.
+    With want_derivatives also d/dshift[0], d/dshift[1]."""
+    dt = np.dtype(dtype)
+    cdt = _cdtype(dt)
+    H, W = img.shape
+    fy = np.fft.fftfreq(H, 1)[:, None].astype(dt)
+    fx = np.fft.fftfreq(W, 1)[None, :].astype(dt)
+    arg = (dt.type(-2 * PI) * (fx * dt.type(shift[1]) + fy * dt.type(shift[0]))).astype(dt)
+    S = (np.fft.fft2(np.asarray(img, dtype=dt)).astype(cdt) * (np.cos(arg) + 1j * np.sin(arg)).astype(cdt)).astype(cdt)
+    out = np.fft.ifft2(S).real.astype(dt)
+    if not want_derivatives:
+        return out
+    dy = np.fft.ifft2(S * (dt.type(-2 * PI) * 1j * fy)).real.astype(dt)
+    dx = np.fft.ifft2(S * (dt.type(-2 * PI) * 1j * fx)).real.astype(dt)
+    return out, dy, dx
+
+
 def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm, raw_data_type='intensity',
-                         sign_convention=1, dtype='float64'):
+                         sign_convention=1, dtype='float64', shifts=None):
     """Loss and gradients of the multi-distance chain for a real_imag object [N,N,1,2] under a complex probe [N,N]:
     psi = probe*o;  Psi_d = IFFT2(FFT2(psi) * exp(-i sigma PI lambda d (u^2+v^2)))  (propagate.py:84-103, 556-568);
     loss = mean_d,pixels (|Psi_d| - sqrt|affine(data_d, A_d)|)^2.  Returns loss, pred, target, grad_obj [N,N,1,2],
-    grad_probe (complex), grad_dists_cm [n_d], grad_affine [n_d,2,3]."""
+    grad_probe (complex), grad_dists_cm [n_d], grad_affine [n_d,2,3].
+
+    ``shifts`` [n_d, 2] (optimize_all_probe_pos with multi-distance data, forward_model.py:1075-1085): every registered hologram
+    is Fourier-shifted by its own (sy, sx), real part kept, before the loss; an eighth return value dL/dshifts [n_d, 2] is
+    appended (the affine gradient is then not formed: the reference demos refine one or the other)."""
     dt = np.dtype(dtype)
     cdt = _cdtype(dt)
     N0, N1 = obj.shape[:2]
@@ -1076,6 +1100,7 @@ def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm
     preds, tgts = [], []
     g_dists = np.zeros(nd, dtype=dt)
     g_aff = np.zeros((nd, 2, 3), dtype=dt)
+    g_sh = np.zeros((nd, 2), dtype=dt)
     GF = np.zeros_like(F)
     for i in range(nd):
         d_nm = dt.type(dists_cm[i]) * dt.type(1e7)
@@ -1084,6 +1109,8 @@ def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm
         Psi = np.fft.ifft2(F * Hd).astype(cdt)
         pred = np.abs(Psi)
         samp = affine_sample(np.asarray(data[i], dtype=dt), np.asarray(affine[i], dtype=dt))
+        if shifts is not None:
+            samp, d_sy, d_sx = fourier_shift_real(samp, shifts[i], dt, want_derivatives=True)
         tgt = np.sqrt(np.abs(samp)) if raw_data_type == 'intensity' else np.abs(samp)
         diff = pred - tgt
         loss += np.sum(diff ** 2) / n_tot
@@ -1092,7 +1119,10 @@ def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm
             dtgt = -(2 / n_tot) * diff
             cot = dtgt * (np.sign(samp) / (2 * np.sqrt(np.abs(samp))) if raw_data_type == 'intensity' else np.sign(samp))
         cot = np.where(np.isfinite(cot), cot, 0)
-        _, g_aff[i] = affine_sample(np.asarray(data[i], dtype=dt), np.asarray(affine[i], dtype=dt), cot=cot)
+        if shifts is not None:
+            g_sh[i] = [np.sum(cot * d_sy), np.sum(cot * d_sx)]
+        else:
+            _, g_aff[i] = affine_sample(np.asarray(data[i], dtype=dt), np.asarray(affine[i], dtype=dt), cot=cot)
         Gh = np.fft.fft2(G) / (N0 * N1)
         dH = (-1j * sign_convention * PI * lm) * uv2 * Hd
         g_dists[i] = np.real(np.sum(np.conj(Gh) * dH * F)) * 1e7
@@ -1103,15 +1133,20 @@ def holo_forward_adjoint(obj, probe, dists_cm, affine, data, energy_ev, psize_cm
     g_obj = np.zeros_like(obj, dtype=dt)
     g_obj[:, :, 0, 0] = g_o.real
     g_obj[:, :, 0, 1] = g_o.imag
+    if shifts is not None:
+        return loss, np.stack(preds), np.stack(tgts), g_obj, g_psi * np.conj(o), g_dists, g_aff, g_sh
     return loss, np.stack(preds), np.stack(tgts), g_obj, g_psi * np.conj(o), g_dists, g_aff
 
 
 def reconstruct_multidist(data, obj_init, probe, dists_cm, energy_ev, psize_cm, n_epochs=1, learning_rate=1e-2,
                           optimize_free_prop=False, free_prop_learning_rate=1e-1, optimize_prj_affine=False,
-                          prj_affine_learning_rate=1e-3, raw_data_type='intensity', dtype='float64'):
+                          prj_affine_learning_rate=1e-3, raw_data_type='intensity', dtype='float64', optimize_all_probe_pos=False,
+                          all_probe_pos_learning_rate=1e-2):
     """reconstruct_ptychography for multi-distance data of one undivided tile (two_d_mode, minibatch 1, one minibatch per
     epoch => the Adam step counter is 0 in every epoch, ptychography.py:848): Adam on the object, optionally on the
-    distances and the affine matrices (matrix 0 is pinned to the identity after every update, optimizers.py:1062-1075)."""
+    distances and the affine matrices (matrix 0 is pinned to the identity after every update, optimizers.py:1062-1075), or on
+    one (sy, sx) per distance (``optimize_all_probe_pos``: probe_pos_correction [n_dists, 2] from zero, re-centred after every
+    update, optimizers.py:1039-1049)."""
     dt = np.dtype(dtype)
     obj = np.stack([obj_init[0], obj_init[1]], -1).astype(dt)
     m, v = np.zeros_like(obj), np.zeros_like(obj)
@@ -1120,18 +1155,27 @@ def reconstruct_multidist(data, obj_init, probe, dists_cm, energy_ev, psize_cm, 
     aff = np.tile(np.array([[1., 0, 0], [0, 1., 0]], dtype=dt), [len(dists), 1, 1])
     am, av = np.zeros_like(aff), np.zeros_like(aff)
     losses, first_grad = [], None
+    sh = np.zeros((len(dists), 2), dtype=dt)
+    sm, sv = np.zeros_like(sh), np.zeros_like(sh)
+    trace = []
     for i_epoch in range(n_epochs):
-        loss, _, _, g, _, gd, ga = holo_forward_adjoint(obj, probe, dists, aff, data, energy_ev, psize_cm, raw_data_type, 1, dt)
+        res = holo_forward_adjoint(obj, probe, dists, aff, data, energy_ev, psize_cm, raw_data_type, 1, dt,
+                                   shifts=sh if optimize_all_probe_pos else None)
+        loss, g, gd, ga = res[0], res[3], res[5], res[6]
         if first_grad is None:
             first_grad = g.copy()
         obj, m, v = adam_step(obj, g, m, v, 0, step_size=learning_rate)
+        if optimize_all_probe_pos:
+            sh, sm, sv = adam_step(sh, res[7], sm, sv, 0, step_size=all_probe_pos_learning_rate)
+            sh = sh - sh.mean(axis=0)
+            trace.append(sh.copy())
         if optimize_free_prop:
             dists, dm, dv = adam_step(dists, gd, dm, dv, 0, step_size=free_prop_learning_rate)
         if optimize_prj_affine:
             aff, am, av = adam_step(aff, ga, am, av, 0, step_size=prj_affine_learning_rate)
             aff[0] = np.array([[1., 0, 0], [0, 1., 0]], dtype=dt)
         losses.append(float(loss))
-    return dict(obj=obj, dists=dists, affine=aff, losses=losses, first_grad=first_grad)
+    return dict(obj=obj, dists=dists, affine=aff, losses=losses, first_grad=first_grad, shifts=sh, shift_trace=trace)
 
 
 # --------------------------------------------------------------------------------------

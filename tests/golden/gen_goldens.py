@@ -908,8 +908,103 @@ def gen_f18():
     save('F18_multidist_tiles', **out)
 
 
+# ----------------------------------------------------------------------------- F19 (f1 row: per-distance shift refinement)
+def _multidist_chain_shift(o, dists_cm, shifts, data, energy, psize_cm, raw='intensity'):
+    """MultiDistModel.predict + get_loss_function with optimize_all_probe_pos (forward_model.py:1075-1085): plane probe, every
+    measured hologram Fourier-shifted by its own (sy, sx) (realign_image_fourier, real part kept) before the loss."""
+    N = o.shape[0]
+    one = torch.ones((N, N), dtype=o.dtype); zero = torch.zeros((N, N), dtype=o.dtype)
+    preds = []
+    for i in range(len(dists_cm)):
+        er, ei = multislice_propagate_batch(o[None], one, zero, energy, psize_cm, kernel=None, free_prop_cm=float(dists_cm[i]),
+                                            obj_batch_shape=[1, N, N, 1], type='real_imag')
+        preds.append(w.sqrt(er ** 2 + ei ** 2))
+    pred = w.concatenate(preds, 0)
+    tg = []
+    for i in range(len(dists_cm)):
+        t, _ = U.realign_image_fourier(data[i:i + 1], w.zeros_like(data[i:i + 1]), shifts[i], axes=(1, 2))
+        tg.append(t)
+    tgt = w.concatenate(tg)
+    fm = adorym.ForwardModel(loss_function_type='lsq', raw_data_type=raw)
+    return fm.get_mismatch_loss(pred, tgt), pred, tgt
+
+
+def gen_f19():
+    """demos/2d_multidist_holography_w_position_correction.py at a small size: the holograms of distances 1 and 2 are recorded
+    shifted by a fraction of a pixel; `optimize_all_probe_pos` refines one (sy, sx) per distance with the object."""
+    out = {}
+    C = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = C['N']
+    nd = len(C['dists_cm'])
+    gs.run_fp64 = True
+    truth = np.stack([inp['truth'][0] * np.cos(inp['truth'][1]), inp['truth'][0] * np.sin(inp['truth'][1])], -1)
+    shift_true = np.array([[0., 0.], [0.6, -0.45], [-0.35, 0.8]])
+    d64 = torch.tensor(C['dists_cm'], dtype=torch.float64)
+    _, pred_t, _ = _multidist_chain_shift(torch.tensor(truth), d64, torch.zeros((nd, 2), dtype=torch.float64),
+                                          torch.zeros((nd, N, N), dtype=torch.float64), C['energy_ev'], C['psize_cm'])
+    inten = pred_t.detach() ** 2
+    # recorded holograms = the true ones displaced by -shift_true (so that +shift_true registers them)
+    data = torch.cat([U.realign_image_fourier(inten[i:i + 1], torch.zeros_like(inten[i:i + 1]), torch.tensor(-shift_true[i]), axes=(1, 2))[0]
+                      for i in range(nd)]).numpy()
+    out['data'] = data.astype(np.float32)
+    out['shift_true'] = shift_true
+    data = out['data'].astype(np.float64)
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    guess = np.stack([g0.real, g0.imag], -1)
+    out['guess'] = guess
+    shift_guess = shift_true + 0.2 * cases.rng(1900).uniform(-1, 1, (nd, 2))
+    out['shift_guess'] = shift_guess
+    for fp64 in (True, False):
+        gs.run_fp64 = fp64
+        dt = torch.float64 if fp64 else torch.float32
+        o = torch.tensor(guess, dtype=dt, requires_grad=True)
+        sh = torch.tensor(shift_guess, dtype=dt, requires_grad=True)
+        loss, pred, tgt = _multidist_chain_shift(o, torch.tensor(C['dists_cm'], dtype=dt), sh, torch.tensor(data, dtype=dt), C['energy_ev'], C['psize_cm'])
+        g = torch.autograd.grad(loss, [o, sh])
+        tag = '_64' if fp64 else '_32'
+        out['loss' + tag] = np.array(loss.item()); out['pred' + tag] = pred.detach().numpy(); out['target' + tag] = tgt.detach().numpy()
+        out['grad_obj' + tag] = g[0].numpy(); out['grad_shifts' + tag] = g[1].numpy()
+    gs.run_fp64 = False
+    # the reference driver end to end
+    import adorym.ptychography as PT
+    orig_up = PT.update_parameters
+    prj = out['data'][None].astype(np.float64)
+
+    class MultiDistPlugin(adorym.MultiDistModel):
+        def __init__(self, *a, run_bfloat16=False, run_float64=False, **k):
+            super().__init__(*a, **k)
+
+    for fp64 in (True, False):
+        rec = {}
+        def rec_up(opt_ls, optimizable_params, kw, _rec=rec):
+            res = orig_up(opt_ls, optimizable_params, kw)
+            _rec['shifts'] = res['probe_pos_correction'].detach().numpy().copy()
+            _rec.setdefault('shift_trace', []).append(_rec['shifts'])
+            return res
+        PT.update_parameters = rec_up
+        try:
+            run_driver(prj, [N, N, 1], np.array([[0., 0.]]), 0, 1,
+                       dict(minibatch_size=1, n_epochs=5, two_d_mode=True, energy_ev=C['energy_ev'], psize_cm=C['psize_cm'],
+                            free_prop_cm=np.array(C['dists_cm']), initial_guess=[inp['guess'][0], inp['guess'][1]],
+                            probe_type='plane', raw_data_type='intensity', unknown_type='real_imag', gamma=0, alpha_d=0, alpha_b=0,
+                            optimizer='adam', learning_rate=1e-2, optimize_all_probe_pos=True, all_probe_pos_learning_rate=1e-1,
+                            n_dp_batch=1, run_float64=fp64, randomize_probe_pos=True, safe_zone_width=0, forward_model=MultiDistPlugin),
+                       rec, ri=True)
+        finally:
+            PT.update_parameters = orig_up
+        tag = '_64' if fp64 else '_32'
+        out['e2e_obj' + tag] = np.stack([rec['mag'] * np.cos(rec['phase']), rec['mag'] * np.sin(rec['phase'])], -1)
+        out['e2e_losses' + tag] = rec['losses']
+        out['e2e_shifts' + tag] = rec['shifts']
+        out['e2e_shift_trace' + tag] = np.stack(rec['shift_trace'])
+        out['e2e_first_grad' + tag] = rec['first_grad']
+    gs.run_fp64 = False
+    save('F19_multidist_shifts', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f18']
+    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f18', 'f19']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -926,3 +1021,4 @@ if __name__ == '__main__':
     if 'f16' in which: gen_f16()
     if 'f17' in which: gen_f17()
     if 'f18' in which: gen_f18()
+    if 'f19' in which: gen_f19()

@@ -594,3 +594,34 @@ def test_f18_two_ranks_vs_reference_driver_as_two_processes():
     g = w2['first_grad_sum_64']
     assert np.linalg.norm(out['first_grad'] - g) < 1e-9 * np.linalg.norm(g)
     assert np.abs(out['obj'] - w2['obj_64']).max() < 2e-6 * np.abs(w2['obj_64']).max()
+
+
+# ------------------------------------------------------------------------------------ F19 (f1 row, per-distance shift refinement)
+def test_f19_shifted_holograms_gradients():
+    """optimize_all_probe_pos with multi-distance data (forward_model.py:1075-1085; demos/2d_multidist_holography_w_position_correction.py):
+    loss, registered targets, gradients w.r.t. the object and the per-distance shifts against the reference's autograd."""
+    f = load('F19_multidist_shifts')
+    C = cases.C5MINI
+    N = C['N']
+    ident = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [3, 1, 1])
+    res = O.holo_forward_adjoint(f['guess'], np.ones((N, N), complex), C['dists_cm'], ident, f['data'].astype(np.float64), C['energy_ev'],
+                                 C['psize_cm'], shifts=f['shift_guess'])
+    loss, pred, tgt, g_obj, g_sh = res[0], res[1], res[2], res[3], res[7]
+    assert abs(loss - f['loss_64']) < 1e-10 * abs(f['loss_64'])
+    assert np.abs(pred - f['pred_64']).max() < 1e-10
+    assert np.abs(tgt ** 2 - np.abs(f['target_64'])).max() < 1e-10          # golden = shifted intensity (sign kept there)
+    assert np.linalg.norm(g_obj - f['grad_obj_64']) < 1e-8 * np.linalg.norm(f['grad_obj_64'])
+    assert np.linalg.norm(g_sh - f['grad_shifts_64']) < 1e-8 * np.linalg.norm(f['grad_shifts_64'])
+
+
+def test_f19_end_to_end_shift_refinement():
+    f = load('F19_multidist_shifts')
+    C = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = C['N']
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    out = O.reconstruct_multidist(f['data'].astype(np.float64), [g0.real, g0.imag], np.ones((N, N), complex), C['dists_cm'], C['energy_ev'],
+                                  C['psize_cm'], n_epochs=5, learning_rate=1e-2, optimize_all_probe_pos=True, all_probe_pos_learning_rate=1e-1)
+    assert np.allclose(out['losses'], f['e2e_losses_64'], rtol=1e-8)
+    assert np.abs(np.stack(out['shift_trace']) - f['e2e_shift_trace_64']).max() < 1e-8
+    assert np.abs(out['obj'] - f['e2e_obj_64']).max() < 2e-6
