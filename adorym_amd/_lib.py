@@ -145,6 +145,10 @@ SIGNATURES = {
     'adm_holo_destroy': (_I, [_VP]),
     'adm_holo_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     'adm_holo_fwd_adj_adam': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(HoloAdam), _VP, _VP]),
+    'adm_holo_data_spectrum': (_I, [_VP, _VP, _VP]),
+    'adm_holo_shift_targets': (_I, [_VP, _VP, _VP, _VP]),
+    'adm_holo_set_registration': (_I, [_VP, _VP, C.c_int]),
+    'adm_holo_shift_grad': (_I, [_VP, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

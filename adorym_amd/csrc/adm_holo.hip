@@ -28,6 +28,9 @@ struct adm_holo {
     float2 *T14, *Ft;         // T14 [nx][ny] x spectra of the rows (K1 -> K2), later [ny][nx] (K4 -> K5); Ft [nx][ny] = FFT2(psi)
     float2 *Wq, *T3;          // [n_dists][ny][nx] / [n_dists][nx][ny] work fields
     float *part3, *part4;     // per-line partial sums: [n_dists][ny][8], [n_dists][nx]
+    float* part_s;            // [n_dists][nx][2]: per-line sums of the shift gradient (adm_holo_shift_grad; allocated on first use)
+    float* cot;               // adm_holo_set_registration: where K3 leaves dL/d(registered hologram sample), or nullptr
+    int direct;               //   ... and whether `data` is taken pixel for pixel (already registered) instead of resampled
 };
 
 // transposed store index (row r of pitch p, column c); -DHOLO_ABL_STORE: timing-only variant that stores along the line instead
@@ -176,6 +179,8 @@ struct HoloArgs {
     float2 *T1, *Ft, *Wq, *T3, *T4;                  // T1 [nx][ny], Ft [nx][ny], Wq [nd][ny][nx], T3 [nd][nx][ny], T4 [ny][nx]
     const float2 *tw_x, *tw_y;
     float *pred, *part3, *part4;                    // part3 [nd][ny][8], part4 [nd][nx]
+    float* cot;                                     // [nd][ny][nx] dL/d(sample of the registered hologram), or nullptr
+    int direct;                                     // data[d][y][x] IS the registered sample (no affine resampling)
     float2 *grad_obj, *grad_probe;
     float *loss_sum, *grad_affine, *grad_dists;
     int ny, nx, nd, real_imag, intensity, want_affine, want_dists, set_obj;
@@ -346,7 +351,8 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
         const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
         const float wx = ix - (float)x0, wy = iy - (float)y0;
         const float v00 = s00[j], v01 = s01[j], v10 = s10[j], v11 = s11[j];
-        const float samp = v00 * (1.f - wx) * (1.f - wy) + v01 * wx * (1.f - wy) + v10 * (1.f - wx) * wy + v11 * wx * wy;
+        const float samp = A.direct ? img[(size_t)y * NX + x]
+                                    : v00 * (1.f - wx) * (1.f - wy) + v01 * wx * (1.f - wy) + v10 * (1.f - wx) * wy + v11 * wx * wy;
         const float as = fabsf(samp);
         const float tgt = A.intensity ? sqrtf(as) : as;
         const float2 ps = cscale(res[x], A.inv_n);                  // Psi_d(y, x): normalised inverse
@@ -359,10 +365,11 @@ template <int NX, bool GRAD> __global__ __launch_bounds__(256) void holo_k3(Holo
         if (GRAD) {
             const float g = (mag > 0.f) ? A.gscale * diff / mag : 0.f;
             oth[x] = cscale(ps, g);                                  // dL/dPsi_d
-            if (A.want_affine && ok) {
+            if ((A.want_affine || A.cot) && ok) {
                 const float sg = (float)((samp > 0.f) - (samp < 0.f));
                 float cot = -A.gscale * diff * (A.intensity ? sg / (2.f * sqrtf(as)) : sg);
                 if (!(fabsf(cot) <= 3.0e38f)) cot = 0.f;             // 0/0 at an exactly zero sample
+                if (A.cot) A.cot[(size_t)d * n + (size_t)y * NX + x] = cot;
                 const float dix = ((v01 - v00) * (1.f - wy) + (v11 - v10) * wy) * mx * (0.5f * (float)NX) * cot;
                 const float diy = ((v10 - v00) * (1.f - wx) + (v11 - v01) * wx) * my * (0.5f * (float)ny) * cot;
                 ga[0] += dix * X; ga[1] += dix * Y; ga[2] += dix;
@@ -566,6 +573,151 @@ template <int NX, bool FUSE> __global__ __launch_bounds__(256) void holo_k5(Holo
 }
 
 #define ADM_HOLO_SIZES(X) X(16) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048)
+// ---------------------------------------------------------------------------------------------------------------
+// Per-distance shift refinement of the measured holograms (optimize_all_probe_pos with multi-distance data,
+// adorym/forward_model.py:1075-1085; demos/2d_multidist_holography_w_position_correction.py): the loss compares with
+//     T_d = Re IFFT2( FFT2(|data_d|) * Phi_d ),   Phi_d(ky, kx) = exp(-2 PI i (fx(kx) s_d[1] + fy(ky) s_d[0]))     (util.py:380-397)
+// instead of data_d.  D^_d = FFT2(|data_d|) does not depend on anything that is optimised: computed once per dataset (SR + SLF<0>),
+// kept transposed [d][kx][ky].  Per minibatch: SLI (lines kx: D^ Phi -> IFFT_y) + SRI (rows: IFFT_x, real part) in front of K1..K5,
+// which then take T_d pixel for pixel (HoloArgs::direct) and leave c = dL/dT_d (HoloArgs::cot); behind them SR + SLF<1>:
+//     dL/ds_d[q] = sum_pixels c dT_d/ds_d[q] = (1/n) Re sum_k conj(FFT2(c))_k D^_k Phi_k (-2 PI i f_q(k)) = (2 PI / n) sum_k f_q(k) Im(conj(C^_k) D^_k Phi_k)
+// per-line sums in fixed order, then one wave per output.  Same line transforms, LDS layout and transposed stores as K1..K5.
+// ---------------------------------------------------------------------------------------------------------------
+struct ShiftArgs {
+    const float* img;          // SR: real rows [nd][ny][nx]
+    int absval;                // SR: take |img| (raw data: forward_model.py:1055) or img as it is (the cotangent)
+    float2* T;                 // SR out / SLF in: [nd][nx][ny]
+    float2* spec_out;          // SLF<0>: [nd][nx][ny]
+    const float2* spec;        // SLI / SLF<1>: D^
+    const float* shifts;       // [nd][2] (sy, sx)
+    float2* W;                 // SLI out / SRI in: [nd][ny][nx]
+    float* out;                // SRI: [nd][ny][nx]
+    float* part;               // SLF<1>: [nd][nx][2]
+    float* grad_shifts;        // [nd][2], accumulated
+    const float2 *tw_x, *tw_y;
+    int ny, nx, nd;
+    float inv_n;
+};
+__device__ __forceinline__ float fft_freq(int k, int n) { return (float)(k < (n + 1) / 2 ? k : k - n) / (float)n; }   // np.fft.fftfreq(n, 1)
+
+// rows (d, y) of a real image -> FFT_x -> T[d][kx][y]
+template <int NX> __global__ __launch_bounds__(256) void holo_sr(ShiftArgs A) {
+    using LG = LineGeo<NX>;
+    __shared__ cf buf[2][LG::LPB * LG::LP];
+    __shared__ float2 twl[TwLds<NX>::SIZE];
+    const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int y0 = blockIdx.x * LG::LPB, y = y0 + ll, d = blockIdx.y;
+    const bool ok = y < A.ny;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    const float* row = A.img + ((size_t)d * A.ny + (ok ? y : 0)) * NX;
+    for (int x = t; x < NX; x += LG::TPR) {
+        const float v = ok ? row[x] : 0.f;
+        a[x] = make_float2(A.absval ? fabsf(v) : v, 0.f);
+    }
+    __syncthreads();
+    const cf* res = line_fft<NX, false>(a, b, tw, t);
+    float2* T = A.T + (size_t)d * NX * A.ny;
+    const int ny = A.ny;
+    store_lines_transposed<NX>(res - ll * LG::LP, min(LG::LPB, ny - y0), [=](int k, int c) { return T + HOLO_TIDX(k, ny, y0 + c, NX); });
+}
+
+// lines (d, kx): FFT_y of T.  MODE 0: the spectrum is stored ([d][kx][ky]); MODE 1: the two sums of the shift gradient
+template <int NY, int MODE> __global__ __launch_bounds__(256) void holo_slf(ShiftArgs A) {
+    using LG = LineGeo<NY>;
+    __shared__ cf buf[2][LG::LPB * LG::LP];
+    __shared__ float red[2][256];
+    __shared__ float2 twl[TwLds<NY>::SIZE];
+    const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int kx0 = blockIdx.x * LG::LPB, kx = kx0 + ll, d = blockIdx.y;
+    const bool ok = kx < A.nx;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    const size_t line = ((size_t)d * A.nx + (ok ? kx : 0)) * NY;
+    for (int j = t; j < NY; j += LG::TPR) a[j] = ok ? A.T[line + j] : make_float2(0.f, 0.f);
+    __syncthreads();
+    const cf* G = line_fft<NY, false>(a, b, tw, t);
+    if (MODE == 0) {
+        if (ok)
+            for (int k = t; k < NY; k += LG::TPR) A.spec_out[line + k] = G[k];
+        return;
+    }
+    const float sy = A.shifts[2 * d], sx = A.shifts[2 * d + 1];
+    const float fx = fft_freq(kx, A.nx);
+    float v[2] = {0.f, 0.f};
+    if (ok) {
+        for (int k = t; k < NY; k += LG::TPR) {
+            const float fy = fft_freq(k, NY);
+            float sn, cs;
+            sincosf(-2.f * 3.14159265359f * (fx * sx + fy * sy), &sn, &cs);
+            const cf c = cmul(cmul(conjf2(G[k]), A.spec[line + k]), make_float2(cs, sn));
+            v[0] += fy * c.y;
+            v[1] += fx * c.y;
+        }
+    }
+    line_sums<LG::TPR, 2>(v, red);
+    if (ok && t == 0) {
+        const float s = 2.f * 3.14159265359f * A.inv_n;
+        A.part[((size_t)d * A.nx + kx) * 2] = s * v[0];
+        A.part[((size_t)d * A.nx + kx) * 2 + 1] = s * v[1];
+    }
+}
+// one wave per output (d, q): the per-line sums in a fixed order
+__global__ __launch_bounds__(64) void holo_shift_sum_kernel(ShiftArgs A) {
+    const int o = blockIdx.x, d = o >> 1, q = o & 1, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int kx = lane; kx < A.nx; kx += 64) acc += A.part[((size_t)d * A.nx + kx) * 2 + q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) A.grad_shifts[o] += acc;
+}
+
+// lines (d, kx): D^ Phi -> IFFT_y -> W[d][y][kx]
+template <int NY> __global__ __launch_bounds__(256) void holo_sli(ShiftArgs A) {
+    using LG = LineGeo<NY>;
+    __shared__ cf buf[2][LG::LPB * LG::LP];
+    __shared__ float2 twl[TwLds<NY>::SIZE];
+    const float2* tw = stage_twiddles<NY>(twl, A.tw_y);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int kx0 = blockIdx.x * LG::LPB, kx = kx0 + ll, d = blockIdx.y;
+    const bool ok = kx < A.nx;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    const size_t line = ((size_t)d * A.nx + (ok ? kx : 0)) * NY;
+    const float sy = A.shifts[2 * d], sx = A.shifts[2 * d + 1];
+    const float fx = fft_freq(kx, A.nx);
+    for (int k = t; k < NY; k += LG::TPR) {
+        float sn, cs;
+        sincosf(-2.f * 3.14159265359f * (fx * sx + fft_freq(k, NY) * sy), &sn, &cs);
+        a[k] = ok ? cmul(A.spec[line + k], make_float2(cs, sn)) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const cf* res = line_fft<NY, true>(a, b, tw, t);
+    float2* W = A.W + (size_t)d * NY * A.nx;
+    const int nx = A.nx;
+    store_lines_transposed<NY>(res - ll * LG::LP, min(LG::LPB, nx - kx0), [=](int y, int c) { return W + HOLO_TIDX(y, nx, kx0 + c, NY); });
+}
+// rows (d, y): IFFT_x / n, real part -> out[d][y][x]
+template <int NX> __global__ __launch_bounds__(256) void holo_sri(ShiftArgs A) {
+    using LG = LineGeo<NX>;
+    __shared__ cf buf[2][LG::LPB * LG::LP];
+    __shared__ float2 twl[TwLds<NX>::SIZE];
+    const float2* tw = stage_twiddles<NX>(twl, A.tw_x);
+    const int ll = threadIdx.x / LG::TPR, t = threadIdx.x % LG::TPR;
+    const int y = blockIdx.x * LG::LPB + ll, d = blockIdx.y;
+    const bool ok = y < A.ny;
+    cf* a = buf[0] + ll * LG::LP;
+    cf* b = buf[1] + ll * LG::LP;
+    const size_t row = ((size_t)d * A.ny + (ok ? y : 0)) * NX;
+    for (int k = t; k < NX; k += LG::TPR) a[k] = ok ? A.W[row + k] : make_float2(0.f, 0.f);
+    __syncthreads();
+    const cf* res = line_fft<NX, true>(a, b, tw, t);
+    if (ok)
+        for (int x = t; x < NX; x += LG::TPR) A.out[row + x] = res[x].x * A.inv_n;
+}
+
 template <int N> static int blocks_for(int lines) { return (lines + LineGeo<N>::LPB - 1) / LineGeo<N>::LPB; }
 
 static hipError_t holo_run(const HoloArgs& A, bool want_grad, hipStream_t st, bool fuse = false) {
@@ -661,7 +813,7 @@ extern "C" int adm_holo_create(adm_ctx* ctx, const adm_holo_desc* desc, adm_holo
 
 extern "C" int adm_holo_destroy(adm_holo* h) {
     if (!h) return ADM_OK;
-    void* bufs[] = {h->tw_y, h->tw_x, h->uv2t, h->T14, h->Ft, h->Wq, h->T3, h->part3, h->part4};
+    void* bufs[] = {h->tw_y, h->tw_x, h->uv2t, h->T14, h->Ft, h->Wq, h->T3, h->part3, h->part4, h->part_s};
     for (void* b : bufs)
         if (b) adm_free(h->ctx, b);
     delete h;
@@ -682,6 +834,8 @@ extern "C" int adm_holo_fwd_adj(adm_holo* h, const float* obj, const float* prob
     A.T1 = h->T14; A.Ft = h->Ft; A.Wq = h->Wq; A.T3 = h->T3; A.T4 = h->T14;
     A.tw_x = h->tw_x; A.tw_y = h->tw_y;
     A.pred = pred; A.part3 = h->part3; A.part4 = h->part4;
+    A.cot = want_grad ? h->cot : nullptr; A.direct = h->direct;
+    if (h->direct && affine) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj: data registered elsewhere (adm_holo_set_registration, direct) excludes affine matrices");
     A.grad_obj = (float2*)grad_obj; A.grad_probe = (float2*)grad_probe;
     A.loss_sum = loss_sum; A.grad_affine = grad_affine; A.grad_dists = grad_dists;
     A.ny = d.ny; A.nx = d.nx; A.nd = d.n_dists; A.real_imag = d.unknown_type; A.intensity = d.raw_intensity;
@@ -712,6 +866,7 @@ extern "C" int adm_holo_fwd_adj_adam(adm_holo* h, float* obj, const float* probe
     A.T1 = h->T14; A.Ft = h->Ft; A.Wq = h->Wq; A.T3 = h->T3; A.T4 = h->T14;
     A.tw_x = h->tw_x; A.tw_y = h->tw_y;
     A.pred = pred; A.part3 = h->part3; A.part4 = h->part4;
+    if (h->cot || h->direct) return fail(ADM_ERR_INVALID, "adm_holo_fwd_adj_adam: not with adm_holo_set_registration (the shift refinement takes the general path)");
     A.loss_sum = loss_sum;
     A.ny = d.ny; A.nx = d.nx; A.nd = d.n_dists; A.real_imag = d.unknown_type; A.intensity = d.raw_intensity;
     A.want_affine = opt->m_affine ? 1 : 0;
@@ -727,5 +882,81 @@ extern "C" int adm_holo_fwd_adj_adam(adm_holo* h, float* obj, const float* probe
     A.adam = adam_scalars(opt->i_batch, opt->step_obj, opt->b1, opt->b2, opt->eps, 0, nullptr);
     A.step_d = (float)opt->step_dists; A.step_a = (float)opt->step_affine;
     ADM_HIP(holo_run(A, true, h->ctx->stream, true));
+    return ADM_OK;
+}
+
+// ---- per-distance shift refinement (kernels holo_sr / holo_slf / holo_sli / holo_sri above) ----
+static void shift_args(const adm_holo* h, ShiftArgs& S) {
+    std::memset(&S, 0, sizeof(S));
+    S.tw_x = h->tw_x; S.tw_y = h->tw_y;
+    S.ny = h->d.ny; S.nx = h->d.nx; S.nd = h->d.n_dists;
+    S.inv_n = (float)(1.0 / ((double)h->d.ny * h->d.nx));
+}
+static hipError_t launch_sr(const ShiftArgs& S, hipStream_t st) {
+#define X(N_) case N_: hipLaunchKernelGGL((holo_sr<N_>), dim3(blocks_for<N_>(S.ny), S.nd), dim3(256), 0, st, S); break;
+    switch (S.nx) { ADM_HOLO_SIZES(X) default: return hipErrorInvalidValue; }
+#undef X
+    return hipGetLastError();
+}
+template <int MODE> static hipError_t launch_slf(const ShiftArgs& S, hipStream_t st) {
+#define X(N_) case N_: hipLaunchKernelGGL((holo_slf<N_, MODE>), dim3(blocks_for<N_>(S.nx), S.nd), dim3(256), 0, st, S); break;
+    switch (S.ny) { ADM_HOLO_SIZES(X) default: return hipErrorInvalidValue; }
+#undef X
+    return hipGetLastError();
+}
+static hipError_t launch_sli(const ShiftArgs& S, hipStream_t st) {
+#define X(N_) case N_: hipLaunchKernelGGL((holo_sli<N_>), dim3(blocks_for<N_>(S.nx), S.nd), dim3(256), 0, st, S); break;
+    switch (S.ny) { ADM_HOLO_SIZES(X) default: return hipErrorInvalidValue; }
+#undef X
+    return hipGetLastError();
+}
+static hipError_t launch_sri(const ShiftArgs& S, hipStream_t st) {
+#define X(N_) case N_: hipLaunchKernelGGL((holo_sri<N_>), dim3(blocks_for<N_>(S.ny), S.nd), dim3(256), 0, st, S); break;
+    switch (S.nx) { ADM_HOLO_SIZES(X) default: return hipErrorInvalidValue; }
+#undef X
+    return hipGetLastError();
+}
+
+extern "C" int adm_holo_set_registration(adm_holo* h, float* cot_out, int direct) {
+    if (!h) return fail(ADM_ERR_INVALID, "adm_holo_set_registration: null handle");
+    h->cot = cot_out;
+    h->direct = direct ? 1 : 0;
+    return ADM_OK;
+}
+
+extern "C" int adm_holo_data_spectrum(adm_holo* h, const float* data, float* spectrum) {
+    if (!h || !data || !spectrum) return fail(ADM_ERR_INVALID, "adm_holo_data_spectrum: null argument");
+    ShiftArgs S;
+    shift_args(h, S);
+    S.img = data; S.absval = 1; S.T = h->T3; S.spec_out = (float2*)spectrum;
+    ADM_HIP(launch_sr(S, h->ctx->stream));
+    ADM_HIP(launch_slf<0>(S, h->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_holo_shift_targets(adm_holo* h, const float* spectrum, const float* shifts, float* targets) {
+    if (!h || !spectrum || !shifts || !targets) return fail(ADM_ERR_INVALID, "adm_holo_shift_targets: null argument");
+    ShiftArgs S;
+    shift_args(h, S);
+    S.spec = (const float2*)spectrum; S.shifts = shifts; S.W = h->Wq; S.out = targets;
+    ADM_HIP(launch_sli(S, h->ctx->stream));
+    ADM_HIP(launch_sri(S, h->ctx->stream));
+    return ADM_OK;
+}
+
+extern "C" int adm_holo_shift_grad(adm_holo* h, const float* cot, const float* spectrum, const float* shifts, float* grad_shifts) {
+    if (!h || !cot || !spectrum || !shifts || !grad_shifts) return fail(ADM_ERR_INVALID, "adm_holo_shift_grad: null argument");
+    if (!h->part_s) {
+        int rc = adm_malloc(h->ctx, (size_t)h->d.n_dists * h->d.nx * 2 * sizeof(float), (void**)&h->part_s);
+        if (rc) return rc;
+    }
+    ShiftArgs S;
+    shift_args(h, S);
+    S.img = cot; S.absval = 0; S.T = h->T3; S.spec = (const float2*)spectrum; S.shifts = shifts; S.part = h->part_s;
+    S.grad_shifts = grad_shifts;
+    ADM_HIP(launch_sr(S, h->ctx->stream));
+    ADM_HIP(launch_slf<1>(S, h->ctx->stream));
+    hipLaunchKernelGGL(holo_shift_sum_kernel, dim3(S.nd * 2), dim3(64), 0, h->ctx->stream, S);
+    ADM_HIP(hipGetLastError());
     return ADM_OK;
 }

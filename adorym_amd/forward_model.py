@@ -572,10 +572,17 @@ class MultiDistModel(PtychographyModel):
 
     def _check(self, safe_zone_width, ctf_lg_kappa, probe_pos_correction):
         cv = self.common_vars
-        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset', 'optimize_all_probe_pos',
-                     'optimize_ctf_lg_kappa'):
+        for flag in ('optimize_probe_defocusing', 'optimize_probe_pos_offset', 'optimize_prj_pos_offset', 'optimize_ctf_lg_kappa'):
             if cv.get(flag):
                 raise NotImplementedError('%s with MultiDistModel is outside the accelerated path' % flag)
+        if cv.get('optimize_all_probe_pos'):
+            # one (sy, sx) per distance applied to the measured holograms (forward_model.py:1075-1085)
+            if cv.get('optimize_prj_affine'):
+                raise NotImplementedError('optimize_all_probe_pos together with optimize_prj_affine is outside the accelerated path')
+            if self.tile_engine is not None:
+                raise NotImplementedError('optimize_all_probe_pos with multi-distance data divided into sub-tiles is outside the accelerated path')
+            if probe_pos_correction is None:
+                raise ValueError('optimize_all_probe_pos needs probe_pos_correction [n_dists, 2]')
         if not cv.get('two_d_mode'):
             raise NotImplementedError('MultiDistModel is accelerated for two_d_mode (one object slice) only')
         if self.tile_engine is not None:
@@ -726,11 +733,28 @@ class MultiDistModel(PtychographyModel):
             self._data_key = key
         return self._data_dev
 
+    def _spectrum(self, this_i_theta):
+        """FFT2(|data_d|) of this angle's holograms, kept on the device beside them (the shift refinement multiplies it with a
+        phase ramp per distance and minibatch)."""
+        data = self._data(this_i_theta)
+        if getattr(self, '_spec_key', None) != self._data_key:
+            self._spec_dev = self.holo.data_spectrum(data)
+            self._spec_key = self._data_key
+        return self._spec_dev
+
     def _run(self, obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad, grad_obj=None, grads=None,
-             want_pred=False, overwrite=False):
+             want_pred=False, overwrite=False, probe_pos_correction=None):
         nd = self.holo.n_dists
         probe = self._probe(probe_real, probe_imag)          # [1, ny, nx, 2]
         dists = self._dev('free_prop_cm', free_prop_cm, (nd,))
+        if self.common_vars.get('optimize_all_probe_pos'):   # forward_model.py:1075-1085
+            g = grads or {}
+            if g.get('dists') is not None:
+                raise NotImplementedError('optimize_all_probe_pos together with optimize_free_prop is outside the accelerated path')
+            shifts = self._dev('probe_pos_correction', probe_pos_correction, (nd, 2))
+            self.holo.forward_adjoint_shifted(obj, probe, dists, self._spectrum(this_i_theta), shifts, want_grad=want_grad, grad_obj=grad_obj,
+                                              grad_probe=g.get('probe'), grad_shifts=g.get('shifts'), want_pred=want_pred, overwrite=overwrite)
+            return
         aff = None
         if self.common_vars.get('optimize_prj_affine'):      # forward_model.py:1063-1070
             aff = self._dev('prj_affine_ls', prj_affine_ls, (nd, 2, 3))
@@ -746,7 +770,8 @@ class MultiDistModel(PtychographyModel):
         self.i_call += 1
         if self.tile_engine is not None:
             return self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False, want_pred=True)
-        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True)
+        self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False, want_pred=True,
+                  probe_pos_correction=probe_pos_correction)
         return self.holo.pred()
 
     def get_loss_function(self):
@@ -758,7 +783,8 @@ class MultiDistModel(PtychographyModel):
                 datav = self._run_tiled(obj, probe_real, probe_imag, this_i_theta, this_pos_batch, this_ind_batch, want_grad=False)
                 self.current_loss = float(datav() + self._regularize(obj, None))
                 return self.current_loss
-            self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False)
+            self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=False,
+                      probe_pos_correction=probe_pos_correction)
             self.current_loss = float(self.holo.loss() + self._regularize(obj, None))
             return self.current_loss
         calculate_loss.forward_model = self
@@ -802,7 +828,7 @@ class MultiDistModel(PtychographyModel):
         # _init_grad: the object-gradient buffer holds garbage -> the engine overwrites every gradient ('=' instead of '+=': no
         # zero fills on a path that is bound by the number of launches); otherwise it accumulates into zeroed small buffers
         nd = self.holo.n_dists
-        idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls')}
+        idx = {n: self.get_argument_index(n) for n in ('probe_real', 'probe_imag', 'free_prop_cm', 'prj_affine_ls', 'probe_pos_correction')}
         grads = {}
         if idx['probe_real'] in opt_args_ls or idx['probe_imag'] in opt_args_ls:
             probe = self._probe(probe_real, probe_imag)
@@ -817,8 +843,12 @@ class MultiDistModel(PtychographyModel):
             if getattr(self, '_ga', None) is None:
                 self._ga = self.device.empty((nd, 2, 3))
             grads['affine'] = self._ga if _init_grad else self._ga.zero_()
+        if idx['probe_pos_correction'] in opt_args_ls:
+            if getattr(self, '_gs', None) is None:
+                self._gs = self.device.empty((nd, 2))
+            grads['shifts'] = self._gs.zero_()           # (adm_holo_shift_grad accumulates)
         self._run(obj, probe_real, probe_imag, this_i_theta, free_prop_cm, prj_affine_ls, want_grad=True, grad_obj=grad_obj, grads=grads,
-                  overwrite=bool(_init_grad))
+                  overwrite=bool(_init_grad), probe_pos_correction=probe_pos_correction)
         # loss and regulariser value are read back lazily (the driver looks at them after the next minibatch has been queued)
         regv = self._reg_value_async(self._regularize_launch(obj, grad_obj))
         datav = self.holo.loss_async()
@@ -833,6 +863,8 @@ class MultiDistModel(PtychographyModel):
                 out.append(grads['dists'])
             elif i == idx['prj_affine_ls']:
                 out.append(grads['affine'])
+            elif i == idx['probe_pos_correction']:
+                out.append(grads['shifts'])
             else:
                 raise NotImplementedError("gradient w.r.t. '%s' is outside the accelerated path" % self.argument_ls[i])
         return tuple(out)

@@ -74,6 +74,37 @@ class HolographyEngine(object):
         check(self.ctx.lib.adm_holo_fwd_adj_adam(self.handle, obj.ptr, probe.ptr, dists_cm.ptr, p(affine), data.ptr, C.byref(o),
                                                  self._pred.ptr if want_pred else None, self._pinned[self._slot].handle))
 
+    # ---- per-distance shift refinement of the measured holograms (optimize_all_probe_pos, adorym/forward_model.py:1075-1085) ----
+    def data_spectrum(self, data):
+        """FFT2(|data_d|) of the raw holograms [n_dists, ny, nx] (DeviceArray), transposed ([d][kx][ky]); once per dataset."""
+        spec = DeviceArray(self.ctx, (self.n_dists, self.nx, self.ny, 2), np.float32)
+        check(self.ctx.lib.adm_holo_data_spectrum(self.handle, data.ptr, spec.ptr))
+        return spec
+
+    def forward_adjoint_shifted(self, obj, probe, dists_cm, spectrum, shifts, want_grad=True, grad_obj=None, grad_probe=None,
+                                grad_shifts=None, want_pred=False, overwrite=False):
+        """forward_adjoint() against the holograms Fourier-shifted by ``shifts`` [n_dists, 2] = (sy, sx) (realign_image_fourier, real
+        part kept): the registered targets are formed from ``spectrum`` (data_spectrum) in front of the launch group and, with
+        ``grad_shifts`` (+=), dL/dshifts behind it."""
+        if getattr(self, '_targets', None) is None:
+            self._targets = DeviceArray(self.ctx, (self.n_dists, self.ny, self.nx), np.float32)
+            self._cot = DeviceArray(self.ctx, (self.n_dists, self.ny, self.nx), np.float32)
+        lib = self.ctx.lib
+        check(lib.adm_holo_shift_targets(self.handle, spectrum.ptr, shifts.ptr, self._targets.ptr))
+        want_sg = want_grad and grad_shifts is not None
+        check(lib.adm_holo_set_registration(self.handle, self._cot.ptr if want_sg else None, 1))
+        try:
+            self.forward_adjoint(obj, probe, dists_cm, self._targets, want_grad=want_grad, grad_obj=grad_obj, grad_probe=grad_probe,
+                                 want_pred=want_pred, overwrite=overwrite)
+        finally:
+            check(lib.adm_holo_set_registration(self.handle, None, 0))
+        if want_sg:
+            check(lib.adm_holo_shift_grad(self.handle, self._cot.ptr, spectrum.ptr, shifts.ptr, grad_shifts.ptr))
+
+    def shifted_targets(self):
+        """The registered holograms T_d of the last forward_adjoint_shifted() (host copy; tests)."""
+        return self._targets.get()
+
     def loss(self):
         """mean over (distance, pixel) of the squared residual of the last launch -- blocks."""
         return self.loss_async()()

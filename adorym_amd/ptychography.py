@@ -391,14 +391,13 @@ def reconstruct_ptychography(
         _not_implemented(not two_d_mode, 'multi-distance holography of a 3-D object')
         _not_implemented(n_probe_modes != 1, 'several probe modes with multi-distance data')
         _not_implemented(loss_function_type != 'lsq', 'Poisson loss with multi-distance data')
-        _not_implemented(optimize_all_probe_pos, 'optimize_all_probe_pos with multi-distance data')
         holo_tiled = len(probe_pos) > 1 or safe_zone_width > 0
         if holo_tiled:
             # data divided into sub-tiles and / or a safe zone around every tile (adorym/forward_model.py:884-1034)
             tile_size = [int(v) + 2 * safe_zone_width for v in prj.shape[-2:]]
             _not_implemented(max(tile_size) > 128, 'sub-hologram + 2 safe zones larger than 128 pixels (%d x %d)' % tuple(tile_size))
-            _not_implemented(optimize_free_prop or optimize_prj_affine or optimize_probe,
-                             'optimize_free_prop / optimize_prj_affine / optimize_probe with multi-distance data divided into sub-tiles')
+            _not_implemented(optimize_free_prop or optimize_prj_affine or optimize_probe or optimize_all_probe_pos,
+                             'optimize_free_prop / optimize_prj_affine / optimize_probe / optimize_all_probe_pos with multi-distance data divided into sub-tiles')
             _not_implemented(beamstop is not None, 'a beamstop with multi-distance data divided into sub-tiles')
             pp_ = np.round(np.asarray(probe_pos)).astype(int)
             if safe_zone_width == 0:
@@ -411,6 +410,9 @@ def reconstruct_ptychography(
                 _not_implemented(mb_ % n_dp_batch == 1, 'a minibatch whose last n_dp_batch chunk holds a single tile')
         else:
             _not_implemented(list(prj.shape[-2:]) != list(obj_size[:2]), 'holograms whose size differs from the object size')
+            # one (sy, sx) per distance on the measured holograms (forward_model.py:1075-1085): beside the object and the probe only
+            _not_implemented(optimize_all_probe_pos and (optimize_free_prop or optimize_prj_affine),
+                             'optimize_all_probe_pos together with optimize_free_prop / optimize_prj_affine')
         probe_size = [int(v) for v in obj_size[:2]]          # subdiv_probe (ptychography.py:312-314)
     else:
         _not_implemented(optimize_free_prop or optimize_prj_affine, 'optimize_free_prop / optimize_prj_affine without multi-distance data')

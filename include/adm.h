@@ -479,6 +479,21 @@ typedef struct adm_holo_adam {
 } adm_holo_adam;
 int adm_holo_fwd_adj_adam(adm_holo* h, float* obj, const float* probe, float* dists_cm, float* affine, const float* data,
                           const adm_holo_adam* opt, float* pred, float* loss_sum);
+/* Per-distance shift refinement of the measured holograms: `optimize_all_probe_pos` with multi-distance data,
+ * adorym/forward_model.py:1075-1085 (demos/2d_multidist_holography_w_position_correction.py) -- the loss compares with
+ *     T_d = Re IFFT2( FFT2(|data_d|) * exp(-2 PI i (fx s_d[1] + fy s_d[0])) )        (realign_image_fourier, util.py:380-397)
+ * and torch.autograd.grad returns dL/ds_d.  Device pointers throughout.
+ *   adm_holo_data_spectrum   spectrum [n_dists][nx][ny][2] <- FFT2(|data_d|), transposed ([kx][ky]); once per dataset.
+ *   adm_holo_shift_targets   targets [n_dists][ny][nx] <- T_d for shifts [n_dists][2] = (sy, sx).
+ *   adm_holo_set_registration(h, cot_out, direct): from now on adm_holo_fwd_adj takes `data` pixel for pixel when direct != 0
+ *                            (it holds T_d; no affine matrices then) and, with want_grad, leaves c = dL/dT_d in cot_out
+ *                            [n_dists][ny][nx] (NULL: not wanted).  (NULL, 0) restores the default.
+ *   adm_holo_shift_grad      grad_shifts [n_dists][2] += sum_pixels c dT_d/ds_d.
+ * The work fields of the handle are shared with adm_holo_fwd_adj: the calls of one minibatch follow each other on the stream. */
+int adm_holo_data_spectrum(adm_holo* h, const float* data, float* spectrum);
+int adm_holo_shift_targets(adm_holo* h, const float* spectrum, const float* shifts, float* targets);
+int adm_holo_set_registration(adm_holo* h, float* cot_out, int direct);
+int adm_holo_shift_grad(adm_holo* h, const float* cot, const float* spectrum, const float* shifts, float* grad_shifts);
 
 /* y[i] += a * x[i]  (gradient accumulation, adorym/ptychography.py:1063-1066) */
 int adm_axpy(adm_ctx* ctx, float* y, const float* x, float a, size_t n);

@@ -653,3 +653,93 @@ def test_config5_driver_fused_update_equals_separate_update_bitwise(A, ctx, tmp_
     for k in ('delta', 'beta', 'free_prop_cm', 'prj_affine_ls'):
         assert np.array_equal(a[k], b[k]), k
     assert np.abs(b['free_prop_cm'] - np.array(inp['dists_guess'])).max() > 1e-3
+
+
+# ------------------------------------------------------------------------------------ f1 row: per-distance shift refinement
+def test_shifted_holograms_gradients_vs_reference(A, ctx):
+    """optimize_all_probe_pos with multi-distance data (adorym/forward_model.py:1075-1085): the registered targets
+    Re IFFT2(FFT2(|data|) Phi(shift)), the loss and the gradients w.r.t. the object and the per-distance shifts against the
+    reference's autograd (golden F19) under the 3x rule."""
+    from adorym_amd.holography import HolographyEngine
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F19_multidist_shifts.npz'))
+    Cc = cases.C5MINI
+    N = Cc['N']
+    eng = HolographyEngine(ctx, (N, N), 3, Cc['energy_ev'], Cc['psize_cm'])
+    obj = ctx.array(f['guess'].astype(np.float32))
+    probe = ctx.array(np.stack([np.ones((N, N)), np.zeros((N, N))], -1).astype(np.float32))
+    dists = ctx.array(np.array(Cc['dists_cm'], np.float32))
+    shifts = ctx.array(f['shift_guess'].astype(np.float32))
+    spec = eng.data_spectrum(ctx.array(f['data'].astype(np.float32)))
+    want = np.fft.fft2(np.abs(f['data'].astype(np.float64)))                       # [d][ky][kx]
+    got = spec.get()
+    got = (got[..., 0] + 1j * got[..., 1]).transpose(0, 2, 1)
+    assert np.linalg.norm(got - want) < 2e-6 * np.linalg.norm(want)
+    g_obj, g_sh = ctx.zeros(obj.shape), ctx.zeros((3, 2))
+    eng.forward_adjoint_shifted(obj, probe, dists, spec, shifts, grad_obj=g_obj, grad_shifts=g_sh, want_pred=True)
+    t64 = f['target_64']
+    assert np.linalg.norm(eng.shifted_targets() - t64) < max(2e-6, 3 * np.linalg.norm(f['target_32'] - t64) / np.linalg.norm(t64)) * np.linalg.norm(t64)
+    assert abs(eng.loss() - f['loss_64']) < 2e-5 * abs(f['loss_64'])
+    assert np.linalg.norm(eng.pred() - f['pred_64']) < 2e-6 * np.linalg.norm(f['pred_64'])
+    for mine, key in ((g_obj.get(), 'grad_obj'), (g_sh.get(), 'grad_shifts')):
+        r64, r32 = f[key + '_64'], f[key + '_32']
+        err = np.linalg.norm(mine - r64) / np.linalg.norm(r64)
+        err_ref = np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        print('%s: %.2e (reference fp32: %.2e)' % (key, err, err_ref))
+        assert err < max(1e-4, 3 * err_ref), (key, err, err_ref)
+    # forward only: same loss, nothing written
+    eng.forward_adjoint_shifted(obj, probe, dists, spec, shifts, want_grad=False)
+    assert abs(eng.loss() - f['loss_64']) < 2e-5 * abs(f['loss_64'])
+
+
+@pytest.mark.parametrize('shape', [(16, 64), (128, 32), (256, 256)])
+def test_shifted_holograms_vs_oracle_at_other_sizes(A, ctx, shape):
+    """The shift stage at non-square fields and other line lengths (lines-per-block geometries of the transforms)."""
+    from adorym_amd.holography import HolographyEngine
+    ny, nx = shape
+    r = cases.rng(1900 + ny + nx)
+    nd = 2
+    dists = np.array([35., 70.])
+    o = (1 + 0.1 * r.standard_normal((ny, nx))) * np.exp(1j * 0.2 * r.standard_normal((ny, nx)))
+    obj_h = np.stack([o.real, o.imag], -1)[:, :, None, :]
+    data = (1 + 0.2 * r.standard_normal((nd, ny, nx))) ** 2
+    sh = r.uniform(-1.5, 1.5, (nd, 2))
+    eng = HolographyEngine(ctx, (ny, nx), nd, 17050., 1e-4)
+    obj = ctx.array(obj_h.astype(np.float32))
+    probe = ctx.array(np.stack([np.ones((ny, nx)), np.zeros((ny, nx))], -1).astype(np.float32))
+    spec = eng.data_spectrum(ctx.array(data.astype(np.float32)))
+    g_obj, g_sh = ctx.zeros(obj.shape), ctx.zeros((nd, 2))
+    eng.forward_adjoint_shifted(obj, probe, ctx.array(dists.astype(np.float32)), spec, ctx.array(sh.astype(np.float32)), grad_obj=g_obj, grad_shifts=g_sh)
+    ident = np.tile(np.array([[1., 0, 0], [0, 1., 0]]), [nd, 1, 1])
+    res = O.holo_forward_adjoint(obj_h, np.ones((ny, nx), complex), dists, ident, data.astype(np.float32).astype(np.float64), 17050., 1e-4, shifts=sh)
+    assert abs(eng.loss() - res[0]) < 2e-5 * abs(res[0])
+    assert np.linalg.norm(np.sqrt(np.abs(eng.shifted_targets())) - res[2]) < 1e-5 * np.linalg.norm(res[2])
+    assert np.linalg.norm(g_obj.get() - res[3]) < 1e-4 * np.linalg.norm(res[3])
+    assert np.linalg.norm(g_sh.get() - res[7]) < 2e-4 * np.linalg.norm(res[7]), (g_sh.get(), res[7])
+
+
+def test_shift_refinement_driver_vs_reference(A, ctx, tmp_path):
+    """demos/2d_multidist_holography_w_position_correction.py at a small size through reconstruct_ptychography against the REFERENCE
+    driver's own run (golden F19): the object and one (sy, sx) per distance refined together, the corrections re-centred after
+    every update (optimizers.py:1039-1049)."""
+    f = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'F19_multidist_shifts.npz'))
+    Cc = cases.C5MINI
+    inp = cases.c5mini_inputs()
+    N = Cc['N']
+    st = A.reconstruct_ptychography(
+        fname=f['data'][None], obj_size=(N, N, 1), probe_pos=np.array([[0., 0.]]), theta_st=0, theta_end=0, n_theta=1, two_d_mode=True,
+        energy_ev=Cc['energy_ev'], psize_cm=Cc['psize_cm'], free_prop_cm=np.array(Cc['dists_cm']), minibatch_size=1, n_epochs=5,
+        initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='plane', raw_data_type='intensity', unknown_type='real_imag',
+        gamma=0, alpha_d=0, alpha_b=0, optimizer='adam', learning_rate=1e-2, optimize_all_probe_pos=True, all_probe_pos_learning_rate=1e-1,
+        n_dp_batch=1, randomize_probe_pos=True, safe_zone_width=0, save_path=str(tmp_path), output_folder='sh', store_checkpoint=False,
+        use_checkpoint=False, return_state=True)
+    l64, l32 = f['e2e_losses_64'], f['e2e_losses_32']
+    assert np.all(np.abs(np.array(st['losses']) - l64) <= np.maximum(2e-4 * np.abs(l64), 3 * np.abs(l32 - l64))), (st['losses'], l64)
+    s64, s32 = f['e2e_shifts_64'], f['e2e_shifts_32']
+    print('shifts', st['probe_pos_correction'], 'reference', s64)
+    assert np.abs(st['probe_pos_correction'] - s64).max() < max(2e-3, 3 * np.abs(s32 - s64).max())
+    assert abs(st['probe_pos_correction'].mean(axis=0)).max() < 1e-6          # re-centred
+    x = np.stack([st['delta'], st['beta']], -1)
+    g0 = inp['guess'][0] * np.exp(1j * inp['guess'][1])
+    upd = np.linalg.norm(f['e2e_obj_64'] - np.stack([g0.real, g0.imag], -1))
+    e, e_ref = np.linalg.norm(x - f['e2e_obj_64']) / upd, np.linalg.norm(f['e2e_obj_32'] - f['e2e_obj_64']) / upd
+    assert e < max(5e-3, 3 * e_ref), (e, e_ref)

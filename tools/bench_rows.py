@@ -285,6 +285,27 @@ def bench_c5(ctx, steps=50):
     dt_sep, _ = loop()
     fused[0] = True
     dt, t_issue = loop()
+    # the other demo of this row (demos/2d_multidist_holography_w_position_correction.py): one (sy, sx) per distance refined with the
+    # object -- registered targets in front of the launch group, shift gradient behind it, one small-parameter launch
+    spec = eng.data_spectrum(data)
+    sh, gs = ctx.zeros((nd, 2)), ctx.zeros((nd, 2))
+    o_s = AdamOptimizer('probe_pos_correction', options_dict={'step_size': 1e-1}); o_s.create_param_arrays([nd, 2], device=ctx)
+
+    def step_shift():
+        eng.forward_adjoint_shifted(obj, probe, dists, spec, sh, grad_obj=g, grad_shifts=gs, overwrite=True)
+        apply_small_params(ctx, [dict(opt=o_obj, x=obj_flat, g=g_flat), dict(opt=o_s, x=sh, g=gs, center_cols=2, zero_grad=True)], 0)
+        tok = eng.loss_async()
+        out = pending[0]() if pending[0] is not None else None
+        pending[0] = tok
+        return out
+    for _ in range(3):
+        step_shift()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_shift()
+    ctx.sync()
+    dt_shift = (time.perf_counter() - t0) / steps
     timed[0] = True
     ks = []
     for _ in range(10):
@@ -307,6 +328,7 @@ def bench_c5(ctx, steps=50):
             'value': 1.0 / dt, 'unit': 'minibatches/s (4 holograms each)', 'ms_per_step': 1e3 * dt, 'host_issue_ms_per_step': 1e3 * t_issue,
             'update': 'Adam of object, distances and affine matrices inside the last kernel of the launch group (adm_holo_fwd_adj_adam)',
             'ms_per_step_with_a_separate_adam_launch': 1e3 * dt_sep,
+            'ms_per_step_with_shift_refinement': 1e3 * dt_shift,
             'cpu_baseline': {'value': 1.0 / tc, 'unit': 'minibatches/s', 'cores': 1, 'kind': 'port',
                              'sample': 'one fwd+adjoint of the 4-distance chain, oracle fp32 (optimiser excluded)'}}
 
