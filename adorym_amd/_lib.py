@@ -130,6 +130,7 @@ SIGNATURES = {
     'adm_tile_grad_accumulate': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP]),
     'adm_tile_grad_accumulate_part': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _VP, _I, _I, _I]),
     'adm_tile_cover_build': (_I, [_VP, _VP, _SZ, _VP, _I, _VP, _I, _I, _I]),
+    'adm_tile_grad_accumulate_range': (_I, [_VP, _VP, C.c_size_t, _VP, _I, _VP, _VP, _I, _I, _I]),
     'adm_tile_grad_status': (_I, [_VP, _VP, _SZ, _I, C.POINTER(_I)]),
     'adm_reg_grad': (_I, [_VP, _VP, _F, _F, _F, _VP, _VP]),
     'adm_reg_grad_range': (_I, [_VP, _VP, _F, _F, _F, _VP, _SZ, _SZ, _SZ, _SZ]),

@@ -482,7 +482,9 @@ struct TileGeom {
     int add_lo, add_hi;   // padded rows [add_lo, add_hi) already hold an earlier part of the same batch: accumulate there
 };
 
-__global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict__ pos, int B, TileGeom g,
+// positions [b0, B) of the batch enter the lists (b0 > 0: one pass of a batch whose coverage exceeds ADM_MAXCOVER, see
+// adm_tile_grad_accumulate_range)
+__global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict__ pos, int b0, int B, TileGeom g,
                                                           unsigned* __restrict__ cover, int* __restrict__ overflow) {
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict
     unsigned* out = cover + (size_t)r * g.Xp + x;
     int cnt = 0;
     const unsigned per_pos = (unsigned)g.n_steps * g.row_elems;
-    for (int b = 0; b < B; ++b) {
+    for (int b = b0; b < B; ++b) {
         const int2 p = pos[b];
         const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
         if (row >= 0 && row < g.Py && col >= 0 && col < g.Px) {
@@ -1324,15 +1326,16 @@ static bool cover_key_take(adm_plan* plan, const void* ws, const void* pos, cons
     return false;
 }
 
-static int cover_build(adm_plan* plan, void* workspace, const int32_t* pos, int batch, const TileGeom& g) {
+static int cover_build(adm_plan* plan, void* workspace, const int32_t* pos, int batch, const TileGeom& g, int b_lo = 0, int b_hi = -1) {
+    if (b_hi < 0) b_hi = batch;
     char* ws = (char*)workspace;
     unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
     int* overflow = (int*)(cover + (size_t)g.Yp * g.Xp * (ADM_MAXCOVER + 1));
     hipStream_t st = plan->ctx->stream;
     // (a batch of at most ADM_MAXCOVER positions cannot overflow a cover list: no flag to reset, one launch less per minibatch)
-    if (batch > ADM_MAXCOVER) ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    if (b_hi - b_lo > ADM_MAXCOVER) ADM_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
-    hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, batch, g, cover, overflow);
+    hipLaunchKernelGGL(cover_build_kernel, grid, dim3(256), 0, st, (const int2*)pos, b_lo, b_hi, g, cover, overflow);
     ADM_HIP(hipGetLastError());
     return ADM_OK;
 }
@@ -1374,6 +1377,34 @@ extern "C" int adm_tile_grad_accumulate_part(adm_plan* plan, void* workspace, si
     hipStream_t st = plan->ctx->stream;
     dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
     const unsigned nz8 = ((plan->n_steps + TA_STEPS - 1) / TA_STEPS + 7) / 8;      // step chunks per XCD
+    hipLaunchKernelGGL(tile_accumulate_kernel, dim3(8u * nz8 * grid.x * grid.y), dim3(256), 0, st, gtile, (const unsigned*)cover,
+                       (float2*)grad_rot, g);
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
+// A batch in which a pixel is covered by more than ADM_MAXCOVER tiles (dense 2-D scans taken as ONE minibatch,
+// demos/2d_ptychography_w_probe_optimization.py: 2704 positions 5 pixels apart under a 72 x 72 probe): the overlap-add runs in
+// passes over position ranges [b_lo, b_hi) of at most ADM_MAXCOVER positions each -- a range cannot overflow a list --, the first
+// writing the batch's rows, the others adding to them.  Sums in position order, deterministic like the one-pass form.
+extern "C" int adm_tile_grad_accumulate_range(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                             const int32_t* pos_host, float* grad_rot, int b_lo, int b_hi, int add) {
+    if (!plan || !workspace || !pos || !pos_host || !grad_rot) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: null argument");
+    if (batch <= 0 || b_lo < 0 || b_hi <= b_lo || b_hi > batch) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: bad range");
+    if (b_hi - b_lo > ADM_MAXCOVER) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: at most 64 positions per pass");
+    if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: workspace too small");
+    TileGeom g;
+    int rc = tile_geom(plan, batch, pos_host, 0, 0, add, g);       // the window of the WHOLE batch; add: accumulate in all of it
+    if (rc) return rc;
+    (void)cover_key_take(plan, workspace, pos, pos_host, batch, g);  // lists built ahead for the one-pass form are void now
+    rc = cover_build(plan, workspace, pos, batch, g, b_lo, b_hi);
+    if (rc) return rc;
+    char* ws = (char*)workspace;
+    const float2* gtile = (const float2*)(ws + ws_off_gtile(plan, batch));
+    unsigned* cover = (unsigned*)(ws + ws_off_cover(plan, batch));
+    hipStream_t st = plan->ctx->stream;
+    dim3 grid((g.Xp + 31) / 32, (g.nrows + 7) / 8, 1);
+    const unsigned nz8 = ((plan->n_steps + TA_STEPS - 1) / TA_STEPS + 7) / 8;
     hipLaunchKernelGGL(tile_accumulate_kernel, dim3(8u * nz8 * grid.x * grid.y), dim3(256), 0, st, gtile, (const unsigned*)cover,
                        (float2*)grad_rot, g);
     ADM_HIP(hipGetLastError());

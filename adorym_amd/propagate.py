@@ -361,11 +361,11 @@ class MultisliceEngine(object):
     MAX_COVER = 64        # ADM_MAXCOVER of adm_object.hip: cover-list entries per rotated-frame pixel
 
     def _check_cover(self, pos):
-        """The overlap-add keeps at most MAX_COVER tiles per pixel; more would silently drop gradient contributions.
-        Checked on the host BEFORE the launch (a batch of <= MAX_COVER positions cannot overflow), cached per position set,
-        so the asynchronous driver path is covered too, not only the blocking loss()."""
+        """How many tiles of ``pos`` cover the most-covered pixel (an upper bound of len(pos) is returned for small batches).  The
+        overlap-add's lists keep at most MAX_COVER tiles per pixel: a batch beyond that takes the multi-pass form
+        (accumulate_tiles).  Evaluated on the host BEFORE the launch, cached per position set."""
         if len(pos) <= self.MAX_COVER:
-            return
+            return len(pos)
         import collections
         key = pos.tobytes()
         cache = self.__dict__.setdefault('_cover_ok', collections.OrderedDict())
@@ -383,25 +383,33 @@ class MultisliceEngine(object):
             np.add.at(d, (y0, x0 + Px), -1)
             np.add.at(d, (y0 + Py, x0 + Px), 1)
             cache[key] = int(d.cumsum(0).cumsum(1).max())
-        if cache[key] > self.MAX_COVER:
-            raise RuntimeError('tile overlap-add: a pixel is covered by %d tiles of this launch (limit %d); use a smaller '
-                               'minibatch_size' % (cache[key], self.MAX_COVER))
+        return cache[key]
 
     def build_cover(self):
         """Queue the cover lists of the overlap-add of the batch given to set_batch() NOW (they depend on the positions only):
         called inside Context.fork()/end_fork(), they are built beside the multislice launch and accumulate_tiles() -- after
         Context.join() -- skips its own build: one launch and one dependency gap less behind the kernel."""
-        self._check_cover(self._pos_host)
+        if self._check_cover(self._pos_host) > self.MAX_COVER:
+            return                  # (the multi-pass overlap-add builds a list per pass)
         check(self.ctx.lib.adm_tile_cover_build(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
                                                 self._pos_host.ctypes.data, 0, 0, 0))
 
     def accumulate_tiles(self):
-        """Overlap-add the per-position tile gradients into the batch's rows of grad_rot."""
-        self._check_cover(self._pos_host)
-        check(self.ctx.lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, self._B,
-                                                    self._pos_host.ctypes.data, self.grad_rot.ptr))
+        """Overlap-add the per-position tile gradients into the batch's rows of grad_rot.  A batch in which some pixel is covered
+        by more than MAX_COVER tiles (a dense 2-D scan taken as one minibatch) is added in passes of MAX_COVER positions each."""
+        lib, B = self.ctx.lib, self._B
+        if self._check_cover(self._pos_host) > self.MAX_COVER:
+            for k, lo in enumerate(range(0, B, self.MAX_COVER)):
+                check(lib.adm_tile_grad_accumulate_range(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, B,
+                                                         self._pos_host.ctypes.data, self.grad_rot.ptr, lo, min(lo + self.MAX_COVER, B),
+                                                         1 if k else 0))
+            self._accumulated = True
+            self._acc_parts = []            # (a pass of <= MAX_COVER positions cannot overflow a list: nothing to check)
+            return
+        check(lib.adm_tile_grad_accumulate(self.plan.handle, self._ws.ptr, self._ws.nbytes, self._cur_pos.ptr, B,
+                                           self._pos_host.ctypes.data, self.grad_rot.ptr))
         self._accumulated = True
-        self._acc_parts = [(self._ws, self._B)]
+        self._acc_parts = [(self._ws, B)]
 
     N_CU = 256        # MI355X compute units = multislice workgroups resident at once
 
@@ -411,7 +419,8 @@ class MultisliceEngine(object):
         i runs on the side stream BESIDE the launch of round i+1 -- in particular beside a short last round that leaves most
         CUs idle.  Same sums as one launch + one overlap-add, up to the order of the additions per pixel."""
         B = self._B
-        if B <= self.N_CU:
+        if B <= self.N_CU or self._check_cover(self._pos_host) > self.MAX_COVER:
+            # (a batch denser than the cover lists hold is one launch followed by the multi-pass overlap-add)
             self.multislice(probe, grad_probe=grad_probe, want_grad=True, want_pred=want_pred, grad_scale=grad_scale)
             self.ctx.join()                   # side-stream work the caller queued before the launch (no-op if none)
             return
@@ -435,8 +444,7 @@ class MultisliceEngine(object):
         y_lo = int(self._pos_host[:, 0].min())
         y_hi = int(self._pos_host[:, 0].max()) + Py
         self._acc_parts = []
-        for o, n in parts:
-            self._check_cover(self._pos_host[o:o + n])
+        # (the whole batch's coverage is within MAX_COVER here, hence every round's)
         if len(parts) <= 4:
             # the cover lists of every round only need the positions: all built now, on the side stream beside the first
             # round, so that no round's overlap-add waits for its own list (the LAST one's build sat behind the last launch)

@@ -615,7 +615,8 @@ def reconstruct_ptychography(
         pr0, pi0 = initialize_probe(probe_size, probe_type, pupil_function=pupil_function, probe_initial=probe_initial,
                                     rescale_intensity=rescale_probe_intensity, extra_defocus_cm=probe_extra_defocus_cm,
                                     sign_convention=sign_convention, raw_data_type=raw_data_type,
-                                    data_first_angle=np.asarray(prj[0:1]) if rescale_probe_intensity else None, **pk)
+                                    data_first_angle=np.asarray(prj[0:1]) if rescale_probe_intensity else None,
+                                    data_all=prj if probe_type == 'ifft' else None, **pk)
         if n_probe_modes == 1:
             probe_real = np.stack([np.squeeze(pr0)]) if pr0.ndim != 3 else pr0[:1]
             probe_imag = np.stack([np.squeeze(pi0)]) if pi0.ndim != 3 else pi0[:1]

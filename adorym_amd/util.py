@@ -105,7 +105,14 @@ def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=
         probe_real = np.ones(probe_size)
         probe_imag = np.zeros(probe_size)
     elif probe_type == 'ifft':
-        raise NotImplementedError("probe_type 'ifft' is outside the accelerated path")
+        # util.py:225-236 -> create_probe_initial_guess_ptycho (:300-333): the probe estimated from ALL measured data.  (Its
+        # beamstop branch is never reached from the driver: `beamstop` is a named argument of reconstruct_ptychography and not
+        # part of the **kwargs that adorym/ptychography.py:609-618 hands to initialize_probe.)
+        if kwargs.get('data_all') is None:
+            raise ValueError("probe_type 'ifft' needs the measured data (data_all)")
+        guess = create_probe_initial_guess_ptycho(kwargs['data_all'], raw_data_type=kwargs.get('raw_data_type', 'intensity'),
+                                                  sign_convention=sign_convention)
+        probe_real, probe_imag = guess.real, guess.imag
     else:
         raise ValueError("Invalid wavefront type. Choose from 'plane', 'fixed', 'supplied'.")
     if pupil_function is not None:
@@ -130,6 +137,20 @@ def initialize_probe(probe_size, probe_type, pupil_function=None, probe_initial=
         probe_real = probe_real * s_
         probe_imag = probe_imag * s_
     return probe_real, probe_imag
+
+
+def create_probe_initial_guess_ptycho(data, raw_data_type='intensity', sign_convention=1):
+    """adorym/util.py:300-333 without beamstop and noise: mean over (angle, position) of the measured magnitudes, back from the
+    detector plane.  ``data``: the whole exchange/data array-like [n_theta, n_pos, Py, Px] (read in one piece, as the reference does)."""
+    dat = np.asarray(data[...] if hasattr(data, 'shape') and not isinstance(data, np.ndarray) else data)
+    if raw_data_type == 'intensity':
+        dat = np.sqrt(dat)
+    wavefront = np.mean(np.abs(dat), axis=(0, 1))
+    if sign_convention == 1:
+        wavefront = np.fft.ifft2(np.fft.ifftshift(wavefront))
+    else:
+        wavefront = np.fft.fft2(np.fft.ifftshift(wavefront))
+    return np.fft.ifftshift(wavefront)
 
 
 def build_rotation_adjoint_csr(coords_fp16, obj_size, Yp, Xp, pad_x0, staged=False):

@@ -363,6 +363,12 @@ int adm_tile_cover_build(adm_plan* plan, void* workspace, size_t workspace_bytes
                          const int32_t* pos_host, int win_y_lo, int win_y_hi, int add);
 /* Blocking: *overflow_host = 1 if some pixel of the last adm_tile_grad_accumulate was covered by more than 64 tiles
  * (the overlap-add then dropped contributions; use smaller batches). */
+/* The overlap-add of a batch in which a pixel is covered by more than 64 tiles (dense 2-D scans taken as one minibatch,
+ * demos/2d_ptychography_w_probe_optimization.py): one pass per range [b_lo, b_hi) of at most 64 positions of the batch -- the
+ * first with add = 0 (writes the batch's rows), the others with add = 1.  Same arguments as adm_tile_grad_accumulate otherwise;
+ * replaces autograd's index_add over the tile stack (adorym/forward_model.py:313-331) for such batches. */
+int adm_tile_grad_accumulate_range(adm_plan* plan, void* workspace, size_t workspace_bytes, const int32_t* pos, int batch,
+                                   const int32_t* pos_host, float* grad_rot, int b_lo, int b_hi, int add);
 int adm_tile_grad_status(adm_plan* plan, void* workspace, size_t workspace_bytes, int batch, int* overflow_host);
 
 /* ---- R9  regulariser gradients --------------------------------------------------------

@@ -736,6 +736,17 @@ def aperture_defocus_probe(probe_size, aperture_radius, probe_defocus_cm, lmbda_
     return np.fft.ifft2(np.fft.fft2(mag.astype(np.complex128)) * h)
 
 
+def probe_ifft_guess(data, raw_data_type='intensity', sign_convention=1):
+    """create_probe_initial_guess_ptycho (util.py:300-333, no beamstop, no noise): the mean measured magnitude over all angles and
+    positions, taken back from the detector plane -- ifftshift, inverse (forward for sign_convention -1) FFT2, ifftshift."""
+    dat = np.asarray(data)
+    if raw_data_type == 'intensity':
+        dat = np.sqrt(dat)
+    wavefront = np.mean(np.abs(dat), axis=(0, 1))
+    wavefront = np.fft.ifft2(np.fft.ifftshift(wavefront)) if sign_convention == 1 else np.fft.fft2(np.fft.ifftshift(wavefront))
+    return np.fft.ifftshift(wavefront)
+
+
 def rescale_probe(probe, data_first_angle, raw_data_type='magnitude', normalize_fft=False, sign_convention=1):
     """initialize_probe, rescale_intensity tail (util.py:254-281).  ``probe`` complex [Py,Px] or [M,Py,Px];
     ``data_first_angle`` = exchange/data[0:1].  Reproduces the reference's `len(probe_real) == 3` test (the per-mode

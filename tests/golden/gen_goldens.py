@@ -1003,8 +1003,26 @@ def gen_f19():
     save('F19_multidist_shifts', **out)
 
 
+# ----------------------------------------------------------------------------- F20 (probe_type='ifft', util.py:225-236, 300-333)
+def gen_f20():
+    """The probe estimated from the measured data (demos/2d_ptychography_w_probe_optimization.py: probe_type='ifft'):
+    create_probe_initial_guess_ptycho for both raw data types and both sign conventions, and through initialize_probe with
+    the intensity rescaling on."""
+    r = cases.rng(2000)
+    data = (np.abs(r.standard_normal((2, 5, 16, 12))) * (1 + 4 * np.exp(-((np.arange(16)[:, None] - 8) ** 2 + (np.arange(12)[None, :] - 6) ** 2) / 8.))).astype(np.float32)
+    STORE['ifft.h5'] = {'exchange/data': data}
+    out = {'data': data}
+    for raw in ('intensity', 'magnitude'):
+        for sc in (1, -1):
+            out['guess_%s_%d' % (raw, sc)] = U.create_probe_initial_guess_ptycho('ifft.h5', raw_data_type=raw, sign_convention=sc)
+    pr, pi = U.initialize_probe([16, 12], 'ifft', save_path='.', fname='ifft.h5', raw_data_type='intensity', rescale_intensity=True,
+                                n_probe_modes=1, normalize_fft=False, sign_convention=1, stdout_options={})
+    out['init_rescaled'] = pr + 1j * pi
+    save('F20_probe_ifft', **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f18', 'f19']
+    which = sys.argv[1:] or ['f15', 'f16', 'f17', 'f1', 'f23', 'f4', 'f5', 'f6', 'f7', 'f8', 'f9', 'f10', 'f11', 'f12', 'f13', 'f18', 'f19', 'f20']
     if 'f1' in which: gen_f1()
     if 'f23' in which: gen_f2_f3()
     if 'f4' in which: gen_f4()
@@ -1022,3 +1040,4 @@ if __name__ == '__main__':
     if 'f17' in which: gen_f17()
     if 'f18' in which: gen_f18()
     if 'f19' in which: gen_f19()
+    if 'f20' in which: gen_f20()

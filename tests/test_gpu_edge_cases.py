@@ -743,3 +743,43 @@ def test_shift_refinement_driver_vs_reference(A, ctx, tmp_path):
     upd = np.linalg.norm(f['e2e_obj_64'] - np.stack([g0.real, g0.imag], -1))
     e, e_ref = np.linalg.norm(x - f['e2e_obj_64']) / upd, np.linalg.norm(f['e2e_obj_32'] - f['e2e_obj_64']) / upd
     assert e < max(5e-3, 3 * e_ref), (e, e_ref)
+
+
+def test_dense_scan_as_one_minibatch_with_probe_from_data_vs_oracle(A, ctx, tmp_path):
+    """The feature set of demos/2d_ptychography_w_probe_optimization.py at a small size: 2-D ptychography, the WHOLE dense scan as one
+    minibatch (20 x 20 positions one pixel apart under a 16 x 16 probe: up to 256 tiles on a pixel -> the multi-pass overlap-add),
+    probe_type='ifft' (estimated from the data), Adam on object + probe + sub-pixel position corrections.  Against the fp64 oracle
+    under the 3x rule with the oracle's own fp32 run as the yardstick (the reference's pieces behind the oracle are pinned by F11 / F20)."""
+    r = cases.rng(2100)
+    N, P = 40, 16
+    pos = np.array([(y, x) for y in range(2, 22) for x in range(2, 22)], dtype=float) + r.uniform(-0.3, 0.3, (400, 2))
+    truth = np.stack([2e-6 * cases.smooth_field((N, N, 1), 361), 2e-7 * cases.smooth_field((N, N, 1), 362)], -1)
+    pm, pp = cases.smooth_field((P, P, 1), 363)[..., 0] + 0.5, 0.3 * cases.smooth_field((P, P, 1), 364)[..., 0]
+    probe_t = pm * np.exp(1j * pp)
+    phys = O.Physics((P, P), 8000., 1e-5)
+    tiles, _ = O.extract_tiles(truth, np.round(pos).astype(int), (P, P))
+    pred, _ = O.predict(tiles, probe_t, phys)
+    prj = (pred ** 2)[None].astype(np.float32)                                   # intensity data
+    guess = [np.full((N, N, 1), 5e-7), np.full((N, N, 1), 5e-8)]
+    kw = dict(n_epochs=3, minibatch_size=400, learning_rate=1e-7, raw_data_type='intensity', optimize_probe=True, probe_learning_rate=1e-3,
+              optimize_all_probe_pos=True, all_probe_pos_learning_rate=1e-2)
+    st = A.reconstruct_ptychography(
+        fname=prj, obj_size=(N, N, 1), probe_pos=pos, theta_st=0, theta_end=0, n_theta=1, two_d_mode=True, energy_ev=8000., psize_cm=1e-5,
+        free_prop_cm='inf', initial_guess=guess, probe_type='ifft', gamma=0, alpha_d=0, alpha_b=0, optimizer='adam', save_path=str(tmp_path),
+        output_folder='dense', store_checkpoint=False, use_checkpoint=False, return_state=True, **kw)
+    p0 = O.probe_ifft_guess(prj, 'intensity', 1)
+    runs = {}
+    for dt in ('float64', 'float32'):
+        runs[dt] = O.reconstruct_2d(prj.astype(np.float64), guess, p0[None], pos, phys, dtype=dt, **kw)
+    o64, o32 = runs['float64'], runs['float32']
+    assert np.allclose(st['losses'], o64['losses'], rtol=max(2e-4, 3 * np.abs(np.array(o32['losses']) / np.array(o64['losses']) - 1).max()))
+    x = np.stack([st['delta'], st['beta']], -1)
+    upd = np.linalg.norm(o64['obj'] - np.stack(guess, -1))
+    e, e_ref = np.linalg.norm(x - o64['obj']) / upd, np.linalg.norm(o32['obj'] - o64['obj']) / upd
+    print('dense scan: object %.2e of the update from the fp64 oracle (oracle fp32: %.2e)' % (e, e_ref))
+    assert upd > 0 and e < max(5e-3, 3 * e_ref), (e, e_ref)
+    p = (st['probe_real'] + 1j * st['probe_imag'])[0]
+    pn = np.linalg.norm(o64['probes'][0])
+    assert np.linalg.norm(p - o64['probes'][0]) / pn < max(1e-4, 3 * np.linalg.norm(o32['probes'][0] - o64['probes'][0]) / pn)
+    cn = np.linalg.norm(o64['pos_corr'])
+    assert np.linalg.norm(st['probe_pos_correction'] - o64['pos_corr']) / cn < max(2e-2, 3 * np.linalg.norm(o32['pos_corr'] - o64['pos_corr']) / cn)

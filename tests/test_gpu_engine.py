@@ -77,38 +77,61 @@ def test_upload_ring_matches_blocking_upload(A, ctx):
     assert np.array_equal(big.get(), hb)
 
 
-def test_overlap_add_refuses_more_than_64_tiles_per_pixel(A, ctx):
-    Y, X, S, P = 40, 40, 2, 16
-    pos = np.array([(3, 4)] * 70)                         # 70 duplicates: every tile pixel is covered 70 times
-    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=70)
+def test_overlap_add_of_more_than_64_tiles_per_pixel_vs_oracle(A, ctx):
+    """A pixel covered by more tiles than the overlap-add's lists hold (64): the batch is added in passes of 64 positions
+    (adm_tile_grad_accumulate_range).  70 duplicates of one position + a dense 5-pixel raster of 169 positions under a 16 x 16
+    probe (coverage up to 9+70), against the fp64 oracle's gradient; the early cover build is skipped, the loss is unaffected."""
+    Y, X, S, P = 80, 80, 2, 16
+    pos = np.array([(3, 4)] * 70 + [(y, x) for y in range(0, 65, 5) for x in range(0, 65, 5)])
+    B = len(pos)
+    eng = A.MultisliceEngine(ctx, (Y, X, S), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B)
+    assert eng._check_cover(np.ascontiguousarray(pos.astype(np.int32))) > eng.MAX_COVER
     r = cases.rng(2)
-    obj = ctx.array(np.stack([r.uniform(0, 1e-3, (Y, X, S)), r.uniform(0, 1e-4, (Y, X, S))], -1).astype(np.float32))
-    probe = ctx.array(r.standard_normal((1, P, P, 2)).astype(np.float32))
-    eng.set_batch(pos, np.ones((70, P, P), np.float32))
+    obj_h = np.stack([r.uniform(0, 1e-3, (Y, X, S)), r.uniform(0, 1e-4, (Y, X, S))], -1)
+    obj = ctx.array(obj_h.astype(np.float32))
+    probe_h = r.standard_normal((P, P)) + 1j * r.standard_normal((P, P))
+    probe = ctx.array(np.stack([probe_h.real, probe_h.imag], -1)[None].astype(np.float32))
+    meas = (np.abs(r.standard_normal((B, P, P))) * 5).astype(np.float32)
+    g = ctx.zeros(obj.shape)
+    eng.set_batch(pos, meas)
     eng.rotate(obj, None)
-    with pytest.raises(RuntimeError, match='covered by 70 tiles'):
-        eng.multislice(probe)                             # raises before the overlap-add is launched
-    eng.set_batch(pos[:64], np.ones((64, P, P), np.float32))
+    eng.build_cover()                                    # (a no-op for such a batch)
     eng.multislice(probe)
-    assert np.isfinite(eng.loss())
+    eng.rotate_adjoint(g, None)
+    loss = eng.loss()
+    phys = O.Physics((P, P), cases.ENERGY_EV, cases.PSIZE_CM)
+    lo, _, go, _ = O.forward_adjoint_object(obj_h, None, probe_h, pos, meas.astype(np.float64), phys)
+    assert abs(loss - lo) < 1e-5 * abs(lo)
+    assert np.linalg.norm(g.get() - go) < 1e-4 * np.linalg.norm(go)
+    # ... and the same batch through the path for batches larger than the chip (B = 239 <= 256 here; forced with N_CU = 128)
+    eng.N_CU = 128
+    try:
+        g2 = ctx.zeros(obj.shape)
+        eng.set_batch(pos, meas)
+        eng.rotate(obj, None)
+        eng.multislice_overlapped(probe)
+        eng.rotate_adjoint(g2, None)
+        assert np.array_equal(g2.get(), g.get())
+    finally:
+        del eng.N_CU
 
 
-def test_driver_refuses_overcovered_fused_angle(A, ctx, tmp_path):
-    """The same guard through reconstruct_ptychography's asynchronous path ('per angle' fuses 80 positions, 72 of them on
-    one spot)."""
+def test_driver_runs_an_overcovered_fused_angle(A, ctx, tmp_path):
+    """The same through reconstruct_ptychography's asynchronous path ('per angle' fuses 80 positions, 72 of them on one spot):
+    runs, finite loss (it raised before the multi-pass overlap-add existed)."""
     n_pos, P, N = 80, 16, 32
     pos = np.array([(4, 4)] * 72 + [(i, 2 * i) for i in range(8)])
     r = cases.rng(3)
     prj = (np.abs(r.standard_normal((1, n_pos, P, P))) + 1).astype(np.float32)
     fn = os.path.join(str(tmp_path), 'd.npz')
     np.savez(fn, data=prj)
-    with pytest.raises(RuntimeError, match='tiles of this launch'):
-        A.reconstruct_ptychography(fname=fn, save_path=str(tmp_path), output_folder='o', obj_size=(N, N, 4), probe_pos=pos,
-                                   theta_st=0, theta_end=0, n_theta=1, energy_ev=cases.ENERGY_EV, psize_cm=cases.PSIZE_CM,
-                                   minibatch_size=8, n_epochs=1, update_scheme='per angle', free_prop_cm='inf',
-                                   probe_type='gaussian', probe_mag_sigma=4, probe_phase_sigma=4, probe_phase_max=0.5,
-                                   initial_guess=[np.full((N, N, 4), 1e-4), np.full((N, N, 4), 1e-5)], gamma=0, alpha_d=None,
-                                   random_theta=False, store_checkpoint=False, use_checkpoint=False, cpu_only=False)
+    st = A.reconstruct_ptychography(fname=fn, save_path=str(tmp_path), output_folder='o', obj_size=(N, N, 4), probe_pos=pos,
+                                    theta_st=0, theta_end=0, n_theta=1, energy_ev=cases.ENERGY_EV, psize_cm=cases.PSIZE_CM,
+                                    minibatch_size=8, n_epochs=1, update_scheme='per angle', free_prop_cm='inf',
+                                    probe_type='gaussian', probe_mag_sigma=4, probe_phase_sigma=4, probe_phase_max=0.5,
+                                    initial_guess=[np.full((N, N, 4), 1e-4), np.full((N, N, 4), 1e-5)], gamma=0, alpha_d=None,
+                                    random_theta=False, store_checkpoint=False, use_checkpoint=False, cpu_only=False, return_state=True)
+    assert len(st['losses']) >= 1 and np.all(np.isfinite(st['losses'])) and np.all(np.isfinite(st['delta']))
 
 
 @pytest.mark.regression
