@@ -45,6 +45,7 @@ def print_flush(a, designate_rank=None, this_rank=None, save_stdout=False, outpu
     if designate_rank is None or this_rank == designate_rank:
         print(a)
         if save_stdout:
+            os.makedirs(output_folder, exist_ok=True)     # (the first lines are printed before the driver creates the folder)
             with open(os.path.join(output_folder, 'stdout_{}.txt'.format(timestamp)), 'a') as f:
                 f.write(a + '\n')
     sys.stdout.flush()
@@ -300,7 +301,9 @@ def reconstruct_ptychography(
 
     # ---- combinations outside the accelerated path: fail loudly -------------------------------------
     _not_implemented(distribution_mode is not None, "distribution_mode='%s'" % distribution_mode)
-    _not_implemented(cpu_only, 'cpu_only=True (there is no CPU fallback)')
+    if cpu_only:
+        # (demos/2d_ptychography_w_position_correction.py asks for it; there is no CPU path here and none is substituted)
+        warnings.warn('cpu_only=True is ignored: adorym_amd computes on the GPU only.')
     _not_implemented(run_bfloat16 or run_float64, 'run_bfloat16 / run_float64')
     if unknown_type not in ('delta_beta', 'real_imag'):
         raise ValueError("unknown_type must be 'delta_beta' or 'real_imag'")
