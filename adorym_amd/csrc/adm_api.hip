@@ -575,7 +575,7 @@ extern "C" int adm_probe_shift(adm_plan* plan, const float* probe, const float* 
 }
 
 extern "C" int adm_probe_shift_adj(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,
-                                   const float* grad_probes, float* grad_probe, float* grad_shifts) {
+                                   float* grad_probes, float* grad_probe, float* grad_shifts) {
     if (!plan || !probe || !shifts || !grad_probes || !grad_shifts) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: null argument");
     if (batch <= 0) return fail(ADM_ERR_INVALID, "adm_probe_shift_adj: batch must be positive");
     if (plan->generic) return fail(ADM_ERR_UNSUPPORTED, "adm_probe_shift_adj: sub-pixel probe shifts need one of the tuned probe sizes {8,12,16,18,24,27,32,36,64,72}");
@@ -589,6 +589,15 @@ extern "C" int adm_probe_shift_adj(adm_plan* plan, const float* probe, const flo
     q.grad_shifts = grad_shifts;
     q.twid = plan->twid_dev;
     q.n_modes = plan->d.n_modes;
+    // Many (position, mode) workgroups adding into ONE probe gradient with float atomics serialise on its few thousand addresses
+    // (2704 positions: 545 us) and leave the order of the additions to chance: beyond 256 of them every workgroup writes its term
+    // into its own slot of grad_probes (consumed by then) and the slots are summed in a fixed order.
+    const bool slots = grad_probe && (size_t)batch * q.n_modes > 256;
+    if (slots) q.slots = (float2*)grad_probes;
     ADM_HIP(shift_launch(plan->d.probe_x, q, batch, true, plan->ctx->stream));
+    if (slots) {
+        const size_t n = (size_t)q.n_modes * plan->d.probe_y * plan->d.probe_x;
+        ADM_HIP(probe_grad_reduce_large((float2*)grad_probes, batch, n, (float2*)grad_probe, plan->ctx->stream));
+    }
     return ADM_OK;
 }

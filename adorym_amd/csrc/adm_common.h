@@ -97,6 +97,8 @@ struct ShiftParams {
     const int* index;          // [B] or nullptr
     float2* probes_out;        // forward: [B][M][P][P]
     const float2* grad_probes; // adjoint: [B][M][P][P]
+    float2* slots;             // adjoint, large batches: every (position, mode) leaves its probe-gradient term in its own [P][P] slot
+                               // (= grad_probes, in place) for a fixed-order sum afterwards instead of atomics on grad_probe
     float2* grad_probe;        // adjoint: [M][P][P] accumulated (atomics) or nullptr
     float* grad_shifts;        // adjoint: accumulated (atomics) at [index ? index[b] : b][2]
     const float2* twid;
@@ -112,6 +114,7 @@ size_t ws_off_cover(const adm_plan* plan, int batch);
 size_t ws_off_det(const adm_plan* plan, int batch);
 size_t ws_off_gprobe(const adm_plan* plan, int batch);
 hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* out, hipStream_t st);
+hipError_t probe_grad_reduce_large(float2* part, int batch, size_t n, float2* out, hipStream_t st);   // two levels, `part` is scratch
 int ms_r1_for(int n);
 hipError_t ms_launch(int n, const MsParams& p, int batch, hipStream_t st);
 // adm_multislice_fwd_adj's body (per_position: one probe set per position)

@@ -746,7 +746,8 @@ __global__ __launch_bounds__((Geo<N, R1, R2>::NT)) void probe_shift_adj_kernel(S
             }
         }
         ifft2_from_regs<N, R1, R2>(c, bg, a);
-        add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr, false);
+        if (q.slots) add_probe_grad<N, R1, R2>(c, a, q.slots + ((size_t)b * q.n_modes + m) * N * N, true);
+        else add_probe_grad<N, R1, R2>(c, a, q.grad_probe ? q.grad_probe + (size_t)m * N * N : nullptr, false);
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #pragma unroll

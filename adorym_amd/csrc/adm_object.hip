@@ -690,19 +690,44 @@ __global__ __launch_bounds__(256) void reg_grad_range_kernel(const float2* __res
 }
 
 // out[i] += sum_b part[b][i], b ascending: the per-position probe gradients of a launch, summed deterministically
-__global__ __launch_bounds__(256) void probe_grad_reduce_kernel(const float2* __restrict__ part, int batch, size_t n, float2* __restrict__ out) {
+__global__ __launch_bounds__(256) void probe_grad_reduce_kernel(const float2* __restrict__ part, int batch, size_t stride, size_t n,
+                                                                float2* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float2 acc = out[i];
     for (int b = 0; b < batch; ++b) {
-        const float2 v = part[(size_t)b * n + i];
+        const float2 v = part[(size_t)b * stride + i];
         acc.x += v.x;
         acc.y += v.y;
     }
     out[i] = acc;
 }
+// Large batches (a dense 2-D scan taken as one minibatch: 2704 positions): one thread per element walking the whole batch is a
+// chain of `batch` dependent adds on 21 workgroups.  Two levels instead: chunk c of PGR_CHUNK slots is summed in slot order into
+// its first slot (every thread touches element i of every slot only: in place), then the chunk sums are added in chunk order.
+// A fixed order either way: bit-reproducible.
+#define PGR_CHUNK 32
+__global__ __launch_bounds__(256) void probe_grad_reduce_chunks_kernel(float2* __restrict__ part, int batch, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b0 = blockIdx.y * PGR_CHUNK, b1 = min(b0 + PGR_CHUNK, batch);
+    float2 acc = part[(size_t)b0 * n + i];
+    for (int b = b0 + 1; b < b1; ++b) {
+        const float2 v = part[(size_t)b * n + i];
+        acc.x += v.x;
+        acc.y += v.y;
+    }
+    part[(size_t)b0 * n + i] = acc;
+}
+hipError_t probe_grad_reduce_large(float2* part, int batch, size_t n, float2* out, hipStream_t st) {
+    const int chunks = (batch + PGR_CHUNK - 1) / PGR_CHUNK;
+    hipLaunchKernelGGL(probe_grad_reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256), chunks), dim3(256), 0, st, part, batch, n);
+    // the chunk sums sit PGR_CHUNK slots apart
+    hipLaunchKernelGGL(probe_grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float2*)part, chunks, (size_t)PGR_CHUNK * n, n, out);
+    return hipGetLastError();
+}
 hipError_t probe_grad_reduce(const float2* part, int batch, size_t n, float2* out, hipStream_t st) {
-    hipLaunchKernelGGL(probe_grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, batch, n, out);
+    hipLaunchKernelGGL(probe_grad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, batch, n, n, out);
     return hipGetLastError();
 }
 
@@ -1393,10 +1418,22 @@ extern "C" int adm_tile_grad_accumulate_range(adm_plan* plan, void* workspace, s
     if (batch <= 0 || b_lo < 0 || b_hi <= b_lo || b_hi > batch) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: bad range");
     if (b_hi - b_lo > ADM_MAXCOVER) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: at most 64 positions per pass");
     if (workspace_bytes < adm_plan_workspace_bytes(plan, batch)) return fail(ADM_ERR_INVALID, "adm_tile_grad_accumulate_range: workspace too small");
-    TileGeom g;
-    int rc = tile_geom(plan, batch, pos_host, 0, 0, add, g);       // the window of the WHOLE batch; add: accumulate in all of it
+    TileGeom g, gb;
+    int rc = tile_geom(plan, batch, pos_host, 0, 0, 0, gb);        // the window of the WHOLE batch
     if (rc) return rc;
-    (void)cover_key_take(plan, workspace, pos, pos_host, batch, g);  // lists built ahead for the one-pass form are void now
+    (void)cover_key_take(plan, workspace, pos, pos_host, batch, gb); // lists built ahead for the one-pass form are void now
+    if (!add) {
+        // first pass: the batch's rows start from zero, every pass then ADDS inside the rows its own positions reach (a pass over
+        // the whole batch window cost the same whatever the range covered: 43 passes x 276 rows for the 2704-position demo)
+        hipStream_t st0 = plan->ctx->stream;
+        const size_t slice = (size_t)gb.Yp * gb.Xp;
+        ADM_HIP(hipMemset2DAsync(grad_rot + 2 * (size_t)gb.row0 * gb.Xp, slice * sizeof(float2), 0, (size_t)gb.nrows * gb.Xp * sizeof(float2),
+                                 (size_t)plan->d.obj_z, st0));
+    }
+    rc = tile_geom(plan, b_hi - b_lo, pos_host + 2 * (size_t)b_lo, 0, 0, 1, g);      // this range's own rows, accumulated
+    if (rc) return rc;
+    if ((size_t)batch * plan->n_steps * g.row_elems >= 0xFFFFFFFFull)
+        return fail(ADM_ERR_UNSUPPORTED, "adm_tile_grad_accumulate_range: batch too large for 32-bit tile offsets");
     rc = cover_build(plan, workspace, pos, batch, g, b_lo, b_hi);
     if (rc) return rc;
     char* ws = (char*)workspace;

@@ -173,12 +173,16 @@ class TcpGroup(object):
                     c.settimeout(5.0)
                     got = bytes(_recv_exact(c, len(hello)))
                     r = struct.unpack('!I', bytes(_recv_exact(c, 4)))[0]
-                    if not hmac.compare_digest(got, hello) or not (0 < r < self.size) or r in self._peers:
+                    if not hmac.compare_digest(got, hello) or not (0 < r < self.size):
                         raise ConnectionError('foreign connection')
                     c.sendall(_MAGIC)
                 except Exception:
                     c.close()           # not one of this job's ranks (a port scanner, another job): ignore it
                     continue
+                if r in self._peers:
+                    # the rank connected again: it gave its earlier connection up (this process was slow to accept it).  The last
+                    # connection is the live one -- registering the dead one left rank 0 talking to a closed socket.
+                    self._peers.pop(r).close()
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 c.settimeout(self.op_timeout)
                 self._peers[r] = c
@@ -192,7 +196,9 @@ class TcpGroup(object):
                     except OSError:
                         continue
                     try:
-                        s.settimeout(5.0)
+                        # rank 0 answers when it gets to this connection -- on a loaded machine that can take a while: wait for it
+                        # as long as the rendezvous may take (a connection rank 0 refuses is CLOSED by it, which ends the wait)
+                        s.settimeout(max(5.0, deadline - time.time()))
                         s.sendall(hello + struct.pack('!I', self.rank))
                         if bytes(_recv_exact(s, len(_MAGIC))) == _MAGIC:
                             sock, self.port = s, p

@@ -333,10 +333,12 @@ int adm_multislice_fwd_adj_pp(adm_plan* plan, const float* obj_rot, const float*
  * index   device int32 [batch]: entry used by position b; NULL = entry b
  * adm_probe_shift_adj is the adjoint (what torch.autograd.grad returns through that op for probe_real/imag and
  * probe_pos_correction): grad_probe [n_modes][Py][Px][2] += sum_b shift_{-s_b}(grad_probes[b]) (may be NULL);
- * grad_shifts[index[b]][0..1] += dL/d(sy, sx) (float [n_entries][2], NOT zeroed by the call). */
+ * grad_shifts[index[b]][0..1] += dL/d(sy, sx) (float [n_entries][2], NOT zeroed by the call).
+ * grad_probes is CONSUMED: with more than 256 (position, mode) pairs its slots are reused for the terms of the sum, which is then
+ * formed in a fixed order (no atomics); its contents are undefined afterwards. */
 int adm_probe_shift(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch, float* probes_out);
 int adm_probe_shift_adj(adm_plan* plan, const float* probe, const float* shifts, const int32_t* index, int batch,
-                        const float* grad_probes, float* grad_probe, float* grad_shifts);
+                        float* grad_probes, float* grad_probe, float* grad_shifts);
 /* x[r][c] -= mean_r x[r][c]: the drift guard applied to probe_pos_correction after its update
  * (adorym/optimizers.py:1046-1048).  Single workgroup; meant for small parameter arrays. */
 int adm_center_rows(adm_ctx* ctx, float* x, size_t n_rows, int n_cols);

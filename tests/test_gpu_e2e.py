@@ -78,9 +78,14 @@ def test_probe_optimisation_runs_and_reduces_loss(tmp_path):
 
 def test_unsupported_options_raise(tmp_path):
     for bad in (dict(distribution_mode='shared_file'), dict(optimizer='cg'), dict(multiscale_level=2),
-                dict(optimize_probe_pos_offset=True), dict(optimize_probe_defocusing=True), dict(cpu_only=True)):
+                dict(optimize_probe_pos_offset=True), dict(optimize_probe_defocusing=True)):
         with pytest.raises(NotImplementedError):
             run(tmp_path, n_epochs=1, **bad)
+    # cpu_only=True (demos/2d_ptychography_w_position_correction.py sets it): there is no CPU path and none is substituted -- the
+    # run goes to the GPU with a warning saying so
+    with pytest.warns(UserWarning, match='cpu_only=True is ignored'):
+        g, inp, st = run(tmp_path, n_epochs=1, cpu_only=True)
+    assert np.all(np.isfinite(st['delta']))
 
 
 def test_driver_variants_run(tmp_path):

@@ -519,3 +519,37 @@ def test_transmission_cache_tracks_its_source_buffer(A, ctx):
         assert not e2.transmission_cache
         assert ctx.lib.adm_plan_set_transmission_cache(e2.plan.handle, 1) == _lib.ADM_ERR_UNSUPPORTED
     assert ctx.lib.adm_transmission_refresh(ref.plan.handle, other.ptr, 0, Y) == _lib.ADM_ERR_INVALID     # no cache on that plan
+
+
+@pytest.mark.regression
+def test_probe_gradient_through_shifts_of_a_large_batch_is_bit_reproducible(A, ctx):
+    """More than 256 (position, mode) pairs: adm_probe_shift_adj sums the positions' probe-gradient terms from per-position slots in a
+    fixed order (two levels) instead of float atomics on the one probe gradient -- the same bits run after run, and the sum equals
+    the sum over two halves of the batch launched separately (which take the same path) to rounding."""
+    r = cases.rng(77)
+    Y, X, P, B = 48, 48, 16, 300
+    pos = np.stack([r.integers(-4, Y - 10, B), r.integers(-4, X - 10, B)], 1)
+    eng = A.MultisliceEngine(ctx, (Y, X, 1), (P, P), pos, cases.ENERGY_EV, cases.PSIZE_CM, max_batch=B, n_probe_modes=2)
+    obj = ctx.array(np.stack([r.uniform(0, 1e-3, (Y, X, 1)), r.uniform(0, 1e-4, (Y, X, 1))], -1).astype(np.float32))
+    probe = ctx.array(r.standard_normal((2, P, P, 2)).astype(np.float32))
+    shifts = ctx.array(r.uniform(-0.5, 0.5, (B, 2)).astype(np.float32))
+    meas = (np.abs(r.standard_normal((B, P, P))) * 5).astype(np.float32)
+    outs = []
+    for _ in range(3):
+        eng.set_batch(pos, meas)
+        eng.rotate(obj, None)
+        gp, gs = ctx.zeros(probe.shape), ctx.zeros((B, 2))
+        eng.multislice(probe, grad_probe=gp, shifts=shifts, grad_shifts=gs)
+        outs.append((gp.get(), gs.get()))
+    assert np.abs(outs[0][0]).max() > 0
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    # the same positions as 2 x 150 (each still beyond 256 pairs): same sum up to the order of the additions
+    acc = np.zeros_like(outs[0][0])
+    for lo in (0, 150):
+        eng.set_batch(pos[lo:lo + 150], meas[lo:lo + 150])
+        eng.rotate(obj, None)
+        gp = ctx.zeros(probe.shape)
+        eng.multislice(probe, grad_probe=gp, shifts=ctx.array(shifts.get()[lo:lo + 150]), grad_shifts=ctx.zeros((150, 2)), grad_scale=2.0 / (B * eng.n_det))
+        acc += gp.get()
+    assert np.abs(acc - outs[0][0]).max() <= 2e-5 * np.abs(acc).max()

@@ -182,3 +182,56 @@ def test_a_peer_without_the_job_token_is_not_admitted():
         TcpGroup(1, 2, '127.0.0.1', port, job='j', exact_port=True, timeout=1.5, token='wrong')
     t.join(10)
     assert 'only 1 of 2 ranks connected' in str(errs.get(0))
+
+
+def test_a_rank_that_reconnects_replaces_its_abandoned_connection():
+    """A rank that gave a connection up (rank 0 was slow to answer on a loaded machine) and connected again: rank 0 has the hello of
+    BOTH connections in its queue.  It must end up talking to the live one -- registering the first left it with a closed socket
+    and the rank locked out until the time-out (seen once as a spurious failure of a 4-rank GPU test on a slow box)."""
+    import hashlib
+    import hmac
+    import struct
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    from adorym_amd import rendezvous as R
+    port = _free_port()
+    out = {}
+    srv_ready = threading.Event()
+
+    def rank0():
+        try:
+            srv_ready.set()
+            g = R.TcpGroup(0, 3, '127.0.0.1', port, job='j', exact_port=True, timeout=20.0, token='t')
+            out[0] = g.bcast_object({'x': 7})
+            g.barrier()
+        except Exception as e:
+            out[0] = e
+
+    def rank(r):
+        try:
+            g = R.TcpGroup(r, 3, '127.0.0.1', port, job='j', exact_port=True, timeout=20.0, token='t')
+            out[r] = g.bcast_object(None)
+            g.barrier()
+        except Exception as e:
+            out[r] = e
+
+    t0 = threading.Thread(target=rank0)
+    t0.start()
+    srv_ready.wait(5)
+    # rank 1's abandoned attempt: a complete hello, then the socket is closed without waiting for the answer
+    proof = hmac.new(b't', b'adm-rendezvous:j', hashlib.sha256).digest()
+    hello = R._MAGIC + struct.pack('!I', 1) + b'j' + proof + struct.pack('!I', 1)
+    for _ in range(200):
+        try:
+            s = socket.create_connection(('127.0.0.1', port), timeout=1.0)
+            break
+        except OSError:
+            time.sleep(0.02)
+    s.sendall(hello)
+    s.close()
+    time.sleep(0.2)
+    ts = [threading.Thread(target=rank, args=(r,)) for r in (1, 2)]
+    [t.start() for t in ts]
+    [t.join(30) for t in ts + [t0]]
+    assert out.get(0) == {'x': 7} and out.get(1) == {'x': 7} and out.get(2) == {'x': 7}, out
