@@ -148,3 +148,28 @@ def test_multislice_tomography(A, tmp_path):
     assert len(st['losses']) == 2 * 2                      # 20 angles / theta_downsample 10 = 2 angles per epoch
     outside = ((zz ** 2 + yy ** 2 + xx ** 2) >= (0.45 * N) ** 2)
     assert np.all(st['delta'][outside] == 0)               # the finite-support mask is applied after every update
+
+
+def test_manual_scripts_multislice_ptycho_gd_binning_checkpoints(A, tmp_path):
+    """tests/manual_scripts/test_multislice_ptycho_256_theta.py:40-78 and test_multislice_ptycho_64.py:36-82 of the reference at 32^3:
+    the GD optimiser with its step-halving schedule, binning = 8 (4 modulation steps), theta_downsample, a minibatch that does not
+    divide the scan, the forward model handed over as a CLASS, store_checkpoint=True, the old `shared_file_object` keyword."""
+    N, P, n_theta = 32, 12, 20
+    pos = [(y, x) for y in np.arange(3) * 8 - 2 for x in np.arange(3) * 8 - 2]
+    obj = np.stack([2e-6 * cases.smooth_field((N, N, N), 397), 2e-7 * cases.smooth_field((N, N, N), 398)], -1)
+    mag, ph = O.generate_gaussian_map((P, P), 1, 3, 0.5, 3)
+    theta = np.linspace(0, 2 * np.pi, n_theta, dtype='float32')
+    prj = _ptycho_data(obj, np.array(pos, dtype=float), (mag * np.exp(1j * ph))[None], 5000., 1e-7, raw='magnitude', theta=theta)
+    st = A.reconstruct_ptychography(
+        fname=prj, theta_st=0, theta_end=2 * np.pi, theta_downsample=10, n_epochs=2, obj_size=(N, N, N), alpha_d=0, alpha_b=0, gamma=0,
+        probe_size=(P, P), learning_rate=1e-5, center=16, energy_ev=5000, psize_cm=1.e-7, minibatch_size=4, n_batch_per_update=1,
+        output_folder='epoch_0', cpu_only=False, use_checkpoint=False, store_checkpoint=True, save_path=str(tmp_path), multiscale_level=1,
+        n_epoch_final_pass=None, save_intermediate=True, full_intermediate=True, initial_guess=None, n_dp_batch=23, probe_type='gaussian',
+        forward_algorithm='fresnel', forward_model=A.PtychographyModel, probe_pos=pos, finite_support_mask=None, probe_mag_sigma=3,
+        probe_phase_sigma=3, probe_phase_max=0.5, reweighted_l1=False, optimizer='gd', free_prop_cm='inf', backend='pytorch', binning=8,
+        shared_file_object=False, object_type='normal', optimize_probe_defocusing=False, probe_defocusing_learning_rate=1e-7,
+        probe_learning_rate=1e-3, probe_learning_rate_init=1e-3, debug=False, update_scheme='immediate', distribution_mode=None,
+        return_state=True)
+    _finite(st)
+    assert len(st['losses']) == 2 * 2 * 3                 # 2 epochs x 2 angles x ceil(9 / 4) minibatches
+    assert os.path.isdir(os.path.join(str(tmp_path), 'epoch_0', 'checkpoint'))
