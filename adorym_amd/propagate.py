@@ -613,7 +613,15 @@ class AngleBatch(object):
             self._adj_ptrs = DeviceArray(self.ctx, (self.R, 5), np.uint64)
         self.ctx.uploader().upload(self._adj_ptrs, np.array([[p_[0].ptr, p_[1].ptr, p_[2].ptr, p_[3].ptr, p_[4].ptr] for p_ in parts],
                                                             dtype=np.uint64))
-        check(self.ctx.lib.adm_rotate_adj_staged_stack(eng.plan.handle, eng.grad_rot.ptr, self._adj_ptrs.ptr, self.R, grad_obj.ptr))
+        # scratch for the angles' terms side by side (R copies of the real gradient), as long as that stays moderate
+        # (ADM_STACK_SCRATCH_MB, 512): the R terms are then formed in parallel and added in angle order by a second launch
+        if getattr(self, '_adj_scratch', None) is None:
+            need = self.R * grad_obj.size * 4
+            limit = float(os.environ.get('ADM_STACK_SCRATCH_MB', '512')) * 2 ** 20
+            self._adj_scratch = DeviceArray(self.ctx, (self.R * grad_obj.size,), np.float32) if need <= limit else False
+        sc = self._adj_scratch
+        check(self.ctx.lib.adm_rotate_adj_staged_stack(eng.plan.handle, eng.grad_rot.ptr, self._adj_ptrs.ptr, self.R, grad_obj.ptr,
+                                                       sc.ptr if sc is not False else None, sc.nbytes if sc is not False else 0))
 
     def loss_and_grad(self, obj, grad_obj, tables, probe, targets):
         """obj, grad_obj: DeviceArray [Y,X,Z,2]; tables: R RotationTables (built for obj_size); targets [R,Py,Px] magnitudes

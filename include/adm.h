@@ -259,8 +259,11 @@ int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* 
  * back-rotated with the r-th set of CSR tables and the n_tables contributions are ADDED, r ascending, into the ONE gradient
  * grad_obj [obj_y / n_tables, X, Z, 2] -- the additions n_tables sequential calls would make (`gradient.arr = comm.allreduce(...)`
  * of 16 single-angle ranks, adorym/ptychography.py:1113-1114), in one launch.  tables_dev: device array of n_tables records of five
- * device pointers (csr_ptr, csr_src, csr_lsrc, csr_w, boxes: the outputs of adm_rotation_csr_build, in that order). */
-int adm_rotate_adj_staged_stack(adm_plan* plan, const float* grad_rot, const void* tables_dev, int n_tables, float* grad_obj);
+ * device pointers (csr_ptr, csr_src, csr_lsrc, csr_w, boxes: the outputs of adm_rotation_csr_build, in that order).
+ * scratch (device, n_tables x the size of grad_obj; or NULL): with it the angles' terms are formed side by side and then added in
+ * angle order by a second launch -- the same additions, the same bits, without a chain of n_tables rounds inside every block. */
+int adm_rotate_adj_staged_stack(adm_plan* plan, const float* grad_rot, const void* tables_dev, int n_tables, float* grad_obj,
+                                float* scratch, size_t scratch_bytes);
 /* Builds, on the device, everything adm_rotate_adj_staged needs for one angle from the fp16 lookup table `coords`
  * (device, [X*Z][2]): csr_ptr [X*Z+1], csr_src / csr_lsrc / csr_w [4*X*Z] (only the first csr_ptr[X*Z] entries are
  * meaningful), boxes [ceil(Z/16)*ceil(X/16)][4].  Rows ordered by target voxel, entries by ascending source offset: the same

@@ -435,6 +435,12 @@ def test_angle_batch_stacked_rotations_equal_per_angle_launches_bitwise(A, ctx, 
     assert np.array_equal(l1, l2)
     a, b = g1.get(), g2.get()
     assert np.abs(a).max() > 0 and np.array_equal(a, b)
+    # ... and the one-launch form without scratch (every block walks the angles one after the other)
+    assert ab._adj_scratch is not False
+    ab._adj_scratch = False
+    g3 = ctx.zeros((N, N, N, 2))
+    ab.loss_and_grad(obj, g3, tabs, probe, data)
+    assert np.array_equal(g3.get(), b)
 
 
 def c2(z):
