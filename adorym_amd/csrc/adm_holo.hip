@@ -646,17 +646,20 @@ template <int NY, int MODE> __global__ __launch_bounds__(256) void holo_slf(Shif
     }
     const float sy = A.shifts[2 * d], sx = A.shifts[2 * d + 1];
     const float fx = fft_freq(kx, A.nx);
-    float v[2] = {0.f, 0.f};
+    // (the terms cancel almost completely -- for uncorrelated data the sum is ~1e-3 of the sum of their magnitudes: the eight terms of
+    // a thread and, below, the nx line sums are added in double; the tree over a line's threads stays in float)
+    double v0 = 0.0, v1 = 0.0;
     if (ok) {
         for (int k = t; k < NY; k += LG::TPR) {
             const float fy = fft_freq(k, NY);
             float sn, cs;
             sincosf(-2.f * 3.14159265359f * (fx * sx + fy * sy), &sn, &cs);
             const cf c = cmul(cmul(conjf2(G[k]), A.spec[line + k]), make_float2(cs, sn));
-            v[0] += fy * c.y;
-            v[1] += fx * c.y;
+            v0 += (double)(fy * c.y);
+            v1 += (double)(fx * c.y);
         }
     }
+    float v[2] = {(float)v0, (float)v1};
     line_sums<LG::TPR, 2>(v, red);
     if (ok && t == 0) {
         const float s = 2.f * 3.14159265359f * A.inv_n;
@@ -667,11 +670,11 @@ template <int NY, int MODE> __global__ __launch_bounds__(256) void holo_slf(Shif
 // one wave per output (d, q): the per-line sums in a fixed order
 __global__ __launch_bounds__(64) void holo_shift_sum_kernel(ShiftArgs A) {
     const int o = blockIdx.x, d = o >> 1, q = o & 1, lane = threadIdx.x;
-    float acc = 0.f;
-    for (int kx = lane; kx < A.nx; kx += 64) acc += A.part[((size_t)d * A.nx + kx) * 2 + q];
+    double acc = 0.0;
+    for (int kx = lane; kx < A.nx; kx += 64) acc += (double)A.part[((size_t)d * A.nx + kx) * 2 + q];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) A.grad_shifts[o] += acc;
+    if (lane == 0) A.grad_shifts[o] += (float)acc;
 }
 
 // lines (d, kx): D^ Phi -> IFFT_y -> W[d][y][kx]

@@ -37,7 +37,8 @@ class HolographyEngine(object):
 
     def __del__(self):
         try:
-            if getattr(self, 'handle', None):
+            if getattr(self, 'handle', None) and self.ctx.handle:
+                # (the handle keeps a pointer to the context: destroying it after Context.close() would touch freed memory)
                 self.ctx.lib.adm_holo_destroy(self.handle)
                 self.handle = None
         except Exception:

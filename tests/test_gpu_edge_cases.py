@@ -691,7 +691,7 @@ def test_shifted_holograms_gradients_vs_reference(A, ctx):
     assert abs(eng.loss() - f['loss_64']) < 2e-5 * abs(f['loss_64'])
 
 
-@pytest.mark.parametrize('shape', [(16, 64), (128, 32), (256, 256)])
+@pytest.mark.parametrize('shape', [(16, 64), (128, 32), (256, 256), (1024, 2048)])
 def test_shifted_holograms_vs_oracle_at_other_sizes(A, ctx, shape):
     """The shift stage at non-square fields and other line lengths (lines-per-block geometries of the transforms)."""
     from adorym_amd.holography import HolographyEngine
@@ -714,7 +714,11 @@ def test_shifted_holograms_vs_oracle_at_other_sizes(A, ctx, shape):
     assert abs(eng.loss() - res[0]) < 2e-5 * abs(res[0])
     assert np.linalg.norm(np.sqrt(np.abs(eng.shifted_targets())) - res[2]) < 1e-5 * np.linalg.norm(res[2])
     assert np.linalg.norm(g_obj.get() - res[3]) < 1e-4 * np.linalg.norm(res[3])
-    assert np.linalg.norm(g_sh.get() - res[7]) < 2e-4 * np.linalg.norm(res[7]), (g_sh.get(), res[7])
+    # (for uncorrelated data the shift gradient is a sum of 10^4 ... 10^6 cancelling terms: the yardstick is the fp32 oracle's own error)
+    r32 = O.holo_forward_adjoint(obj_h, np.ones((ny, nx), complex), dists, ident, data.astype(np.float32).astype(np.float64), 17050., 1e-4, shifts=sh,
+                                 dtype='float32')
+    e, e_ref = np.linalg.norm(g_sh.get() - res[7]), np.linalg.norm(r32[7] - res[7])
+    assert e < max(2e-4 * np.linalg.norm(res[7]), 3 * e_ref), (g_sh.get(), res[7], r32[7])
 
 
 def test_shift_refinement_driver_vs_reference(A, ctx, tmp_path):
