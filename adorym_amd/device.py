@@ -228,7 +228,7 @@ class PinnedArray(object):
 
     def __del__(self):
         try:
-            if getattr(self, 'handle', None) and self.ctx.handle:      # (a context closed earlier took its allocations with it)
+            if getattr(self, 'handle', None) and self.ctx.handle:      # (after Context.close() the block simply stays until the process ends)
                 self.array = None
                 self.ctx.lib.adm_host_free(self.ctx.handle, self.handle)
                 self.handle = None
