@@ -27,6 +27,7 @@ import time
 import numpy as np
 
 _MAGIC = b'ADMRDV2\0'
+_ACK = b'\x06'
 _SCAN = 32            # ports tried above the base port
 
 
@@ -176,6 +177,10 @@ class TcpGroup(object):
                     if not hmac.compare_digest(got, hello) or not (0 < r < self.size):
                         raise ConnectionError('foreign connection')
                     c.sendall(_MAGIC)
+                    # ... and the rank confirms that it is still there: a connection it gave up meanwhile (it waited too long for
+                    # this answer and connected again) is closed at its end and fails here instead of being counted
+                    if bytes(_recv_exact(c, 1)) != _ACK:
+                        raise ConnectionError('no confirmation')
                 except Exception:
                     c.close()           # not one of this job's ranks (a port scanner, another job): ignore it
                     continue
@@ -201,6 +206,7 @@ class TcpGroup(object):
                         s.settimeout(max(5.0, deadline - time.time()))
                         s.sendall(hello + struct.pack('!I', self.rank))
                         if bytes(_recv_exact(s, len(_MAGIC))) == _MAGIC:
+                            s.sendall(_ACK)
                             sock, self.port = s, p
                             break
                     except Exception:

@@ -216,7 +216,7 @@ def test_a_rank_that_reconnects_replaces_its_abandoned_connection():
         except Exception as e:
             out[r] = e
 
-    t0 = threading.Thread(target=rank0)
+    t0 = threading.Thread(target=rank0, daemon=True)
     t0.start()
     srv_ready.wait(5)
     # rank 1's abandoned attempt: a complete hello, then the socket is closed without waiting for the answer
@@ -231,7 +231,7 @@ def test_a_rank_that_reconnects_replaces_its_abandoned_connection():
     s.sendall(hello)
     s.close()
     time.sleep(0.2)
-    ts = [threading.Thread(target=rank, args=(r,)) for r in (1, 2)]
+    ts = [threading.Thread(target=rank, args=(r,), daemon=True) for r in (2, 1)]       # (rank 2 first: rank 0 must not count the dead connection as rank 1 and stop listening)
     [t.start() for t in ts]
     [t.join(30) for t in ts + [t0]]
     assert out.get(0) == {'x': 7} and out.get(1) == {'x': 7} and out.get(2) == {'x': 7}, out
