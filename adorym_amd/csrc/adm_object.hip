@@ -494,37 +494,60 @@ struct TileGeom {
 // adm_tile_grad_accumulate_range)
 __global__ __launch_bounds__(256) void cover_build_kernel(const int2* __restrict__ pos, int b0, int B, TileGeom g,
                                                           unsigned* __restrict__ cover, int* __restrict__ overflow) {
-    // The positions go through LDS, 256 at a time: read one by one from global memory the loop below was a chain of B dependent
-    // scalar loads (~0.2 us each: 15 us per 64 positions whatever the number of pixels).
+    // The positions are read 256 at a time, and only those whose tile reaches this block's 32 x 8 pixels go on -- in position
+    // order (ballot + prefix count per wave) -- to the per-pixel loop: a pixel used to walk ALL positions of the batch, one
+    // dependent load each (15 us per 64 positions whatever the number of pixels; 29 us for the 200 entries of a tiled
+    // multi-distance launch, longer than the multislice kernel beside it).
     __shared__ int2 sp[256];
+    __shared__ int sb[256];
+    __shared__ int wcnt[4];
     const int x = blockIdx.x * 32 + (threadIdx.x & 31);
     const int r = blockIdx.y * 8 + (threadIdx.x >> 5);
     const bool live = x < g.Xp && r < g.nrows;
     const int y = g.row0 + r;
+    const int bx_lo = blockIdx.x * 32, by_lo = g.row0 + blockIdx.y * 8;         // the block's pixels: [bx_lo, +32) x [by_lo, +8)
     // structure-of-arrays: entry c of pixel (r, x) at cover[(c * nrows + r) * Xp + x], so that the lanes of a wave
     // (consecutive x) read consecutive words
     const size_t cplane = (size_t)g.nrows * g.Xp;
     unsigned* out = cover + (size_t)(live ? r : 0) * g.Xp + (live ? x : 0);
     int cnt = 0;
     const unsigned per_pos = (unsigned)g.n_steps * g.row_elems;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int c0 = b0; c0 < B; c0 += 256) {
-        const int nb = min(256, B - c0);
+        const int b = c0 + (int)threadIdx.x;
+        int2 p = make_int2(0, 0);
+        bool hit = false;
+        if (b < B) {
+            p = pos[b];
+            const int ty = p.x + g.pad_y0, tx = p.y + g.pad_x0;                   // the tile's first padded row / column
+            hit = ty < by_lo + 8 && ty + g.Py > by_lo && tx < bx_lo + 32 && tx + g.Px > bx_lo;
+        }
+        const unsigned long long m = __ballot(hit);
+        __syncthreads();                                                          // (the previous chunk's candidates are consumed)
+        if (lane == 0) wcnt[wave] = __popcll(m);
         __syncthreads();
-        if ((int)threadIdx.x < nb) sp[threadIdx.x] = pos[c0 + threadIdx.x];
+        int off = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) off += wcnt[w]; n += wcnt[w]; }
+        if (hit) {
+            const int k = off + __popcll(m & ((1ull << lane) - 1ull));
+            sp[k] = p;
+            sb[k] = b;
+        }
         __syncthreads();
         if (!live) continue;
-        for (int j = 0; j < nb; ++j) {
-            const int2 p = sp[j];
-            const int row = y - (p.x + g.pad_y0), col = x - (p.y + g.pad_x0);
+        for (int j = 0; j < n; ++j) {
+            const int2 q = sp[j];
+            const int row = y - (q.x + g.pad_y0), col = x - (q.y + g.pad_x0);
             if (row >= 0 && row < g.Py && col >= 0 && col < g.Px) {
                 if (cnt < ADM_MAXCOVER) {
-                    unsigned off;
-                    if (g.pixel_major) off = (unsigned)(row * g.Px + col);
+                    unsigned off_e;
+                    if (g.pixel_major) off_e = (unsigned)(row * g.Px + col);
                     else {
                         const int tid = (row / g.LPW) * 64 + (row % g.LPW) * g.G + col % g.R2;
-                        off = adm::ws_elem_offset(g.R1, g.NT, col / g.R2, tid);
+                        off_e = adm::ws_elem_offset(g.R1, g.NT, col / g.R2, tid);
                     }
-                    out[(size_t)(1 + cnt) * cplane] = (unsigned)(c0 + j) * per_pos + off;
+                    out[(size_t)(1 + cnt) * cplane] = (unsigned)sb[j] * per_pos + off_e;
                 }
                 ++cnt;
             }
