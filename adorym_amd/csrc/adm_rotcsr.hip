@@ -60,24 +60,54 @@ __global__ __launch_bounds__(256) void rotcsr_init_kernel(int* box, int nblk) {
 __global__ __launch_bounds__(256) void rotcsr_emit_kernel(const uint16_t* __restrict__ coords, int X, int Z, int Yp, int Xp, int pad_x0,
                                                           unsigned long long* __restrict__ keys, float* __restrict__ vals,
                                                           int* __restrict__ box) {
+    // The source boxes of the 16 x 16 target patches: every entry used to issue four global atomics on its patch's box -- a block's
+    // 1024 entries land in a handful of patches, i.e. ~1000 serialised atomics per address whatever the object size (0.23 - 0.27 ms
+    // per angle for 64^3 and for 256^3 alike).  Now a block collects its patches' boxes in LDS (a 64-slot open-addressing table,
+    // LDS atomics) and issues the global atomics once per patch it touched.  min / max: the result does not depend on the order.
+    __shared__ int skey[64];
+    __shared__ int sbox[64][4];
+    if (threadIdx.x < 64) {
+        skey[threadIdx.x] = -1;
+        sbox[threadIdx.x][0] = 0x7fffffff; sbox[threadIdx.x][1] = 0x7fffffff; sbox[threadIdx.x][2] = -1; sbox[threadIdx.x][3] = -1;
+    }
+    __syncthreads();
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= X * Z) return;
-    const int xr = p / Z, zr = p - xr * Z;
-    const Bilin4 b = bilin4(coords, xr, zr, X, Z);
-    const unsigned src = (unsigned)((size_t)zr * Yp * Xp + pad_x0 + xr);
-    const int nbx = (X + 15) / 16;
-    const unsigned long long none = (unsigned long long)(X * Z) << 32;
+    if (p < X * Z) {
+        const int xr = p / Z, zr = p - xr * Z;
+        const Bilin4 b = bilin4(coords, xr, zr, X, Z);
+        const unsigned src = (unsigned)((size_t)zr * Yp * Xp + pad_x0 + xr);
+        const int nbx = (X + 15) / 16;
+        const unsigned long long none = (unsigned long long)(X * Z) << 32;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool valid = b.w[j] != 0.f;
-        keys[4 * (size_t)p + j] = valid ? (((unsigned long long)b.idx[j] << 32) | src) : none;
-        vals[4 * (size_t)p + j] = b.w[j];
-        if (valid) {
-            const int tx = b.idx[j] / Z, tz = b.idx[j] - tx * Z;
-            int* q = box + 4 * ((tz / 16) * nbx + tx / 16);
-            atomicMin(q + 0, xr); atomicMin(q + 1, zr);
-            atomicMax(q + 2, xr); atomicMax(q + 3, zr);
+        for (int j = 0; j < 4; ++j) {
+            const bool valid = b.w[j] != 0.f;
+            keys[4 * (size_t)p + j] = valid ? (((unsigned long long)b.idx[j] << 32) | src) : none;
+            vals[4 * (size_t)p + j] = b.w[j];
+            if (valid) {
+                const int tx = b.idx[j] / Z, tz = b.idx[j] - tx * Z;
+                const int patch = (tz / 16) * nbx + tx / 16;
+                int slot = patch & 63, tries = 0;
+                for (; tries < 64; ++tries) {
+                    const int old = atomicCAS(&skey[slot], -1, patch);
+                    if (old == -1 || old == patch) break;
+                    slot = (slot + 1) & 63;
+                }
+                if (tries < 64) {
+                    atomicMin(&sbox[slot][0], xr); atomicMin(&sbox[slot][1], zr);
+                    atomicMax(&sbox[slot][2], xr); atomicMax(&sbox[slot][3], zr);
+                } else {                      // (more than 64 patches under one block: straight to memory)
+                    int* q = box + 4 * patch;
+                    atomicMin(q + 0, xr); atomicMin(q + 1, zr);
+                    atomicMax(q + 2, xr); atomicMax(q + 3, zr);
+                }
+            }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && skey[threadIdx.x] >= 0) {
+        int* q = box + 4 * skey[threadIdx.x];
+        atomicMin(q + 0, sbox[threadIdx.x][0]); atomicMin(q + 1, sbox[threadIdx.x][1]);
+        atomicMax(q + 2, sbox[threadIdx.x][2]); atomicMax(q + 3, sbox[threadIdx.x][3]);
     }
 }
 
