@@ -117,6 +117,7 @@ SIGNATURES = {
     'adm_rotate_adj_csr': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I]),
     'adm_rotate_adj_staged': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I]),
     'adm_rotate_adj_staged_stack': (_I, [_VP, _VP, _VP, _I, _VP, _VP, _SZ]),
+    'adm_rotation_table_build': (_I, [_VP, _I, _I, C.c_float, C.c_float, _VP]),
     'adm_rotation_csr_scratch_bytes': (_SZ, [_VP]),
     'adm_rotation_csr_build': (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _SZ]),
     'adm_multislice_fwd_adj': (_I, [_VP, _VP, _VP, _VP, _I, _VP, _I, _VP, _VP, _VP, _F, _VP, _SZ]),

@@ -162,6 +162,35 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 using namespace adm;
 
+// The reference's fp16 lookup table of one angle (adorym/util.py:446-477, 492-516) formed on the device: float32 arithmetic with one
+// rounding per multiply and per add -- `#pragma clang fp contract(off)`: hipcc's __fmul_rn / __fadd_rn are plain operators and were
+// fused into an fma (2 of 8192 entries off by one half-ulp tie at 0.63 rad) --, cos / sin of the angle
+// handed over as the float32 values the host computed, round-to-nearest-even to half: the same bits as adorym_amd.util.rotation_lookup
+// (0.45 ms of NumPy per angle on the host, which the driver paid at every angle change).
+__global__ __launch_bounds__(256) void rot_table_kernel(int X, int Z, float c, float s, __half* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= X * Z) return;
+    const int x = p / Z, z = p - x * Z;
+    const float xc = (float)((double)x - (double)(Z - 1) / 2.0);      // (the reference subtracts the OTHER axis' centre, util.py:459-460)
+    const float zc = (float)((double)z - (double)(X - 1) / 2.0);
+    const float cx = (float)((double)(X - 1) / 2.0), cz = (float)((double)(Z - 1) / 2.0);
+    const float a0 = c * xc, a1 = (-s) * zc, b0 = s * xc, b1 = c * zc;
+    const float x_old = (a0 + a1) + cx;
+    const float z_old = (b0 + b1) + cz;
+    out[2 * (size_t)p] = __float2half_rn(x_old);
+    out[2 * (size_t)p + 1] = __float2half_rn(z_old);
+}
+
+extern "C" int adm_rotation_table_build(adm_ctx* ctx, int X, int Z, float cos_theta, float sin_theta, uint16_t* coords) {
+    if (!ctx || !coords) return fail(ADM_ERR_INVALID, "adm_rotation_table_build: null argument");
+    if (X <= 0 || Z <= 0) return fail(ADM_ERR_INVALID, "adm_rotation_table_build: bad size");
+    hipLaunchKernelGGL(rot_table_kernel, dim3((unsigned)(((size_t)X * Z + 255) / 256)), dim3(256), 0, ctx->stream, X, Z, cos_theta, sin_theta,
+                       reinterpret_cast<__half*>(coords));
+    ADM_HIP(hipGetLastError());
+    return ADM_OK;
+}
+
 extern "C" size_t adm_rotation_csr_scratch_bytes(const adm_plan* plan) {
     if (!plan) return 0;
     const size_t n = 4 * (size_t)plan->d.obj_x * plan->d.obj_z;

@@ -47,7 +47,12 @@ class RotationTable(object):
     def __init__(self, ctx, obj_size, theta, coords_fp16=None):
         self.ctx = ctx
         self.obj_size = tuple(int(v) for v in obj_size)
-        self.host = rotation_lookup(self.obj_size, theta) if coords_fp16 is None else np.asarray(coords_fp16, dtype=np.float16)
+        # the fp16 table itself is formed on the device (adm_rotation_table_build: same bits as util.rotation_lookup, which costs
+        # 0.45 ms of NumPy per angle); a host copy exists only if one was handed in or somebody asks for it (``host``)
+        self._theta = theta
+        self._host = None if coords_fp16 is None else np.asarray(coords_fp16, dtype=np.float16)
+        if self._host is None and os.environ.get('ADM_DEVICE_ROT_TABLE', '1') != '1':
+            self._host = rotation_lookup(self.obj_size, theta)          # (the table from the host, as before round 6)
         # ONE allocation per angle: [fp16 table | ptr | src | w | lsrc | boxes]; the table goes up through the context's
         # pinned ring (no stream synchronisation when the driver meets a new angle in the middle of an epoch)
         _, X, Z = self.obj_size
@@ -61,7 +66,12 @@ class RotationTable(object):
         self.coords = sub(0, (X * Z, 2), np.uint16)
         self._parts = (sub(1, (X * Z + 1,), np.int32), sub(2, (n,), np.int32), sub(4, (n,), np.uint16), sub(3, (n,), np.float32),
                        sub(5, (nblk, 4), np.int32))          # ptr, src, lsrc, w, boxes
-        ctx.uploader(sizes[0]).upload(self.coords, np.ascontiguousarray(self.host).view(np.uint16).reshape(X * Z, 2))
+        if self._host is not None:
+            ctx.uploader(sizes[0]).upload(self.coords, np.ascontiguousarray(self._host).view(np.uint16).reshape(X * Z, 2))
+        else:
+            th32 = np.float32(theta)
+            check(ctx.lib.adm_rotation_table_build(ctx.handle, X, Z, float(np.cos(th32, dtype=np.float32)), float(np.sin(th32, dtype=np.float32)),
+                                                   self.coords.ptr))
         self._csr = None
         self._csr_key = None
         th = float(theta)
@@ -70,6 +80,13 @@ class RotationTable(object):
     @property
     def ptr(self):
         return self.coords.ptr
+
+    @property
+    def host(self):
+        """The table on the host (float16 [X*Z, 2]): the reference arithmetic in NumPy, evaluated on first use."""
+        if self._host is None:
+            self._host = rotation_lookup(self.obj_size, self._theta)
+        return self._host
 
     def csr(self, plan):
         """(ptr, src, lsrc, w, boxes) device arrays of adm_rotate_adj_staged, built on the GPU (adm_rotation_csr_build,

@@ -264,6 +264,11 @@ int adm_rotate_adj_staged(adm_plan* plan, const float* grad_rot, const int32_t* 
  * angle order by a second launch -- the same additions, the same bits, without a chain of n_tables rounds inside every block. */
 int adm_rotate_adj_staged_stack(adm_plan* plan, const float* grad_rot, const void* tables_dev, int n_tables, float* grad_obj,
                                 float* scratch, size_t scratch_bytes);
+/* The fp16 lookup table of one angle formed on the device: what save_rotation_lookup / read_origin_coords hand to apply_rotation
+ * (adorym/util.py:446-477, 492-525) -- source coordinates (x_old, z_old) of every rotated-frame cell, flat index x * Z + z, float32
+ * arithmetic with one rounding per operation, stored as float16; bit-identical to the reference's table.  cos_theta / sin_theta:
+ * np.cos / np.sin of float32(theta) evaluated in float32 on the host (the reference's torch scalars).  coords: device uint16 [X*Z][2]. */
+int adm_rotation_table_build(adm_ctx* ctx, int X, int Z, float cos_theta, float sin_theta, uint16_t* coords);
 /* Builds, on the device, everything adm_rotate_adj_staged needs for one angle from the fp16 lookup table `coords`
  * (device, [X*Z][2]): csr_ptr [X*Z+1], csr_src / csr_lsrc / csr_w [4*X*Z] (only the first csr_ptr[X*Z] entries are
  * meaningful), boxes [ceil(Z/16)*ceil(X/16)][4].  Rows ordered by target voxel, entries by ascending source offset: the same

@@ -559,3 +559,17 @@ def test_probe_gradient_through_shifts_of_a_large_batch_is_bit_reproducible(A, c
         eng.multislice(probe, grad_probe=gp, shifts=ctx.array(shifts.get()[lo:lo + 150]), grad_shifts=ctx.zeros((150, 2)), grad_scale=2.0 / (B * eng.n_det))
         acc += gp.get()
     assert np.abs(acc - outs[0][0]).max() <= 2e-5 * np.abs(acc).max()
+
+
+@pytest.mark.parametrize('size', [(8, 64, 64), (4, 48, 80), (4, 256, 256), (2, 37, 53)])
+def test_device_built_rotation_table_is_the_reference_table_bitwise(A, ctx, size):
+    """adm_rotation_table_build (float32, one rounding per operation, round-to-nearest-even to half) against
+    adorym_amd.util.rotation_lookup, which golden F4 pins to the reference's table bit for bit: 25 angles, cubic and non-cubic
+    cross-sections (the reference subtracts the OTHER axis' centre)."""
+    from adorym_amd.util import rotation_lookup
+    for th in np.concatenate([np.linspace(0, 2 * np.pi, 21, dtype='float32'), np.float32([0.4, 0.78, -1.3, 3.0])]):
+        tab = A.RotationTable(ctx, size, th)
+        want = rotation_lookup(size, th)
+        got = tab.coords.get().view(np.float16)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (size, float(th), int((got != want).sum()))
+        assert np.array_equal(tab.host, want)

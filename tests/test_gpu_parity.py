@@ -145,6 +145,8 @@ def test_rotation_vs_reference(A, ctx, name):
     # the deterministic CSR-gather form of the same operator
     tab = A.RotationTable(ctx, size, theta)
     assert np.array_equal(tab.host, g[name + '_coords'])
+    # ... and the table the product actually uses, formed on the DEVICE (adm_rotation_table_build): the reference's bits
+    assert np.array_equal(tab.coords.get().view(np.float16), g[name + '_coords'])
     d_g2 = ctx.zeros(obj.shape)
     eng.rotate_adjoint(d_g2, tab)
     assert np.abs(d_g2.get() - g[name + '_adj_64']).max() < 3e-5
