@@ -583,6 +583,10 @@ def reconstruct_ptychography(
     if rool:
         _not_implemented(not isinstance(forward_model, PtychographyModel), 'rotate_out_of_loop with a user-defined forward model')
         fuse_per_angle = False
+    if is_multi_dist:
+        # (the multi-distance models evaluate one reference minibatch per call: their loss is a mean over distances x tiles, and
+        # 'per angle' adds the minibatches' gradients -- a fused call would average over all of them instead)
+        fuse_per_angle = False
     print_flush('Forward model: {}.'.format(type(forward_model).__name__), sto_rank, rank, **stdout_options)
 
     if regularizers is None:

@@ -289,3 +289,38 @@ def test_two_ranks_vs_reference_driver_as_two_processes(tmp_path, transport):
     e, e_ref = np.linalg.norm(res[0]['obj'] - o64) / upd, np.linalg.norm(o32 - o64) / upd
     print('world 2 (%s): final object vs the reference two-process run, relative to the update: %.2e (reference fp32: %.2e)' % (transport, e, e_ref))
     assert e < max(5e-3, 3 * e_ref), (e, e_ref)
+
+
+def test_per_angle_update_scheme_adds_the_minibatch_gradients(A, ctx, tmp_path):
+    """update_scheme='per angle' with tiled data: the three minibatches of the (one) angle are evaluated at the same object, each
+    loss a mean over ITS tiles x distances, their gradients are ADDED and one Adam step follows (adorym/ptychography.py:1063-1066,
+    1095-1099) -- restated with the oracle's single-minibatch function; the driver must not fuse them into one averaged call."""
+    f = np.load(F18)
+    C = cases.C5TILES
+    rn = 'ri_szw4'
+    inp = cases.c5tiles_inputs(rn)
+    N = C['N']
+    prj = f[rn + '_prj']
+    st = A.reconstruct_ptychography(
+        fname=prj, obj_size=(N, N, 1), probe_pos=inp['pos'], theta_st=0, theta_end=0, n_theta=1, two_d_mode=True, energy_ev=C['energy_ev'],
+        psize_cm=C['psize_cm'], free_prop_cm=np.array(C['dists_cm']), minibatch_size=C['minibatch_size'], n_epochs=1,
+        initial_guess=[inp['guess'][0], inp['guess'][1]], probe_type='plane', raw_data_type='magnitude', unknown_type='real_imag', gamma=0,
+        alpha_d=0, alpha_b=0, optimizer='adam', learning_rate=C['learning_rate'], n_dp_batch=20, randomize_probe_pos=False,
+        safe_zone_width=inp['szw'], update_scheme='per angle', save_path=str(tmp_path), output_folder='pa', store_checkpoint=False,
+        use_checkpoint=False, return_state=True)
+    obj0 = np.stack(_init(inp), -1).astype(np.float64)
+    batches = O.epoch_task_list(0, 1, len(inp['pos']), C['minibatch_size'], 1, 'per angle', two_d_mode=True)
+    g, losses = np.zeros_like(obj0), []
+    nd, nb = len(C['dists_cm']), len(inp['pos'])
+    for i in range(len(batches)):
+        _, ind = O.rank_batch(batches, i, 0, C['minibatch_size'], 1)
+        full = np.concatenate([ind + k * nb for k in range(nd)])
+        l, _, gi = O.multidist_tiles_forward_adjoint(obj0, np.ones((N, N), complex), inp['pos'][ind], (C['SUB'], C['SUB']), inp['szw'], C['dists_cm'],
+                                                     prj[0, full].astype(np.float64), C['energy_ev'], C['psize_cm'])
+        g += gi
+        losses.append(l)
+    want, _, _ = O.adam_step(obj0, g, np.zeros_like(obj0), np.zeros_like(obj0), 0, step_size=C['learning_rate'])
+    assert abs(st['losses'][-1] - losses[-1]) < 2e-4 * losses[-1]          # (the log carries the angle's last minibatch)
+    x = np.stack([st['delta'], st['beta']], -1)
+    upd = np.linalg.norm(want - obj0)
+    assert upd > 0 and np.linalg.norm(x - want) < 5e-3 * upd
