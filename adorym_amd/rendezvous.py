@@ -144,6 +144,9 @@ class TcpGroup(object):
             return
         proof = hmac.new(token.encode('utf-8'), b'adm-rendezvous:' + job.encode('utf-8'), hashlib.sha256).digest()
         hello = _MAGIC + struct.pack('!I', len(job)) + job.encode('utf-8') + proof
+        # ... and rank 0 proves itself to the rank that knocks (the ranks scan a few ports: on a machine shared with other jobs of
+        # this package -- several users' test runs on one host -- the first listener found need not be ours)
+        answer = _MAGIC + hmac.new(token.encode('utf-8'), b'adm-rendezvous-root:' + job.encode('utf-8'), hashlib.sha256).digest()
         ports = [int(port)] if exact_port else [int(port) + k for k in range(_SCAN)]
         deadline = time.time() + self.timeout
         if self.rank == 0:
@@ -176,7 +179,7 @@ class TcpGroup(object):
                     r = struct.unpack('!I', bytes(_recv_exact(c, 4)))[0]
                     if not hmac.compare_digest(got, hello) or not (0 < r < self.size):
                         raise ConnectionError('foreign connection')
-                    c.sendall(_MAGIC)
+                    c.sendall(answer)
                     # ... and the rank confirms that it is still there: a connection it gave up meanwhile (it waited too long for
                     # this answer and connected again) is closed at its end and fails here instead of being counted
                     if bytes(_recv_exact(c, 1)) != _ACK:
@@ -200,12 +203,19 @@ class TcpGroup(object):
                         s = socket.create_connection((addr, p), timeout=2.0)
                     except OSError:
                         continue
+                    if s.getsockname() == s.getpeername():
+                        # TCP self-connection: nobody listens on p yet and the kernel gave this socket p as its OWN port (the ports
+                        # of one-node jobs come from the ephemeral range).  The rank would read its own hello back -- which begins
+                        # with the greeting -- and take the rest of it for frames ("collective mismatch ... the peer sent ''":
+                        # seen twice on loaded boxes, where rank 0 is slow to bind).
+                        s.close()
+                        continue
                     try:
                         # rank 0 answers when it gets to this connection -- on a loaded machine that can take a while: wait for it
                         # as long as the rendezvous may take (a connection rank 0 refuses is CLOSED by it, which ends the wait)
                         s.settimeout(max(5.0, deadline - time.time()))
                         s.sendall(hello + struct.pack('!I', self.rank))
-                        if bytes(_recv_exact(s, len(_MAGIC))) == _MAGIC:
+                        if hmac.compare_digest(bytes(_recv_exact(s, len(answer))), answer):
                             s.sendall(_ACK)
                             sock, self.port = s, p
                             break

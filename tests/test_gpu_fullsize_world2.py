@@ -113,6 +113,7 @@ def test_world2_exchange_at_config4_size(tmp_path, transport, world):
     orc = {dt: subprocess.Popen([sys.executable, os.path.join(HERE, 'fullsize_oracle.py'), str(tmp_path / ('o_%s.npy' % dt)), 'immediate', dt,
                                  prj_path, '1', str(world)]) for dt in ('float64', 'float32')}
     try:
+        os.environ['ADM_RDV_TOKEN'] = __import__('secrets').token_hex(16)      # this job's secret: other jobs on the machine are not admitted
         mpc = mp.get_context('spawn')
         q = mpc.Queue()
         port = _free_port()

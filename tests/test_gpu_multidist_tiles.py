@@ -270,6 +270,7 @@ def test_two_ranks_vs_reference_driver_as_two_processes(tmp_path, transport):
     import multiprocessing as mp
     import socket
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['ADM_RDV_TOKEN'] = __import__('secrets').token_hex(16)      # this job's secret: other jobs on the machine are not admitted
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     procs = [mpc.Process(target=_w2_worker, args=(r, 2, port, str(tmp_path), q, transport)) for r in range(2)]

@@ -94,6 +94,7 @@ def _rank(rank, world, port, case, q):
 
 
 def _run(world, case, timeout=300):
+    os.environ['ADM_RDV_TOKEN'] = __import__('secrets').token_hex(16)      # this job's secret: other jobs on the machine are not admitted
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     port = _free_port()
@@ -202,6 +203,7 @@ def test_a_peer_that_leaves_the_sequence_is_a_clean_error():
     """Rank 1 stops before the second update.  Rank 0's wait kernel gives up after ADM_P2P_TIMEOUT_S, the fused kernel behind it
     touches nothing, and the next status check raises naming the rank that did not arrive -- no hang, the GPU stays usable."""
     case = dict(n=2 * 4096, opt='adam', options={'step_size': 1e-3}, steps=2, seed=9, skip_rank=1, skip_step=1, env={'ADM_P2P_TIMEOUT_S': '1.5'})
+    os.environ['ADM_RDV_TOKEN'] = __import__('secrets').token_hex(16)      # this job's secret: other jobs on the machine are not admitted
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     port = _free_port()

@@ -132,6 +132,7 @@ def run_world2(tmp_path, n_use, extra, env=None, emulate=False, transport='host'
     read and write each other's device buffers; one fused kernel per update).  ``world`` processes, all on GPU 0."""
     import multiprocessing as mp
     port = _free_port()
+    os.environ['ADM_RDV_TOKEN'] = __import__('secrets').token_hex(16)      # this job's secret: other jobs on the machine are not admitted
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
     os.makedirs(str(tmp_path), exist_ok=True)

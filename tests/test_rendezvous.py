@@ -235,3 +235,33 @@ def test_a_rank_that_reconnects_replaces_its_abandoned_connection():
     [t.start() for t in ts]
     [t.join(30) for t in ts + [t0]]
     assert out.get(0) == {'x': 7} and out.get(1) == {'x': 7} and out.get(2) == {'x': 7}, out
+
+
+def test_a_rank_never_takes_a_tcp_self_connection_for_rank_0():
+    """Nobody listens yet and the kernel hands the connecting socket the target port as its own: the socket is connected to ITSELF and
+    reads its own hello back, which begins with the greeting.  Twice a GPU test failed that way on a loaded box ("collective mismatch
+    ... the peer sent ''").  Forced here: the socket is bound to the port it then connects to; the rank must see through it (the answer of
+    rank 0 carries rank 0's own proof, and a socket whose two ends are the same address is dropped) and keep looking until its time-out."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    from adorym_amd import rendezvous as R
+    port = _free_port()
+    real_create = socket.create_connection
+
+    def self_connecting(addr, timeout=None, **kw):
+        s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        s.settimeout(timeout)
+        s.bind(('127.0.0.1', addr[1]))
+        s.connect(addr)                      # simultaneous open with itself
+        return s
+
+    socket.create_connection = self_connecting
+    try:
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match='could not reach rank 0'):
+            R.TcpGroup(1, 2, '127.0.0.1', port, job='j', exact_port=True, timeout=1.0, token='t')
+        assert time.time() - t0 < 20
+    finally:
+        socket.create_connection = real_create
